@@ -1,0 +1,705 @@
+// scvod_capi.hip -- the extern "C" boundary of libscvod.so (declared in include/scvod.h).
+// Owns the device arena, host staging and the HIP stream; no torch types, no exceptions
+// across the boundary.  GPU-only: every entry point fails loudly without a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scvod.h"
+#include "scvod_kernels.h"
+
+using namespace scvod;
+
+namespace {
+
+struct TimingEntry {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct scvod_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    scvod_params params;
+    scvod_pw_params pw;
+    DevParams dev;
+    int64_t cap_pts = 0;
+    int32_t cap_scans = 0;
+    void* arena_base = nullptr;
+    size_t arena_bytes = 0;
+    Arena A;             // carved pointers (pts / scan_off filled per call)
+    float4* d_in = nullptr;        // ctx-owned input buffer for the per-scan host API
+    int32_t* d_scan_off = nullptr; // [cap_scans+1]
+    // tracking buffers
+    int32_t* t_hit = nullptr;
+    uint64_t* t_work = nullptr;
+    int32_t* t_uniq = nullptr;
+    int32_t* t_begin = nullptr;
+    int32_t* t_pair = nullptr;
+    int32_t* t_count = nullptr;
+    float* t_T = nullptr;
+    // last batch
+    bool batch_valid = false;
+    std::vector<int32_t> h_scan_off;
+    std::vector<int32_t> h_counts;
+    bool counts_valid = false;
+    hipStream_t last_stream = nullptr;
+    int32_t last_track_clusters = 0;
+    // host staging for scvod_scan_result
+    std::vector<uint8_t> r_cls;
+    std::vector<int32_t> r_ground, r_nonground, r_apri_src, r_rejected, r_vox_key, r_vox_begin, r_vox_pts;
+    std::vector<scvod_patch_plane> r_planes;
+    std::vector<scvod_apri> r_apri;
+    std::vector<float> r_vox_av, r_vox_cov;
+    // timing
+    bool timing = false;
+    std::vector<TimingEntry> tim;
+    size_t tim_used = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(scvod_ctx* c, int code, const char* fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) return fail(ctx, SCVOD_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    unsigned char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t count) {
+        off = align_up(off, 256);
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
+    const size_t N = (size_t)c->cap_pts, B = (size_t)c->cap_scans;
+    Carver k{base};
+    Arena& A = c->A;
+    c->d_in = k.take<float4>(N);
+    c->d_scan_off = k.take<int32_t>(B + 1);
+    A.pid = k.take<int16_t>(N);
+    A.keys = k.take<uint64_t>(N);
+    A.seg = k.take<uint32_t>(N);
+    A.scratch_xyz = k.take<float>(4 * N);
+    A.scratch_mask = k.take<uint8_t>(N);
+    A.patch_count = k.take<int32_t>(B * kMaxPatches);
+    A.patch_cursor = k.take<int32_t>(B * kMaxPatches);
+    A.patch_off = k.take<int32_t>(B * (kMaxPatches + 1));
+    A.patch_rec = k.take<PatchRec>(B * kMaxPatches);
+    A.planes = k.take<scvod_patch_plane>(B * kMaxPatches);
+    A.emit_off = k.take<int32_t>(B * kMaxPatches * 4);
+    A.cls = k.take<uint8_t>(N);
+    A.ground_idx = k.take<int32_t>(N);
+    A.nonground_idx = k.take<int32_t>(N);
+    A.apri = k.take<scvod_apri>(N);
+    A.apri_src = k.take<int32_t>(N);
+    A.rejected_src = k.take<int32_t>(N);
+    A.counts = k.take<int32_t>(B * 8);
+    A.vb_count = k.take<int32_t>(B * kMaxBuckets);
+    A.vb_cursor = k.take<int32_t>(B * kMaxBuckets);
+    A.vb_off = k.take<int32_t>(B * (kMaxBuckets + 1));
+    A.vb_nvox = k.take<int32_t>(B * kMaxBuckets);
+    A.vox_off = k.take<int32_t>(B * (kMaxBuckets + 1));
+    A.vkeys = k.take<uint64_t>(N);
+    A.tmp_vox_key = k.take<int32_t>(N);
+    A.tmp_vox_begin = k.take<int32_t>(N);
+    A.tmp_vox_av = k.take<float>(N);
+    A.tmp_vox_cov = k.take<float>(N);
+    A.vox_key = k.take<int32_t>(N);
+    A.vox_pt_begin = k.take<int32_t>(N + B);
+    A.vox_pts = k.take<int32_t>(N);
+    A.vox_av = k.take<float>(N);
+    A.vox_cov = k.take<float>(N);
+    c->t_hit = k.take<int32_t>(N);
+    c->t_work = k.take<uint64_t>(N);
+    c->t_uniq = k.take<int32_t>(N);
+    c->t_begin = k.take<int32_t>(N + 1);
+    c->t_pair = k.take<int32_t>(N);
+    c->t_count = k.take<int32_t>(N);
+    c->t_T = k.take<float>(12 * (B + 1));
+    *total = align_up(k.off, 256);
+}
+
+void build_dev_params(scvod_ctx* c) {
+    const scvod_params& p = c->params;
+    const scvod_pw_params& w = c->pw;
+    DevParams& D = c->dev;
+    memset(&D, 0, sizeof(D));
+    BinParams& b = D.bin;
+    b.min_dis = p.min_dis;
+    b.max_dis = p.max_dis;
+    b.min_angle = p.min_angle;
+    b.max_angle = p.max_angle;
+    b.min_azimuth = p.min_azimuth;
+    b.max_azimuth = p.max_azimuth;
+    b.range_res = p.range_res;
+    b.sector_res = p.sector_res;
+    b.azimuth_res = p.azimuth_res;
+    scvod_grid_dims(&p, &b.range_num, &b.sector_num, &b.azimuth_num, &b.bin_num);
+    CzmParams& z = D.czm;
+    z.min_range = w.min_range;
+    z.max_range = w.max_range;
+    // patchwork.h:83-94
+    const double z2 = (7 * w.min_range + w.max_range) / 8.0;
+    const double z3 = (3 * w.min_range + w.max_range) / 4.0;
+    const double z4 = (w.min_range + w.max_range) / 2.0;
+    z.zone_min[0] = w.min_range;
+    z.zone_min[1] = z2;
+    z.zone_min[2] = z3;
+    z.zone_min[3] = z4;
+    z.ring_size[0] = (z2 - w.min_range) / w.num_rings_each_zone[0];
+    z.ring_size[1] = (z3 - z2) / w.num_rings_each_zone[1];
+    z.ring_size[2] = (z4 - z3) / w.num_rings_each_zone[2];
+    z.ring_size[3] = (w.max_range - z4) / w.num_rings_each_zone[3];
+    int base = 0;
+    for (int k = 0; k < 4; ++k) {
+        z.sector_size[k] = 2 * M_PI / w.num_sectors_each_zone[k];
+        z.num_rings[k] = w.num_rings_each_zone[k];
+        z.num_sectors[k] = w.num_sectors_each_zone[k];
+        z.patch_base[k] = base;
+        base += w.num_rings_each_zone[k] * w.num_sectors_each_zone[k];
+        z.elevation_thr[k] = w.elevation_thr[k];
+        z.flatness_thr[k] = w.flatness_thr[k];
+    }
+    z.num_patches = base;
+    const double sensor_height = (double)p.sensor_height;  // set_sensor(const double&), ssc.cpp:93
+    z.z_cut = -1.8 * sensor_height;
+    z.seed_margin_z = w.adaptive_seed_selection_margin * sensor_height;
+    z.th_seeds = w.th_seeds;
+    z.th_dist = w.th_dist;
+    z.uprightness_thr = w.uprightness_thr;
+    z.num_iter = w.num_iter;
+    z.num_lpr = w.num_lpr;
+    z.num_min_pts = w.num_min_pts;
+    z.num_rings_of_interest = w.num_rings_of_interest;
+    D.n_patches = base;
+    // voxel buckets: keys of filtered points lie in [-(R*S+S+1), bin_num)
+    D.key_off = (int64_t)b.range_num * b.sector_num + b.sector_num + 1;
+    int64_t range = (int64_t)b.bin_num + D.key_off + 1;
+    int shift = 12;
+    while (((range >> shift) + 1) > kMaxBuckets) ++shift;
+    D.vb_shift = shift;
+    D.n_buckets = (int32_t)((range >> shift) + 1);
+}
+
+void timer_hook(void* user, const char* name, int begin) {
+    scvod_ctx* c = (scvod_ctx*)user;
+    if (!c->timing) return;
+    hipStream_t st = c->last_stream;
+    if (begin) {
+        if (c->tim_used == c->tim.size()) {
+            TimingEntry t;
+            t.name = name;
+            hipEventCreate(&t.e0);
+            hipEventCreate(&t.e1);
+            c->tim.push_back(t);
+        }
+        c->tim[c->tim_used].name = name;
+        hipEventRecord(c->tim[c->tim_used].e0, st);
+    } else {
+        hipEventRecord(c->tim[c->tim_used].e1, st);
+        c->tim_used++;
+    }
+}
+
+int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_scans, hipStream_t st,
+              int do_patchwork, int apply_filter, int do_voxels, int sync) {
+    if (!c) return SCVOD_ERR_INVALID;
+    if (n_scans <= 0 || !h_off || !d_xyzi) return fail(c, SCVOD_ERR_INVALID, "empty batch");
+    if (n_scans > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "n_scans %d > capacity %d", n_scans, c->cap_scans);
+    int64_t total = (int64_t)h_off[n_scans] - h_off[0];
+    if (h_off[0] != 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets[0] must be 0");
+    if (total > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%lld points > capacity %lld", (long long)total, (long long)c->cap_pts);
+    int32_t mx = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        int32_t n = h_off[s + 1] - h_off[s];
+        if (n < 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets not monotone");
+        if (n > mx) mx = n;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!st) st = c->stream;
+    c->last_stream = st;
+    c->h_scan_off.assign(h_off, h_off + n_scans + 1);
+    HIPCHK(c, hipMemcpyAsync(c->d_scan_off, c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
+    c->A.pts = (const float4*)d_xyzi;
+    c->A.scan_off = c->d_scan_off;
+    c->A.n_scans = n_scans;
+    c->A.max_scan_pts = mx;
+    c->A.total_pts = total;
+    c->tim_used = 0;
+    c->batch_valid = false;
+    c->counts_valid = false;
+    if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
+    HIPCHK(c, hipGetLastError());
+    if (mx == 0) {
+        HIPCHK(c, hipMemsetAsync(c->A.counts, 0, sizeof(int32_t) * 8 * n_scans, st));
+    }
+    c->batch_valid = true;
+    if (sync) HIPCHK(c, hipStreamSynchronize(st));
+    return SCVOD_OK;
+}
+
+int ensure_counts(scvod_ctx* c) {
+    if (!c->batch_valid) return fail(c, SCVOD_ERR_STATE, "no batch has been run");
+    if (c->counts_valid) return SCVOD_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    c->h_counts.resize((size_t)c->A.n_scans * 8);
+    HIPCHK(c, hipMemcpy(c->h_counts.data(), c->A.counts, sizeof(int32_t) * c->h_counts.size(), hipMemcpyDeviceToHost));
+    c->counts_valid = true;
+    return SCVOD_OK;
+}
+
+template <typename T>
+int dl(scvod_ctx* c, std::vector<T>& dst, const T* src, size_t n) {
+    dst.resize(n ? n : 1);
+    if (n) HIPCHK(c, hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
+    return SCVOD_OK;
+}
+
+int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
+    int rc = ensure_counts(c);
+    if (rc) return rc;
+    if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
+    const int32_t* k = &c->h_counts[(size_t)s * 8];
+    const size_t base = (size_t)c->h_scan_off[s];
+    memset(out, 0, sizeof(*out));
+    out->n_points = k[0];
+    out->n_ground = k[1];
+    out->n_nonground = k[2];
+    out->n_dropped = k[3];
+    out->n_apri = k[4];
+    out->n_rejected = k[5];
+    out->n_voxels = k[6];
+    out->n_patches = k[7];
+    const Arena& A = c->A;
+    if ((rc = dl(c, c->r_cls, A.cls + base, (size_t)k[0]))) return rc;
+    if ((rc = dl(c, c->r_ground, A.ground_idx + base, (size_t)k[1]))) return rc;
+    if ((rc = dl(c, c->r_nonground, A.nonground_idx + base, (size_t)k[2]))) return rc;
+    if ((rc = dl(c, c->r_planes, A.planes + (size_t)s * kMaxPatches, (size_t)k[7]))) return rc;
+    if ((rc = dl(c, c->r_apri, A.apri + base, (size_t)k[4]))) return rc;
+    if ((rc = dl(c, c->r_apri_src, A.apri_src + base, (size_t)k[4]))) return rc;
+    if ((rc = dl(c, c->r_rejected, A.rejected_src + base, (size_t)k[5]))) return rc;
+    if ((rc = dl(c, c->r_vox_key, A.vox_key + base, (size_t)k[6]))) return rc;
+    if ((rc = dl(c, c->r_vox_begin, A.vox_pt_begin + base + s, (size_t)k[6] + 1))) return rc;
+    if ((rc = dl(c, c->r_vox_pts, A.vox_pts + base, (size_t)k[4]))) return rc;
+    if ((rc = dl(c, c->r_vox_av, A.vox_av + base, (size_t)k[6]))) return rc;
+    if ((rc = dl(c, c->r_vox_cov, A.vox_cov + base, (size_t)k[6]))) return rc;
+    if (k[6] == 0) c->r_vox_begin[0] = 0;
+    out->cls = c->r_cls.data();
+    out->ground_idx = c->r_ground.data();
+    out->nonground_idx = c->r_nonground.data();
+    out->planes = c->r_planes.data();
+    out->apri = c->r_apri.data();
+    out->apri_src = c->r_apri_src.data();
+    out->rejected_src = c->r_rejected.data();
+    out->vox_key = c->r_vox_key.data();
+    out->vox_pt_begin = c->r_vox_begin.data();
+    out->vox_pts = c->r_vox_pts.data();
+    out->vox_av = c->r_vox_av.data();
+    out->vox_cov = c->r_vox_cov.data();
+    return SCVOD_OK;
+}
+
+int host_scan(scvod_ctx* c, const float* h_xyzi, int32_t n, int do_pw, int filt, int do_vox, scvod_scan_result* out) {
+    if (!c || !out || n < 0 || (n > 0 && !h_xyzi)) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (n > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%d points > capacity %lld", n, (long long)c->cap_pts);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_in, h_xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int32_t off[2] = {0, n};
+    int rc = run_batch(c, c->d_in, off, 1, c->stream, do_pw, filt, do_vox, 1);
+    if (rc) return rc;
+    rc = fetch_scan(c, 0, out);
+    if (rc) return rc;
+    if (!do_pw) out->n_patches = 0;
+    return SCVOD_OK;
+}
+
+// ---- host-side pose algebra (pcl::getTransformation + Eigen::Affine3f inverse / product) ----
+void get_transformation(const float p[6], float t[12]) {
+    const float x = p[0], y = p[1], z = p[2], roll = p[3], pitch = p[4], yaw = p[5];
+    const float A = std::cos(yaw), B = std::sin(yaw), C = std::cos(pitch), D = std::sin(pitch), E = std::cos(roll),
+                F = std::sin(roll), DE = D * E, DF = D * F;
+    t[0] = A * C;
+    t[1] = A * DF - B * E;
+    t[2] = B * F + A * DE;
+    t[3] = x;
+    t[4] = B * C;
+    t[5] = A * E + B * DF;
+    t[6] = B * DE - A * F;
+    t[7] = y;
+    t[8] = -D;
+    t[9] = C * F;
+    t[10] = C * E;
+    t[11] = z;
+}
+inline float red3(float a, float b, float c) { return a + (b + c); }  // Eigen fixed-size redux order
+
+}  // namespace
+
+extern "C" {
+
+void scvod_params_default(scvod_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->sensor_height = 2.0f;
+    p->min_dis = 0.0f;
+    p->max_dis = 50.0f;
+    p->min_angle = 0.0f;
+    p->max_angle = 360.0f;
+    p->min_azimuth = -30.0f;
+    p->max_azimuth = 60.0f;
+    p->range_res = 0.2f;
+    p->sector_res = 1.2f;
+    p->azimuth_res = 2.0f;
+    p->occupancy = 0.6f;
+}
+
+void scvod_pw_params_default(scvod_pw_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->num_iter = 3;
+    p->num_lpr = 20;
+    p->num_min_pts = 10;
+    p->num_rings_of_interest = 4;
+    const int sec[4] = {16, 32, 54, 32}, rng[4] = {2, 4, 4, 4};
+    const double el[4] = {-1.2, -0.9984, -0.851, -0.605}, fl[4] = {0.0, 0.000125, 0.000185, 0.000185};
+    for (int i = 0; i < 4; ++i) {
+        p->num_sectors_each_zone[i] = sec[i];
+        p->num_rings_each_zone[i] = rng[i];
+        p->elevation_thr[i] = el[i];
+        p->flatness_thr[i] = fl[i];
+    }
+    p->th_seeds = 0.3;
+    p->th_dist = 0.1;
+    p->max_range = 80.0;
+    p->min_range = 2.7;
+    p->uprightness_thr = 0.707;
+    p->adaptive_seed_selection_margin = -1.1;
+}
+
+void scvod_grid_dims(const scvod_params* p, int32_t* range_num, int32_t* sector_num, int32_t* azimuth_num,
+                     int32_t* bin_num) {
+    // src/ssc.cpp:36-39: float arithmetic, std::ceil(float)
+    const int r = (int)std::ceil((p->max_dis - p->min_dis) / p->range_res);
+    const int s = (int)std::ceil((p->max_angle - p->min_angle) / p->sector_res);
+    const int a = (int)std::ceil((p->max_azimuth - p->min_azimuth) / p->azimuth_res);
+    if (range_num) *range_num = r;
+    if (sector_num) *sector_num = s;
+    if (azimuth_num) *azimuth_num = a;
+    if (bin_num) *bin_num = r * s * a;
+}
+
+int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int device, int64_t max_points_total,
+                 int32_t max_scans, scvod_ctx** out) {
+    if (!params || !out || max_points_total <= 0 || max_scans <= 0) return SCVOD_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCVOD_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return SCVOD_ERR_NO_DEVICE;
+    scvod_ctx* c = new scvod_ctx();
+    c->device = device;
+    c->params = *params;
+    if (pw)
+        c->pw = *pw;
+    else
+        scvod_pw_params_default(&c->pw);
+    int np = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (c->pw.num_rings_each_zone[k] <= 0 || c->pw.num_sectors_each_zone[k] <= 0) {
+            delete c;
+            return SCVOD_ERR_INVALID;
+        }
+        np += c->pw.num_rings_each_zone[k] * c->pw.num_sectors_each_zone[k];
+    }
+    if (np > kMaxPatches || !(params->range_res > 0) || !(params->sector_res > 0) || !(params->azimuth_res > 0)) {
+        delete c;
+        return SCVOD_ERR_INVALID;
+    }
+    c->cap_pts = max_points_total;
+    c->cap_scans = max_scans;
+    build_dev_params(c);
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return SCVOD_ERR_NO_DEVICE;
+    }
+    size_t total = 0;
+    carve(c, nullptr, &total);
+    if (hipMalloc(&c->arena_base, total) != hipSuccess) {
+        delete c;
+        return SCVOD_ERR_HIP;
+    }
+    c->arena_bytes = total;
+    carve(c, (unsigned char*)c->arena_base, &total);
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+        hipFree(c->arena_base);
+        delete c;
+        return SCVOD_ERR_HIP;
+    }
+    *out = c;
+    return SCVOD_OK;
+}
+
+void scvod_destroy(scvod_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& t : c->tim) {
+        hipEventDestroy(t.e0);
+        hipEventDestroy(t.e1);
+    }
+    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->arena_base) hipFree(c->arena_base);
+    delete c;
+}
+
+const char* scvod_last_error(const scvod_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+int64_t scvod_arena_bytes(const scvod_ctx* c) { return c ? (int64_t)c->arena_bytes : 0; }
+
+int scvod_process_scan(scvod_ctx* c, const float* h_xyzi, int32_t n, scvod_scan_result* out) {
+    return host_scan(c, h_xyzi, n, 1, 1, 1, out);
+}
+int scvod_patchwork(scvod_ctx* c, const float* h_xyzi, int32_t n, scvod_scan_result* out) {
+    int rc = host_scan(c, h_xyzi, n, 1, 1, 0, out);
+    if (rc == SCVOD_OK) {
+        out->n_apri = out->n_rejected = out->n_voxels = 0;
+    }
+    return rc;
+}
+int scvod_bin_scan(scvod_ctx* c, const float* h_xyzi, int32_t n, int32_t apply_filter, int32_t with_voxels,
+                   scvod_scan_result* out) {
+    return host_scan(c, h_xyzi, n, 0, apply_filter ? 1 : 0, with_voxels ? 1 : 0, out);
+}
+
+void scvod_pose_delta(const float pose_pre[6], const float pose_next[6], float T_out[12]) {
+    float tn[12], tp[12];
+    get_transformation(pose_next, tn);
+    get_transformation(pose_pre, tp);
+    // Eigen::Affine3f::inverse(): cofactor inverse of the linear part, then -R^-1 * t
+    auto M = [&](int i, int j) { return tn[4 * i + j]; };
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+    };
+    const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+    const float det = red3(c0 * M(0, 0), c1 * M(1, 0), c2 * M(2, 0));
+    const float invdet = 1.f / det;
+    float R[3][3];
+    R[0][0] = c0 * invdet;
+    R[0][1] = c1 * invdet;
+    R[0][2] = c2 * invdet;
+    R[1][0] = cof(0, 1) * invdet;
+    R[1][1] = cof(1, 1) * invdet;
+    R[1][2] = cof(2, 1) * invdet;
+    R[2][0] = cof(0, 2) * invdet;
+    R[2][1] = cof(1, 2) * invdet;
+    R[2][2] = cof(2, 2) * invdet;
+    float ti[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) ti[4 * i + j] = R[i][j];
+        ti[4 * i + 3] = red3((-R[i][0]) * tn[3], (-R[i][1]) * tn[7], (-R[i][2]) * tn[11]);
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            T_out[4 * i + j] = red3(ti[4 * i] * tp[j], ti[4 * i + 1] * tp[4 + j], ti[4 * i + 2] * tp[8 + j]);
+        T_out[4 * i + 3] = red3(ti[4 * i] * tp[3], ti[4 * i + 1] * tp[7], ti[4 * i + 2] * tp[11]) + ti[4 * i + 3];
+    }
+}
+
+int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offsets, int32_t n_clusters, const float T[12],
+                      const int32_t* h_next_keys, const int32_t* h_next_labels, int32_t n_next_vox, int32_t* h_hit_slot,
+                      int32_t* h_uniq_slots, int32_t* h_uniq_begin) {
+    if (!c || n_clusters < 0 || !h_offsets || !T || n_next_vox < 0) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    const int32_t n_pts = h_offsets[n_clusters];
+    if (n_pts > c->cap_pts || n_clusters > c->cap_pts || n_next_vox > c->cap_pts)
+        return fail(c, SCVOD_ERR_CAPACITY, "track probe larger than the ctx capacity");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->last_stream = st;
+    c->tim_used = 0;
+    float4* d_pts = (float4*)c->A.scratch_xyz;
+    if (n_pts) HIPCHK(c, hipMemcpyAsync(d_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_pts, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->t_begin, h_offsets, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->t_T, T, sizeof(float) * 12, hipMemcpyHostToDevice, st));
+    if (n_next_vox) {
+        HIPCHK(c, hipMemcpyAsync(c->A.tmp_vox_key, h_next_keys, sizeof(int32_t) * n_next_vox, hipMemcpyHostToDevice, st));
+        if (h_next_labels)
+            HIPCHK(c, hipMemcpyAsync(c->A.tmp_vox_begin, h_next_labels, sizeof(int32_t) * n_next_vox, hipMemcpyHostToDevice, st));
+    }
+    TrackJob J;
+    memset(&J, 0, sizeof(J));
+    J.pts = d_pts;
+    J.pt_cluster_begin = c->t_begin;
+    J.n_clusters = n_clusters;
+    J.n_pts = n_pts;
+    J.T = c->t_T;
+    J.next_keys = c->A.tmp_vox_key;
+    J.next_labels = h_next_labels ? c->A.tmp_vox_begin : nullptr;
+    J.n_next_vox = n_next_vox;
+    J.hit_slot = c->t_hit;
+    J.work = c->t_work;
+    J.uniq_slots = c->t_uniq;
+    J.uniq_count = c->t_count;
+    launch_track(c->dev, c->A, J, 0, st, timer_hook, c);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (n_pts && h_hit_slot) HIPCHK(c, hipMemcpy(h_hit_slot, c->t_hit, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost));
+    std::vector<int32_t> cnt(n_clusters > 0 ? n_clusters : 1), uq(n_pts > 0 ? n_pts : 1);
+    if (n_clusters) HIPCHK(c, hipMemcpy(cnt.data(), c->t_count, sizeof(int32_t) * n_clusters, hipMemcpyDeviceToHost));
+    if (n_pts) HIPCHK(c, hipMemcpy(uq.data(), c->t_uniq, sizeof(int32_t) * n_pts, hipMemcpyDeviceToHost));
+    int32_t o = 0;
+    for (int k = 0; k < n_clusters; ++k) {
+        if (h_uniq_begin) h_uniq_begin[k] = o;
+        for (int j = 0; j < cnt[k]; ++j) {
+            if (h_uniq_slots) h_uniq_slots[o] = uq[h_offsets[k] + j];
+            ++o;
+        }
+    }
+    if (h_uniq_begin) h_uniq_begin[n_clusters] = o;
+    return SCVOD_OK;
+}
+
+int scvod_batch_process(scvod_ctx* c, const void* d_xyzi, const int32_t* h_scan_offsets, int32_t n_scans, void* stream,
+                        int32_t sync) {
+    return run_batch(c, d_xyzi, h_scan_offsets, n_scans, (hipStream_t)stream, 1, 1, 1, sync);
+}
+
+int scvod_batch_counts(scvod_ctx* c, int32_t* h_out) {
+    if (!c || !h_out) return SCVOD_ERR_INVALID;
+    int rc = ensure_counts(c);
+    if (rc) return rc;
+    memcpy(h_out, c->h_counts.data(), sizeof(int32_t) * c->h_counts.size());
+    return SCVOD_OK;
+}
+
+int scvod_batch_fetch(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
+    if (!c || !out) return SCVOD_ERR_INVALID;
+    return fetch_scan(c, s, out);
+}
+
+int scvod_batch_track(scvod_ctx* c, const int32_t* d_members, const int32_t* h_cluster_begin, int32_t n_clusters,
+                      const int32_t* h_pair_cluster_begin, const float* h_T, void* stream, int32_t sync) {
+    if (!c || !d_members || !h_cluster_begin || !h_pair_cluster_begin || !h_T || n_clusters < 0)
+        return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (!c->batch_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track needs a processed batch");
+    const int n_pairs = c->A.n_scans - 1;
+    if (n_pairs < 1) return fail(c, SCVOD_ERR_INVALID, "need at least two scans");
+    const int32_t n_pts = h_cluster_begin[n_clusters];
+    if (n_pts > c->cap_pts || n_clusters > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "too many cluster points");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->last_stream = st;
+    c->tim_used = 0;
+    std::vector<int32_t> pair(n_clusters > 0 ? n_clusters : 1);
+    for (int p = 0; p < n_pairs; ++p)
+        for (int k = h_pair_cluster_begin[p]; k < h_pair_cluster_begin[p + 1]; ++k) pair[k] = p;
+    HIPCHK(c, hipMemcpyAsync(c->t_begin, h_cluster_begin, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
+    if (n_clusters) HIPCHK(c, hipMemcpyAsync(c->t_pair, pair.data(), sizeof(int32_t) * n_clusters, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->t_T, h_T, sizeof(float) * 12 * n_pairs, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));  // `pair` is a pageable temporary
+    TrackJob J;
+    memset(&J, 0, sizeof(J));
+    J.members = d_members;
+    J.pt_cluster_begin = c->t_begin;
+    J.n_clusters = n_clusters;
+    J.n_pts = n_pts;
+    J.cluster_pair = c->t_pair;
+    J.T = c->t_T;
+    J.hit_slot = c->t_hit;
+    J.work = c->t_work;
+    J.uniq_slots = c->t_uniq;
+    J.uniq_count = c->t_count;
+    launch_track(c->dev, c->A, J, 1, st, timer_hook, c);
+    HIPCHK(c, hipGetLastError());
+    c->last_track_clusters = n_clusters;
+    if (sync) HIPCHK(c, hipStreamSynchronize(st));
+    return SCVOD_OK;
+}
+
+int scvod_batch_track_counts(scvod_ctx* c, int32_t* h_out_unique, int32_t n_clusters) {
+    if (!c || !h_out_unique || n_clusters < 0 || n_clusters > c->last_track_clusters) return SCVOD_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    if (n_clusters) HIPCHK(c, hipMemcpy(h_out_unique, c->t_count, sizeof(int32_t) * n_clusters, hipMemcpyDeviceToHost));
+    return SCVOD_OK;
+}
+
+int scvod_set_timing(scvod_ctx* c, int32_t enabled) {
+    if (!c) return SCVOD_ERR_INVALID;
+    c->timing = enabled != 0;
+    return SCVOD_OK;
+}
+
+int scvod_batch_timings(scvod_ctx* c, const char** names, float* ms, int32_t cap) {
+    if (!c) return SCVOD_ERR_INVALID;
+    if (hipSetDevice(c->device) != hipSuccess) return SCVOD_ERR_HIP;
+    if (c->last_stream) hipStreamSynchronize(c->last_stream);
+    int n = 0;
+    for (size_t i = 0; i < c->tim_used && n < cap; ++i, ++n) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, c->tim[i].e0, c->tim[i].e1);
+        if (names) names[n] = c->tim[i].name;
+        if (ms) ms[n] = t;
+    }
+    return n;
+}
+
+int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,
+                    float radius, int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within) {
+    if (!c || n_map < 0 || n_query < 0) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_map = nullptr, *d_q = nullptr, *d_sq = nullptr;
+    int32_t* d_idx = nullptr;
+    uint8_t* d_w = nullptr;
+    const size_t nm = n_map ? n_map : 1, nq = n_query ? n_query : 1;
+    HIPCHK(c, hipMalloc(&d_map, nm * 12));
+    HIPCHK(c, hipMalloc(&d_q, nq * 12));
+    HIPCHK(c, hipMalloc(&d_sq, nq * 4));
+    HIPCHK(c, hipMalloc(&d_idx, nq * 4));
+    HIPCHK(c, hipMalloc(&d_w, nq));
+    hipStream_t st = c->stream;
+    if (n_map) HIPCHK(c, hipMemcpyAsync(d_map, h_map_xyz, (size_t)n_map * 12, hipMemcpyHostToDevice, st));
+    if (n_query) HIPCHK(c, hipMemcpyAsync(d_q, h_query_xyz, (size_t)n_query * 12, hipMemcpyHostToDevice, st));
+    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (n_query) {
+        if (h_nn_idx) HIPCHK(c, hipMemcpy(h_nn_idx, d_idx, (size_t)n_query * 4, hipMemcpyDeviceToHost));
+        if (h_nn_sqdist) HIPCHK(c, hipMemcpy(h_nn_sqdist, d_sq, (size_t)n_query * 4, hipMemcpyDeviceToHost));
+        if (h_within) HIPCHK(c, hipMemcpy(h_within, d_w, (size_t)n_query, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_map);
+    hipFree(d_q);
+    hipFree(d_sq);
+    hipFree(d_idx);
+    hipFree(d_w);
+    return SCVOD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// scvod_kernels.h -- launch interface between the C-ABI layer (scvod_capi.hip) and the
+// gfx950 kernels (scvod_kernels.hip).  All pointers are device pointers.
+#ifndef SCVOD_KERNELS_H_
+#define SCVOD_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scvod.h"
+#include "scvod_math.h"
+
+namespace scvod {
+
+constexpr int kMaxPatches = SCVOD_MAX_PATCHES;
+constexpr int kMaxBuckets = 1024;
+
+struct DevParams {
+    BinParams bin;
+    CzmParams czm;
+    int64_t key_off;     // added to voxel_idx before bucketing (R*S + S + 1)
+    int32_t vb_shift;    // bucket = clamp((voxel_idx + key_off) >> vb_shift, 0, n_buckets-1)
+    int32_t n_buckets;
+    int32_t n_patches;
+};
+
+// per-patch record produced by the patch kernel, consumed by the emission kernels
+struct PatchRec {
+    int32_t n;       // points in the patch (pc2czm)
+    int32_t n_g;     // size of the ground part after the last iteration
+    int32_t status;  // 0 skipped, 1 kept, 2 rejected (tilt), 3 rejected (elevation+flatness)
+    int32_t a_g;     // points of the ground part that pass the range/FOV filter of makeApriVec
+    int32_t a_ng;    // same for the non-ground part
+};
+
+// Device arena of one batch.  Per-point arrays are indexed by scan_off[s] + local index;
+// per-scan arrays by s * stride.
+struct Arena {
+    // inputs
+    const float4* pts;
+    const int32_t* scan_off;  // [B+1]
+    int32_t n_scans;
+    int32_t max_scan_pts;
+    int64_t total_pts;
+    // patchwork
+    int16_t* pid;             // [N] patch id or -1
+    uint64_t* keys;           // [N] (sortable z << 32 | local idx), patch-major per scan
+    uint32_t* seg;            // [N] per patch: [ground part | non-ground part], bit31 = passes bin filter
+    float* scratch_xyz;       // [4N] spill (x|y|z|idx) for patches larger than the LDS tier
+    uint8_t* scratch_mask;    // [N]
+    int32_t* patch_count;     // [B][kMaxPatches]
+    int32_t* patch_cursor;    // [B][kMaxPatches]
+    int32_t* patch_off;       // [B][kMaxPatches+1]
+    PatchRec* patch_rec;      // [B][kMaxPatches]
+    scvod_patch_plane* planes;  // [B][kMaxPatches]
+    int32_t* emit_off;        // [B][kMaxPatches][4]  ground / nonground / apri / rejected
+    // outputs of the Patchwork + binning stage
+    uint8_t* cls;             // [N]
+    int32_t* ground_idx;      // [N]
+    int32_t* nonground_idx;   // [N]
+    scvod_apri* apri;         // [N]
+    int32_t* apri_src;        // [N]
+    int32_t* rejected_src;    // [N]
+    int32_t* counts;          // [B][8]
+    // voxel stage
+    int32_t* vb_count;        // [B][kMaxBuckets]
+    int32_t* vb_cursor;       // [B][kMaxBuckets]
+    int32_t* vb_off;          // [B][kMaxBuckets+1]
+    int32_t* vb_nvox;         // [B][kMaxBuckets]
+    int32_t* vox_off;         // [B][kMaxBuckets+1]
+    uint64_t* vkeys;          // [N] (biased voxel key << 32 | apri idx), bucket-major per scan
+    int32_t* tmp_vox_key;     // [N] per-bucket voxel records before compaction
+    int32_t* tmp_vox_begin;   // [N]
+    float* tmp_vox_av;        // [N]
+    float* tmp_vox_cov;       // [N]
+    int32_t* vox_key;         // [N]
+    int32_t* vox_pt_begin;    // [N + B]  (n_vox + 1 entries per scan, base scan_off[s] + s)
+    int32_t* vox_pts;         // [N]
+    float* vox_av;            // [N]
+    float* vox_cov;           // [N]
+};
+
+struct TrackJob {          // scan-vs-next-scan probe
+    const float4* pts;         // explicit cluster points, or nullptr when gathered from apri
+    const int32_t* members;    // apri indices (batch mode) or nullptr
+    const int32_t* pt_cluster_begin;  // [n_clusters+1] offsets into pts / members
+    int32_t n_clusters;
+    int32_t n_pts;
+    // per cluster: which transform / which source scan / which next table
+    const int32_t* cluster_pair;   // [n_clusters] pair index (0 for the single-pair API)
+    const float* T;                // [n_pairs][12]
+    // next tables: explicit (single pair) or arena scans (batch)
+    const int32_t* next_keys;      // explicit table or nullptr
+    const int32_t* next_labels;    // explicit labels or nullptr (= all labelled)
+    int32_t n_next_vox;
+    // outputs
+    int32_t* hit_slot;     // [n_pts]
+    uint64_t* work;        // [n_pts] sort workspace
+    int32_t* uniq_slots;   // [n_pts] per cluster region starts at pt_cluster_begin[c]
+    int32_t* uniq_count;   // [n_clusters]
+};
+
+typedef void (*TimerHook)(void* user, const char* name, int begin);
+
+// Launches.  `th`/`tu` optional per-kernel timing hook (called before and after each launch).
+void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
+                    int do_voxels, TimerHook th, void* tu);
+void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
+                  TimerHook th, void* tu);
+void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
+               float* nn_sq, uint8_t* within, hipStream_t st);
+
+}  // namespace scvod
+#endif

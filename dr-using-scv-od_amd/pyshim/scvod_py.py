@@ -1,0 +1,313 @@
+"""ctypes plumbing over the C-ABI of libscvod.so (include/scvod.h) for tests/ and bench.py.
+
+This is NOT the product's host side (that is the C++ facade in ../host/, mirroring the
+reference's SSC / PatchWork classes); it only lets Python drive the same extern "C" entry
+points with numpy arrays and torch device tensors.  There is no CPU fallback: loading fails
+loudly when libscvod.so is missing and scvod_create fails when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "csrc", "libscvod.so")
+
+MAX_PATCHES = 1024
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "sensor_height", "min_dis", "max_dis", "min_angle", "max_angle", "min_azimuth", "max_azimuth",
+        "range_res", "sector_res", "azimuth_res", "occupancy")] + [("reserved", C.c_int32 * 5)]
+
+
+class PwParams(C.Structure):
+    _fields_ = [("num_iter", C.c_int32), ("num_lpr", C.c_int32), ("num_min_pts", C.c_int32),
+                ("num_rings_of_interest", C.c_int32), ("num_sectors_each_zone", C.c_int32 * 4),
+                ("num_rings_each_zone", C.c_int32 * 4), ("th_seeds", C.c_double), ("th_dist", C.c_double),
+                ("max_range", C.c_double), ("min_range", C.c_double), ("uprightness_thr", C.c_double),
+                ("adaptive_seed_selection_margin", C.c_double), ("elevation_thr", C.c_double * 4),
+                ("flatness_thr", C.c_double * 4)]
+
+
+APRI_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("range", "f4"), ("angle", "f4"), ("azimuth", "f4"),
+                       ("intensity", "f4"), ("range_idx", "i4"), ("sector_idx", "i4"), ("azimuth_idx", "i4"),
+                       ("voxel_idx", "i4")])
+PLANE_DTYPE = np.dtype([("normal", "f4", 3), ("mean", "f4", 3), ("sv", "f4", 3), ("n_pts", "i4"), ("n_ground", "i4"),
+                        ("status", "i4")])
+assert APRI_DTYPE.itemsize == 44 and PLANE_DTYPE.itemsize == 48
+
+
+class ScanResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_points", "n_ground", "n_nonground", "n_dropped", "n_apri", "n_rejected",
+                                          "n_voxels", "n_patches")] + \
+               [(n, C.c_void_p) for n in ("cls", "ground_idx", "nonground_idx", "planes", "apri", "apri_src",
+                                          "rejected_src", "vox_key", "vox_pt_begin", "vox_pts", "vox_av", "vox_cov")]
+
+
+# ssc/ keys of config/*.yaml -> Params fields (include/utility.h:283-310)
+YAML_KEYS = {"sensor_height_": "sensor_height", "min_dis_": "min_dis", "max_dis_": "max_dis", "min_angle_": "min_angle",
+             "max_angle_": "max_angle", "min_azimuth_": "min_azimuth", "max_azimuth_": "max_azimuth",
+             "range_res_": "range_res", "sector_res_": "sector_res", "azimuth_res_": "azimuth_res",
+             "occupancy_": "occupancy"}
+
+# values of the two YAML files shipped by the reference (config/semantickitti.yaml:24-55, config/parkinglot.yaml:23-48)
+PRESETS = {
+    "semantickitti": dict(sensor_height=1.73, min_dis=1.5, max_dis=30.0, min_angle=0.0, max_angle=360.0,
+                          min_azimuth=-40.0, max_azimuth=80.0, range_res=0.4, sector_res=1.2, azimuth_res=2.0,
+                          occupancy=0.4),
+    "parkinglot": dict(sensor_height=1.83, min_dis=0.8, max_dis=40.0, min_angle=0.0, max_angle=360.0,
+                       min_azimuth=-30.0, max_azimuth=60.0, range_res=0.4, sector_res=1.2, azimuth_res=2.0,
+                       occupancy=0.8),
+    # BASELINE.json configs[4]: OS1-128 stream with a 2x finer voxel grid
+    "os128_fine": dict(sensor_height=1.73, min_dis=1.5, max_dis=30.0, min_angle=0.0, max_angle=360.0,
+                       min_azimuth=-40.0, max_azimuth=80.0, range_res=0.2, sector_res=0.6, azimuth_res=1.0,
+                       occupancy=0.4),
+}
+
+_lib = None
+
+
+def load_lib():
+    """Load libscvod.so (after torch, so both share torch's HIP runtime).  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (must come first: one libamdhip64 per process)
+    except Exception:
+        pass
+    path = os.path.abspath(LIB_PATH)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the SCV-OD hot path has no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "scvod_params_default": (None, [C.POINTER(Params)]),
+        "scvod_pw_params_default": (None, [C.POINTER(PwParams)]),
+        "scvod_grid_dims": (None, [C.POINTER(Params)] + [C.POINTER(i32)] * 4),
+        "scvod_create": (C.c_int, [C.POINTER(Params), C.POINTER(PwParams), C.c_int, i64, i32, C.POINTER(vp)]),
+        "scvod_destroy": (None, [vp]),
+        "scvod_last_error": (C.c_char_p, [vp]),
+        "scvod_arena_bytes": (i64, [vp]),
+        "scvod_process_scan": (C.c_int, [vp, vp, i32, C.POINTER(ScanResult)]),
+        "scvod_patchwork": (C.c_int, [vp, vp, i32, C.POINTER(ScanResult)]),
+        "scvod_bin_scan": (C.c_int, [vp, vp, i32, i32, i32, C.POINTER(ScanResult)]),
+        "scvod_pose_delta": (None, [vp, vp, vp]),
+        "scvod_track_probe": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
+        "scvod_batch_process": (C.c_int, [vp, vp, vp, i32, vp, i32]),
+        "scvod_batch_counts": (C.c_int, [vp, vp]),
+        "scvod_batch_fetch": (C.c_int, [vp, i32, C.POINTER(ScanResult)]),
+        "scvod_batch_track": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, i32]),
+        "scvod_batch_track_counts": (C.c_int, [vp, vp, i32]),
+        "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
+        "scvod_set_timing": (C.c_int, [vp, i32]),
+        "scvod_nn_search": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # raises AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_grid_dims", "scvod_create",
+                    "scvod_destroy", "scvod_last_error", "scvod_arena_bytes", "scvod_process_scan", "scvod_patchwork",
+                    "scvod_bin_scan", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
+                    "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_track", "scvod_batch_track_counts",
+                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search"]
+
+
+def make_params(preset=None, **kw):
+    p = Params()
+    load_lib().scvod_params_default(C.byref(p))
+    vals = dict(PRESETS[preset]) if preset else {}
+    vals.update(kw)
+    for k, v in vals.items():
+        setattr(p, k, v)
+    return p
+
+
+def params_from_yaml(path):
+    """Reads the `ssc:` block of a reference YAML file (config/*.yaml) into Params; keys that the
+    hot path does not use are ignored, missing keys keep the nh.param<> defaults."""
+    import yaml
+    with open(path) as f:
+        doc = yaml.safe_load(f)
+    p = make_params()
+    for k, v in (doc.get("ssc") or {}).items():
+        if k in YAML_KEYS:
+            setattr(p, YAML_KEYS[k], float(v))
+    return p
+
+
+def grid_dims(p):
+    out = [C.c_int32() for _ in range(4)]
+    load_lib().scvod_grid_dims(C.byref(p), *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def _unpack(r):
+    d = {k: getattr(r, k) for k in ("n_points", "n_ground", "n_nonground", "n_dropped", "n_apri", "n_rejected",
+                                    "n_voxels", "n_patches")}
+    d["cls"] = _arr(r.cls, r.n_points, np.uint8)
+    d["ground_idx"] = _arr(r.ground_idx, r.n_ground, np.int32)
+    d["nonground_idx"] = _arr(r.nonground_idx, r.n_nonground, np.int32)
+    d["planes"] = _arr(r.planes, r.n_patches, PLANE_DTYPE)
+    d["apri"] = _arr(r.apri, r.n_apri, APRI_DTYPE)
+    d["apri_src"] = _arr(r.apri_src, r.n_apri, np.int32)
+    d["rejected_src"] = _arr(r.rejected_src, r.n_rejected, np.int32)
+    d["vox_key"] = _arr(r.vox_key, r.n_voxels, np.int32)
+    d["vox_pt_begin"] = _arr(r.vox_pt_begin, r.n_voxels + 1, np.int32)
+    d["vox_pts"] = _arr(r.vox_pts, r.n_apri if r.n_voxels else 0, np.int32)
+    d["vox_av"] = _arr(r.vox_av, r.n_voxels, np.float32)
+    d["vox_cov"] = _arr(r.vox_cov, r.n_voxels, np.float32)
+    return d
+
+
+class ScvodError(RuntimeError):
+    pass
+
+
+class Ctx:
+    def __init__(self, params, max_points_total, max_scans=1, device=0, pw=None):
+        self.lib = load_lib()
+        self.params = params
+        self.h = C.c_void_p()
+        rc = self.lib.scvod_create(C.byref(params), C.byref(pw) if pw is not None else None, device,
+                                   int(max_points_total), int(max_scans), C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise ScvodError(f"scvod_create failed with status {rc} "
+                             "(-2 = no HIP device: the SCV-OD path is GPU-only, there is no CPU fallback)")
+
+    def close(self):
+        if self.h:
+            self.lib.scvod_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ScvodError(f"status {rc}: {self.lib.scvod_last_error(self.h).decode()}")
+
+    @staticmethod
+    def _f32(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    @staticmethod
+    def _i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        return a, a.ctypes.data_as(C.c_void_p)
+
+    def process_scan(self, xyzi):
+        a, p = self._f32(xyzi)
+        r = ScanResult()
+        self._chk(self.lib.scvod_process_scan(self.h, p, a.shape[0], C.byref(r)))
+        return _unpack(r)
+
+    def patchwork(self, xyzi):
+        a, p = self._f32(xyzi)
+        r = ScanResult()
+        self._chk(self.lib.scvod_patchwork(self.h, p, a.shape[0], C.byref(r)))
+        return _unpack(r)
+
+    def bin_scan(self, xyzi, apply_filter=True, with_voxels=True):
+        a, p = self._f32(xyzi)
+        r = ScanResult()
+        self._chk(self.lib.scvod_bin_scan(self.h, p, a.shape[0], int(apply_filter), int(with_voxels), C.byref(r)))
+        return _unpack(r)
+
+    def pose_delta(self, pose_pre, pose_next):
+        a, pa = self._f32(pose_pre)
+        b, pb = self._f32(pose_next)
+        T = np.zeros(12, np.float32)
+        self.lib.scvod_pose_delta(pa, pb, T.ctypes.data_as(C.c_void_p))
+        return T
+
+    def track_probe(self, xyzi, offsets, T, next_keys, next_labels):
+        a, pa = self._f32(xyzi)
+        o, po = self._i32(offsets)
+        t, pt = self._f32(T)
+        k, pk = self._i32(next_keys)
+        n_c = o.shape[0] - 1
+        n_pts = int(o[-1])
+        if next_labels is not None:
+            l, pl = self._i32(next_labels)
+        else:
+            l, pl = None, None
+        hit = np.zeros(max(n_pts, 1), np.int32)
+        uq = np.zeros(max(n_pts, 1), np.int32)
+        ub = np.zeros(n_c + 1, np.int32)
+        self._chk(self.lib.scvod_track_probe(self.h, pa, po, n_c, pt, pk, pl, k.shape[0], hit.ctypes.data_as(C.c_void_p),
+                                             uq.ctypes.data_as(C.c_void_p), ub.ctypes.data_as(C.c_void_p)))
+        return hit[:n_pts], uq[:ub[-1]], ub
+
+    # ---- device-resident batch API (torch tensors) ----
+    def batch_process(self, d_xyzi, scan_offsets, stream=None, sync=True):
+        off, po = self._i32(scan_offsets)
+        self._n_scans = off.shape[0] - 1
+        ptr = C.c_void_p(d_xyzi.data_ptr())
+        self._chk(self.lib.scvod_batch_process(self.h, ptr, po, self._n_scans, C.c_void_p(stream or 0), int(sync)))
+
+    def batch_counts(self):
+        out = np.zeros((self._n_scans, 8), np.int32)
+        self._chk(self.lib.scvod_batch_counts(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def batch_fetch(self, s):
+        r = ScanResult()
+        self._chk(self.lib.scvod_batch_fetch(self.h, int(s), C.byref(r)))
+        return _unpack(r)
+
+    def batch_track(self, d_members, cluster_begin, pair_cluster_begin, T, stream=None, sync=True):
+        cb, pcb = self._i32(cluster_begin)
+        pb, ppb = self._i32(pair_cluster_begin)
+        t, pt = self._f32(T)
+        self._n_track_clusters = cb.shape[0] - 1
+        self._chk(self.lib.scvod_batch_track(self.h, C.c_void_p(d_members.data_ptr()), pcb, self._n_track_clusters, ppb,
+                                             pt, C.c_void_p(stream or 0), int(sync)))
+
+    def batch_track_counts(self):
+        out = np.zeros(max(self._n_track_clusters, 1), np.int32)
+        self._chk(self.lib.scvod_batch_track_counts(self.h, out.ctypes.data_as(C.c_void_p), self._n_track_clusters))
+        return out[:self._n_track_clusters]
+
+    def set_timing(self, on):
+        self._chk(self.lib.scvod_set_timing(self.h, int(bool(on))))
+
+    def timings(self, cap=64):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = self.lib.scvod_batch_timings(self.h, names, ms, cap)
+        return [(names[i].decode(), float(ms[i])) for i in range(max(n, 0))]
+
+    def arena_bytes(self):
+        return int(self.lib.scvod_arena_bytes(self.h))
+
+    def nn_search(self, map_xyz, query_xyz, radius):
+        m, pm = self._f32(map_xyz)
+        q, pq = self._f32(query_xyz)
+        nq = q.shape[0]
+        idx = np.zeros(max(nq, 1), np.int32)
+        sq = np.zeros(max(nq, 1), np.float32)
+        w = np.zeros(max(nq, 1), np.uint8)
+        self._chk(self.lib.scvod_nn_search(self.h, pm, m.shape[0], pq, nq, float(radius), idx.ctypes.data_as(C.c_void_p),
+                                           sq.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
+        return idx[:nq], sq[:nq], w[:nq]

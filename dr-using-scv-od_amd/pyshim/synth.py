@@ -1,0 +1,170 @@
+"""Seeded synthetic LiDAR scans shaped like the datasets BASELINE.json names.
+
+No real SemanticKITTI / ParkingLot data exists in this environment, so tests and bench.py use
+ray-cast scenes: a tilted noisy ground plane, axis-aligned boxes (cars / walls), vertical
+cylinders (poles / trunks) and a few moving boxes, scanned by a spinning multi-beam sensor that
+drives forward 1 m per scan.  Everything is a pure function of (kind, seq, scan index).
+
+kinds:  K64   64 beams (+2.0 .. -24.8 deg), 2083 columns, ~10 % drop-outs -> ~120 k returns
+        OS128 128 beams (+-22.5 deg), 2048 columns, no drop-outs -> 262 144 rays
+        PARK  64 beams (+-16.6 deg), 1024 columns (config/parkinglot.yaml geometry)
+Labels follow SemanticKITTI: 40 ground, 50 building, 71 trunk/pole, 10 static car, 252 moving car.
+"""
+import math
+
+import torch
+
+SEQ_LEN = {0: 4541, 1: 1101, 2: 4661, 3: 801, 4: 271, 5: 2761, 6: 1101, 7: 1101, 8: 4071, 9: 1591, 10: 1201}
+
+KINDS = {
+    "K64": dict(beams=64, el_hi=2.0, el_lo=-24.8, cols=2083, drop=0.10, height=1.73),
+    "OS128": dict(beams=128, el_hi=22.5, el_lo=-22.5, cols=2048, drop=0.0, height=1.73),
+    "PARK": dict(beams=64, el_hi=16.6, el_lo=-16.6, cols=1024, drop=0.05, height=1.83),
+}
+
+
+def pose_of(idx):
+    """(x, y, z, roll, pitch, yaw) of scan idx: 1 m/scan forward, gentle yaw weave."""
+    yaw = math.radians(0.2) * math.sin(idx / 50.0)
+    return (float(idx) * 1.0, 0.0, 0.0, 0.0, 0.0, yaw)
+
+
+def _segment_objects(seq, seg, kind):
+    g = torch.Generator().manual_seed(20241026 + 1000 * seq + 7919 * (seg + 1000) + (0 if kind != "PARK" else 13))
+    x0 = 100.0 * seg
+    u = lambda n, lo, hi: lo + (hi - lo) * torch.rand(n, generator=g)
+    n_car, n_wall, n_cyl = 14, 6, 10
+    cars_c = torch.stack([x0 + u(n_car, 0, 100), torch.where(torch.rand(n_car, generator=g) < 0.5, u(n_car, 3.5, 9), u(n_car, -9, -3.5))], 1)
+    swap = torch.rand(n_car, generator=g) < 0.3
+    car_dx = torch.where(swap, torch.full((n_car,), 0.9), torch.full((n_car,), 2.1))
+    car_dy = torch.where(swap, torch.full((n_car,), 2.1), torch.full((n_car,), 0.9))
+    walls_c = torch.stack([x0 + u(n_wall, 0, 100), torch.where(torch.rand(n_wall, generator=g) < 0.5, u(n_wall, 11, 25), u(n_wall, -25, -11))], 1)
+    cyl_c = torch.stack([x0 + u(n_cyl, 0, 100), torch.where(torch.rand(n_cyl, generator=g) < 0.5, u(n_cyl, 4, 20), u(n_cyl, -20, -4))], 1)
+    cyl_r = u(n_cyl, 0.2, 0.5)
+    cyl_h = u(n_cyl, 3.0, 8.0)
+    q = lambda n: torch.round(torch.rand(n, generator=g) * 100) / 100 * 255
+    return dict(cars_c=cars_c, car_dx=car_dx, car_dy=car_dy, car_i=q(n_car), walls_c=walls_c, wall_i=q(n_wall),
+                cyl_c=cyl_c, cyl_r=cyl_r, cyl_h=cyl_h, cyl_i=q(n_cyl))
+
+
+def _movers(seq, idx, kind):
+    g = torch.Generator().manual_seed(424242 + 1000 * seq + (0 if kind != "PARK" else 17))
+    n = 6
+    speed = (5 + 10 * torch.rand(n, generator=g)) if kind != "PARK" else (1 + 2 * torch.rand(n, generator=g))
+    lane = torch.where(torch.rand(n, generator=g) < 0.5, torch.full((n,), 1.8), torch.full((n,), -1.8))
+    phase = torch.rand(n, generator=g) * 120.0
+    # movers cycle through a window that travels with the sensor so every scan sees some
+    t = idx * 0.1
+    rel = ((phase + (speed - 10.0) * t) % 120.0) - 60.0
+    cx = float(idx) + rel
+    i = torch.round(torch.rand(n, generator=g) * 100) / 100 * 255
+    return torch.stack([cx, lane], 1), i
+
+
+def make_scan(seq, idx, kind="K64", device="cpu", with_labels=True):
+    """Returns (xyzi float32 [n,4] in the sensor frame, labels int32 [n], pose tuple)."""
+    K = KINDS[kind]
+    dev = torch.device(device)
+    h = K["height"]
+    pose = pose_of(idx)
+    sx, yaw = pose[0], pose[5]
+    seed = 20241026 + 1000 * seq + idx
+    g = torch.Generator(device=dev).manual_seed(seed)
+    el = torch.linspace(math.radians(K["el_hi"]), math.radians(K["el_lo"]), K["beams"], device=dev)
+    az = torch.arange(K["cols"], device=dev, dtype=torch.float32) * (2 * math.pi / K["cols"])
+    ce, se = torch.cos(el)[:, None], torch.sin(el)[:, None]
+    dxs = (ce * torch.cos(az)[None, :]).reshape(-1)
+    dys = (ce * torch.sin(az)[None, :]).reshape(-1)
+    dzs = (se * torch.ones_like(az)[None, :]).reshape(-1)
+    # world-frame ray (sensor yaw only), origin (sx, 0, 0)
+    cy, syw = math.cos(yaw), math.sin(yaw)
+    dx = cy * dxs - syw * dys
+    dy = syw * dxs + cy * dys
+    dz = dzs
+    R = dx.numel()
+    INF = 1.0e9
+    best_t = torch.full((R,), INF, device=dev)
+    best_i = torch.zeros(R, device=dev)
+    best_l = torch.zeros(R, dtype=torch.int32, device=dev)
+
+    def take(t, inten, label):
+        nonlocal best_t, best_i, best_l
+        m = t < best_t
+        best_t = torch.where(m, t, best_t)
+        best_i = torch.where(m, inten, best_i)
+        best_l = torch.where(m, torch.full_like(best_l, label), best_l)
+
+    # ground plane z = -h + a*(x - sx) + b*y  (tilt seeded per sequence)
+    gs = torch.Generator().manual_seed(99 + seq)
+    a, b = (0.02 * torch.randn(2, generator=gs)).tolist()
+    den = dz - a * dx - b * dy
+    tg = torch.where(den < -1e-6, (-h) / den, torch.full_like(den, INF))
+    take(tg, torch.full_like(tg, 0.25 * 255), 40)
+
+    def boxes(c, hx, hy, z0, z1, inten, label):
+        # c [m,2] world centres, half sizes hx, hy [m]; slab test, origin (sx,0,0)
+        if c.shape[0] == 0:
+            return
+        c = c.to(dev)
+        hx, hy, inten = hx.to(dev), hy.to(dev), inten.to(dev)
+        ox = c[:, 0][None, :] - sx
+        oy = c[:, 1][None, :]
+        idx_ = 1.0 / torch.where(dx.abs() < 1e-9, torch.full_like(dx, 1e-9), dx)[:, None]
+        idy = 1.0 / torch.where(dy.abs() < 1e-9, torch.full_like(dy, 1e-9), dy)[:, None]
+        idz = 1.0 / torch.where(dz.abs() < 1e-9, torch.full_like(dz, 1e-9), dz)[:, None]
+        tx1, tx2 = (ox - hx[None, :]) * idx_, (ox + hx[None, :]) * idx_
+        ty1, ty2 = (oy - hy[None, :]) * idy, (oy + hy[None, :]) * idy
+        tz1, tz2 = (z0 * idz).expand_as(tx1), (z1 * idz).expand_as(tx1)
+        tmin = torch.maximum(torch.maximum(torch.minimum(tx1, tx2), torch.minimum(ty1, ty2)), torch.minimum(tz1, tz2))
+        tmax = torch.minimum(torch.minimum(torch.maximum(tx1, tx2), torch.maximum(ty1, ty2)), torch.maximum(tz1, tz2))
+        hit = (tmax >= tmin) & (tmin > 0.5)
+        t = torch.where(hit, tmin, torch.full_like(tmin, INF))
+        tb, jb = t.min(dim=1)
+        take(tb, inten[jb], label)
+
+    def cylinders(c, r, hh, inten, label):
+        c, r, hh, inten = c.to(dev), r.to(dev), hh.to(dev), inten.to(dev)
+        ox = (sx - c[:, 0])[None, :]
+        oy = (0.0 - c[:, 1])[None, :]
+        A = (dx * dx + dy * dy)[:, None]
+        Bq = 2 * (ox * dx[:, None] + oy * dy[:, None])
+        Cq = ox * ox + oy * oy - (r * r)[None, :]
+        disc = Bq * Bq - 4 * A * Cq
+        sq = torch.sqrt(torch.clamp(disc, min=0))
+        t = (-Bq - sq) / (2 * A + 1e-12)
+        z = t * dz[:, None]
+        hit = (disc > 0) & (t > 0.5) & (z >= -h) & (z <= (-h + hh)[None, :])
+        t = torch.where(hit, t, torch.full_like(t, INF))
+        tb, jb = t.min(dim=1)
+        take(tb, inten[jb], label)
+
+    seg0 = int(math.floor(sx / 100.0))
+    for sg in (seg0 - 1, seg0, seg0 + 1):
+        o = _segment_objects(seq, sg, kind)
+        boxes(o["cars_c"], o["car_dx"], o["car_dy"], -h, -h + 1.5, o["car_i"], 10)
+        n_w = o["walls_c"].shape[0]
+        boxes(o["walls_c"], torch.full((n_w,), 10.0), torch.full((n_w,), 0.15), -h, -h + 3.0, o["wall_i"], 50)
+        cylinders(o["cyl_c"], o["cyl_r"], o["cyl_h"], o["cyl_i"], 71)
+    mc, mi = _movers(seq, idx, kind)
+    boxes(mc, torch.full((mc.shape[0],), 2.1), torch.full((mc.shape[0],), 0.9), -h, -h + 1.5, mi, 252)
+
+    valid = best_t < 80.0
+    if K["drop"] > 0:
+        valid &= torch.rand(R, generator=g, device=dev) >= K["drop"]
+    t = best_t + 0.02 * torch.randn(R, generator=g, device=dev)
+    inten = torch.clamp(best_i + 2.0 * torch.randn(R, generator=g, device=dev), 0.0, 255.0)
+    pts = torch.stack([t * dxs, t * dys, t * dzs, inten], 1)[valid].contiguous().float()
+    labels = best_l[valid].contiguous() if with_labels else None
+    return pts, labels, pose
+
+
+def make_batch(seq, first, count, kind="K64", device="cpu", stride=1):
+    """Concatenated scans + int32 offsets (host list) + poses."""
+    pts, offs, poses, labels = [], [0], [], []
+    for k in range(count):
+        p, l, pose = make_scan(seq, first + k * stride, kind, device)
+        pts.append(p)
+        labels.append(l)
+        offs.append(offs[-1] + p.shape[0])
+        poses.append(pose)
+    return torch.cat(pts, 0).contiguous(), offs, poses, torch.cat(labels, 0)

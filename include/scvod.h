@@ -1,0 +1,246 @@
+/*
+ * scvod.h -- C-ABI of the MI355X-native SCV-OD hot path (libscvod.so).
+ *
+ * This is the drop-in boundary for the hot path of Yixin-F/DR-Using-SCV-OD
+ * (SURVEY.md section 8b).  The reference has no FFI of its own: the seam is plain
+ * C++ member calls on `class SSC : public Utility` (include/ssc.h:7) and
+ * `template<class PointT> class PatchWork` (include/patchwork.h:37-191).  Each
+ * entry point below names the reference member it replaces (file:line into
+ * /root/reference).  The C++ facade in dr-using-scv-od_amd/host/ keeps the
+ * reference's class signatures and calls only the functions declared here.
+ *
+ * Conventions
+ *   - every function returns int status: 0 = SCVOD_OK, <0 = error (no exceptions,
+ *     no logging, no allocation visible to the caller except through the ctx);
+ *     scvod_last_error(ctx) returns a human-readable message.
+ *   - plain pointers and sizes only.  "h_" pointers are host memory owned by the
+ *     caller, "d_" pointers are device (HBM) memory owned by the caller.
+ *   - a ctx is single-owner and not thread-safe (the reference caller is
+ *     single-threaded, src/main.cpp:9-12); one ctx per GPU / stream.
+ *   - points are packed float4 {x, y, z, intensity} (pcl::PointXYZI without the
+ *     padding, 16 B/point).
+ *   - the library is GPU-only: if no gfx950 device / HIP runtime is usable,
+ *     scvod_create fails with SCVOD_ERR_NO_DEVICE.  There is no CPU fallback.
+ */
+#ifndef SCVOD_H_
+#define SCVOD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCVOD_OK 0
+#define SCVOD_ERR_INVALID (-1)   /* bad argument / parameter combination           */
+#define SCVOD_ERR_NO_DEVICE (-2) /* no usable HIP device (no CPU fallback exists)   */
+#define SCVOD_ERR_HIP (-3)       /* HIP runtime error, see scvod_last_error         */
+#define SCVOD_ERR_CAPACITY (-4)  /* batch larger than the ctx capacity              */
+#define SCVOD_ERR_STATE (-5)     /* call order violated (e.g. fetch before run)     */
+
+#define SCVOD_NUM_ZONES 4
+#define SCVOD_MAX_PATCHES 1024 /* reference model has 504 (patchwork.h:48-49) */
+
+/* per-point class written by Patchwork (patchwork.h:326-391) */
+#define SCVOD_CLS_GROUND 0    /* emitted into cloud_out                         */
+#define SCVOD_CLS_NONGROUND 1 /* emitted into cloud_nonground                   */
+#define SCVOD_CLS_DROPPED 2   /* z < -1.8h, r outside (2.7, 80], patch size <= 10 */
+
+/* ---- configuration --------------------------------------------------------------- */
+
+/* The `ssc/` keys of config/<name>.yaml that the hot path reads (include/utility.h:283-313;
+ * defaults are the nh.param<> defaults there).  Names drop the trailing underscore. */
+typedef struct scvod_params {
+    float sensor_height; /* 2.0  */
+    float min_dis;       /* 0.0  */
+    float max_dis;       /* 50.0 */
+    float min_angle;     /* 0.0  */
+    float max_angle;     /* 360  */
+    float min_azimuth;   /* -30  */
+    float max_azimuth;   /* 60   */
+    float range_res;     /* 0.2  */
+    float sector_res;    /* 1.2  */
+    float azimuth_res;   /* 2.0  */
+    float occupancy;     /* 0.6  */
+    int32_t reserved[5];
+} scvod_params;
+
+/* Patchwork constants.  Hard-coded in the reference (patchwork.h:48-51, :115-129);
+ * exposed here as a defaulted struct (scvod_pw_params_default). */
+typedef struct scvod_pw_params {
+    int32_t num_iter;                                /* 3  */
+    int32_t num_lpr;                                 /* 20 */
+    int32_t num_min_pts;                             /* 10 */
+    int32_t num_rings_of_interest;                   /* 4 (= elevation_thr_.size(), patchwork.h:73) */
+    int32_t num_sectors_each_zone[SCVOD_NUM_ZONES];  /* 16,32,54,32 */
+    int32_t num_rings_each_zone[SCVOD_NUM_ZONES];    /* 2,4,4,4     */
+    double th_seeds;                                 /* 0.3   */
+    double th_dist;                                  /* 0.1   */
+    double max_range;                                /* 80.0  */
+    double min_range;                                /* 2.7   */
+    double uprightness_thr;                          /* 0.707 */
+    double adaptive_seed_selection_margin;           /* -1.1  */
+    double elevation_thr[4];                         /* -1.2,-0.9984,-0.851,-0.605 */
+    double flatness_thr[4];                          /* 0,0.000125,0.000185,0.000185 */
+} scvod_pw_params;
+
+void scvod_params_default(scvod_params* p);       /* utility.h:283-310 defaults */
+void scvod_pw_params_default(scvod_pw_params* p); /* patchwork.h:48-51,115-129  */
+
+/* Curved-voxel grid sizes exactly as SSC::SSC computes them (src/ssc.cpp:36-39):
+ * (int)std::ceil((max - min) / res) in float. */
+void scvod_grid_dims(const scvod_params* p, int32_t* range_num, int32_t* sector_num,
+                     int32_t* azimuth_num, int32_t* bin_num);
+
+/* ---- PODs -------------------------------------------------------------------------- */
+
+/* struct PointAPRI, include/utility.h:96-106 (44 bytes, same field order) */
+typedef struct scvod_apri {
+    float x, y, z;
+    float range;
+    float angle;
+    float azimuth;
+    float intensity;
+    int32_t range_idx;
+    int32_t sector_idx;
+    int32_t azimuth_idx;
+    int32_t voxel_idx;
+} scvod_apri;
+
+/* Per-patch plane record written by the Patchwork kernel (state of normal_, pc_mean_,
+ * singular_values_ after extract_piecewiseground, patchwork.h:339-343). */
+typedef struct scvod_patch_plane {
+    float normal[3];
+    float mean[3];
+    float sv[3];
+    int32_t n_pts;      /* points binned into the patch (pc2czm)                   */
+    int32_t n_ground;   /* |regionwise_ground_| after the last iteration            */
+    int32_t status;     /* 0 skipped (size<=num_min_pts), 1 kept, 2 rejected: tilt,
+                           3 rejected: elevation+flatness                           */
+} scvod_patch_plane;
+
+/* Result of one scan.  All pointers are host memory owned by the ctx, valid until the
+ * next call that produces a scvod_scan_result on the same ctx. */
+typedef struct scvod_scan_result {
+    int32_t n_points;
+    int32_t n_ground;     /* |cloud_out|        patchwork.h:362,377,381           */
+    int32_t n_nonground;  /* |cloud_nonground|  patchwork.h:348-349,363,373-374   */
+    int32_t n_dropped;
+    int32_t n_apri;       /* |apri_vec| == |cloud_use|  ssc.cpp:174,193           */
+    int32_t n_rejected;   /* pushes into cloud_eva_static, ssc.cpp:161-172        */
+    int32_t n_voxels;     /* |hash_cloud|        ssc.cpp:253-280                  */
+    int32_t n_patches;
+    const uint8_t* cls;           /* [n_points] SCVOD_CLS_*                        */
+    const int32_t* ground_idx;    /* [n_ground] input index of cloud_out[k]        */
+    const int32_t* nonground_idx; /* [n_nonground] input index of cloud_nonground[k] */
+    const scvod_patch_plane* planes; /* [n_patches] in (zone, ring, sector) order  */
+    const scvod_apri* apri;       /* [n_apri] apri_vec                             */
+    const int32_t* apri_src;      /* [n_apri] input index of apri_vec[k]/cloud_use[k] */
+    const int32_t* rejected_src;  /* [n_rejected] input index, push order          */
+    /* hash_cloud as CSR, voxels sorted by ascending voxel_idx key */
+    const int32_t* vox_key;       /* [n_voxels] Voxel key (PointAPRI::voxel_idx)   */
+    const int32_t* vox_pt_begin;  /* [n_voxels+1] offsets into vox_pts             */
+    const int32_t* vox_pts;       /* [n_apri] Voxel::ptIdx, ascending per voxel    */
+    const float* vox_av;          /* [n_voxels] Voxel::intensity_av  ssc.cpp:283   */
+    const float* vox_cov;         /* [n_voxels] Voxel::intensity_cov ssc.cpp:284-287 */
+} scvod_scan_result;
+
+/* ---- context ------------------------------------------------------------------------- */
+
+typedef struct scvod_ctx scvod_ctx;
+
+/* max_points_total: capacity of the device arena in points summed over a batch;
+ * max_scans: capacity in scans per batch.  pw may be NULL (defaults). */
+int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int device,
+                 int64_t max_points_total, int32_t max_scans, scvod_ctx** out);
+void scvod_destroy(scvod_ctx* ctx);
+const char* scvod_last_error(const scvod_ctx* ctx);
+/* bytes of HBM held by the ctx arena */
+int64_t scvod_arena_bytes(const scvod_ctx* ctx);
+
+/* ---- per-scan host entry points (what the SSC / PatchWork facade calls) ---------------- */
+
+/* Replaces SSC::process up to and including makeHashCloud (src/ssc.cpp:224-241):
+ * PatchWork::estimate_ground (patchwork.h:277-398) -> SSC::makeApriVec (ssc.cpp:155-195)
+ * -> SSC::makeHashCloud (ssc.cpp:253-289).  h_xyzi: n x {x,y,z,intensity}. */
+int scvod_process_scan(scvod_ctx* ctx, const float* h_xyzi, int32_t n, scvod_scan_result* out);
+
+/* Replaces PatchWork::estimate_ground only (patchwork.h:105-109).  Fills the Patchwork
+ * fields of `out`; the apri / voxel fields are zero. */
+int scvod_patchwork(scvod_ctx* ctx, const float* h_xyzi, int32_t n, scvod_scan_result* out);
+
+/* Replaces SSC::makeApriVec (ssc.cpp:155-195) on an arbitrary cloud (no Patchwork):
+ * with apply_filter != 0 the range/FOV rejection of ssc.cpp:161-172 is applied,
+ * with apply_filter == 0 every point is binned unclamped as in SSC::tracking
+ * (ssc.cpp:1280-1286).  Followed by SSC::makeHashCloud when with_voxels != 0. */
+int scvod_bin_scan(scvod_ctx* ctx, const float* h_xyzi, int32_t n, int32_t apply_filter,
+                   int32_t with_voxels, scvod_scan_result* out);
+
+/* T = getTransformation(next)^-1 * getTransformation(pre), src/ssc.cpp:1255-1257
+ * (pcl::getTransformation + Eigen::Affine3f inverse/product restated on the host).
+ * pose = {x, y, z, roll, pitch, yaw}; T_out is row-major 3x4. */
+void scvod_pose_delta(const float pose_pre[6], const float pose_next[6], float T_out[12]);
+
+/* Bulk part of SSC::tracking (ssc.cpp:1274-1321): for every cluster c (points
+ * h_xyzi[offsets[c] .. offsets[c+1]) ), transform by T (utility.h:394-406), re-bin
+ * without range/FOV rejection (ssc.cpp:1280-1286), probe the next frame's voxel table
+ * (sorted keys + labels) and keep hits whose label != -1 (ssc.cpp:1304-1305).
+ *   h_hit_slot   [n_pts]        slot in the next table of the voxel hit by the point, or -1
+ *   h_uniq_slots [n_pts]        per cluster: sorted unique hit slots (sampleVec, ssc.cpp:1319-1321)
+ *   h_uniq_begin [n_clusters+1] offsets into h_uniq_slots
+ * The label grouping / occupancy-ratio decisions (ssc.cpp:1323-1421) stay on the host
+ * because they mutate the next frame sequentially. */
+int scvod_track_probe(scvod_ctx* ctx, const float* h_xyzi, const int32_t* h_offsets,
+                      int32_t n_clusters, const float T[12], const int32_t* h_next_keys,
+                      const int32_t* h_next_labels, int32_t n_next_vox, int32_t* h_hit_slot,
+                      int32_t* h_uniq_slots, int32_t* h_uniq_begin);
+
+/* ---- device-resident batch entry points (sequence shards; used by bench.py) ------------- */
+
+/* Run Patchwork -> binning -> voxel descriptors over n_scans scans already resident in
+ * HBM.  d_xyzi: all scans concatenated; h_scan_offsets[n_scans+1] point offsets.
+ * stream: hipStream_t (NULL = the ctx's own stream).  Asynchronous w.r.t. the host
+ * unless sync != 0. */
+int scvod_batch_process(scvod_ctx* ctx, const void* d_xyzi, const int32_t* h_scan_offsets,
+                        int32_t n_scans, void* stream, int32_t sync);
+
+/* Per-scan counters of the last batch: out[n_scans][8] =
+ * {n_points, n_ground, n_nonground, n_dropped, n_apri, n_rejected, n_voxels, 0}. */
+int scvod_batch_counts(scvod_ctx* ctx, int32_t* h_out);
+
+/* Download the full result of scan `s` of the last batch. */
+int scvod_batch_fetch(scvod_ctx* ctx, int32_t s, scvod_scan_result* out);
+
+/* Scan-vs-next-scan probe over every consecutive pair (s, s+1) of the last batch, device
+ * resident.  Cluster c of pair s is the apri points of scan s listed in
+ * d_members[h_cluster_begin[c] .. h_cluster_begin[c+1]) (indices into scan s's apri_vec);
+ * h_pair_cluster_begin[n_scans] gives the first cluster of each pair (last entry = total).
+ * h_T: [n_scans-1][12].  Labels of the next table are taken as "!= -1" for every voxel
+ * (the freshly segmented state).  Results stay on the device; counts are returned by
+ * scvod_batch_track_counts: out[n_clusters] = number of unique voxels hit. */
+int scvod_batch_track(scvod_ctx* ctx, const int32_t* d_members, const int32_t* h_cluster_begin,
+                      int32_t n_clusters, const int32_t* h_pair_cluster_begin, const float* h_T,
+                      void* stream, int32_t sync);
+int scvod_batch_track_counts(scvod_ctx* ctx, int32_t* h_out_unique, int32_t n_clusters);
+
+/* hipEvent timing of the kernels of the last batch call, in launch order:
+ * names[i] (static strings), ms[i].  Returns the number of entries (<= cap). */
+int scvod_batch_timings(scvod_ctx* ctx, const char** names, float* ms, int32_t cap);
+/* enable (1) / disable (0) per-kernel hipEvent timing for subsequent batch calls */
+int scvod_set_timing(scvod_ctx* ctx, int32_t enabled);
+
+/* ---- correspondence search (north_star "GICP correspondence search"; the reference's
+ * real analogue is the kd-tree look-up of src/evaluate.cpp:79-145) ----------------------- */
+
+/* For every query point: index of the nearest map point (ties: lowest index) and the
+ * squared distance (fp32, ((dx*dx + dy*dy) + dz*dz)); h_within[q] = 1 if any map point
+ * lies within `radius` (pcl radiusSearch non-empty, evaluate.cpp:95,104).  h_xyz arrays
+ * are n x 3 floats. */
+int scvod_nn_search(scvod_ctx* ctx, const float* h_map_xyz, int32_t n_map,
+                    const float* h_query_xyz, int32_t n_query, float radius,
+                    int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCVOD_H_ */

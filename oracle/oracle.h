@@ -1,0 +1,66 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ * C interface of the CPU restatement of the SCV-OD hot path, loaded by tests/ through
+ * ctypes (oracle/liboracle.so).  It reuses the POD types of the public C-ABI header so
+ * the same ctypes structures describe both sides; it shares no code with the product. */
+#ifndef SCVOD_ORACLE_H_
+#define SCVOD_ORACLE_H_
+
+#include "../include/scvod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void oracle_params_default(scvod_params* p);
+void oracle_pw_params_default(scvod_pw_params* p);
+void oracle_grid_dims(const scvod_params* p, int32_t* range_num, int32_t* sector_num, int32_t* azimuth_num,
+                      int32_t* bin_num);
+
+/* PatchWork::estimate_ground, include/patchwork.h:277-398 */
+int oracle_patchwork(const scvod_params* params, const scvod_pw_params* pw, const float* xyzi, int32_t n,
+                     int32_t sort_mode, uint8_t* cls, int32_t* ground_idx, int32_t* n_ground, int32_t* nonground_idx,
+                     int32_t* n_nonground, scvod_patch_plane* planes, int32_t* n_patches);
+void oracle_svd3(const float cov_rowmajor[9], float sv[3], float U_rowmajor[9]);
+
+/* SSC::makeApriVec, src/ssc.cpp:155-195.  apply_filter == 0: SSC::tracking's unfiltered
+ * re-binning (ssc.cpp:1280-1286).  src_idx[k] = input index of apri[k]; rejected_idx =
+ * points pushed to cloud_eva_static. */
+int oracle_bin(const scvod_params* params, const float* xyzi, int32_t n, int32_t apply_filter, scvod_apri* apri,
+               int32_t* src_idx, int32_t* n_kept, int32_t* rejected_idx, int32_t* n_rejected);
+
+/* SSC::makeHashCloud, src/ssc.cpp:253-289.  Output sorted by ascending key. */
+int oracle_voxelize(const scvod_params* params, const scvod_apri* apri, int32_t n, int32_t* vox_key,
+                    int32_t* vox_pt_begin, int32_t* vox_pts, float* vox_av, float* vox_cov, int32_t* vox_idx3,
+                    float* vox_center, int32_t* n_vox);
+
+/* getTransformation(next)^-1 * getTransformation(pre), src/ssc.cpp:1255-1257 */
+void oracle_pose_delta(const float pose_pre[6], const float pose_next[6], float T_out[12]);
+
+/* bulk part of SSC::tracking, src/ssc.cpp:1274-1321 (+ utility.h:394-406) */
+int oracle_track_probe(const scvod_params* params, const float* xyzi, const int32_t* offsets, int32_t n_clusters,
+                       const float T[12], const int32_t* next_keys, const int32_t* next_labels, int32_t n_next_vox,
+                       int32_t* hit_slot, int32_t* uniq_slots, int32_t* uniq_begin);
+
+/* SSC::clusterAndCreateFrame (src/ssc.cpp:299-393): per apri point cluster name, and per
+ * voxel (sorted-key order) label.  Returns number of clusters. */
+int oracle_cluster(const scvod_params* params, const scvod_apri* apri, int32_t n, int32_t* pt_cluster,
+                   int32_t* max_name);
+
+/* brute-force nearest neighbour / radius test (src/evaluate.cpp:79-145 analogue) */
+int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz, int32_t n_query, float radius,
+                     int32_t* nn_idx, float* nn_sqdist, uint8_t* within);
+
+/* libm probes for tests/test_math_spec.py */
+float oracle_libm_atan2f(float y, float x);
+double oracle_libm_atan2(double y, double x);
+
+/* Timed CPU baseline: runs Patchwork + binning + voxelisation over n_scans scans
+ * (concatenated xyzi, offsets[n_scans+1]) single-threaded; returns seconds per stage in
+ * stage_s[3] = {patchwork, bin, voxelize}. */
+int oracle_time_process(const scvod_params* params, const float* xyzi, const int32_t* offsets, int32_t n_scans,
+                        double stage_s[3], int64_t* checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

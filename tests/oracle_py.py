@@ -1,0 +1,142 @@
+"""ctypes loader of the ORACLE (oracle/liboracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys
+sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
+from scvod_py import APRI_DTYPE, PLANE_DTYPE, Params, PwParams  # POD layouts of include/scvod.h
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return Oracle(_lib)
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("patchwork_oracle.cpp", "ssc_oracle.cpp", "oracle.h")]
+    if (not os.path.exists(so)) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    _lib = C.CDLL(so)
+    _lib.oracle_libm_atan2f.restype = C.c_float
+    _lib.oracle_libm_atan2f.argtypes = [C.c_float, C.c_float]
+    _lib.oracle_libm_atan2.restype = C.c_double
+    _lib.oracle_libm_atan2.argtypes = [C.c_double, C.c_double]
+    return Oracle(_lib)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def params_default(self):
+        p = Params()
+        self.lib.oracle_params_default(C.byref(p))
+        return p
+
+    def grid_dims(self, p):
+        o = [C.c_int32() for _ in range(4)]
+        self.lib.oracle_grid_dims(C.byref(p), *[C.byref(x) for x in o])
+        return tuple(x.value for x in o)
+
+    def patchwork(self, params, xyzi, sort_mode=1):
+        a = np.ascontiguousarray(xyzi, np.float32)
+        n = a.shape[0]
+        cls = np.zeros(max(n, 1), np.uint8)
+        g = np.zeros(max(n, 1), np.int32)
+        ng = np.zeros(max(n, 1), np.int32)
+        planes = np.zeros(1024, PLANE_DTYPE)
+        n_g, n_ng, n_p = C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.oracle_patchwork(C.byref(params), None, _p(a), n, sort_mode, _p(cls), _p(g), C.byref(n_g), _p(ng),
+                                  C.byref(n_ng), _p(planes), C.byref(n_p))
+        return dict(cls=cls[:n], ground_idx=g[:n_g.value], nonground_idx=ng[:n_ng.value], planes=planes[:n_p.value])
+
+    def bin(self, params, xyzi, apply_filter=True):
+        a = np.ascontiguousarray(xyzi, np.float32)
+        n = a.shape[0]
+        apri = np.zeros(max(n, 1), APRI_DTYPE)
+        src = np.zeros(max(n, 1), np.int32)
+        rej = np.zeros(max(n, 1), np.int32)
+        nk, nr = C.c_int32(), C.c_int32()
+        self.lib.oracle_bin(C.byref(params), _p(a), n, int(apply_filter), _p(apri), _p(src), C.byref(nk), _p(rej),
+                            C.byref(nr))
+        return dict(apri=apri[:nk.value], src=src[:nk.value], rejected=rej[:nr.value])
+
+    def voxelize(self, params, apri):
+        a = np.ascontiguousarray(apri)
+        n = a.shape[0]
+        key = np.zeros(max(n, 1), np.int32)
+        beg = np.zeros(n + 1, np.int32)
+        pts = np.zeros(max(n, 1), np.int32)
+        av = np.zeros(max(n, 1), np.float32)
+        cov = np.zeros(max(n, 1), np.float32)
+        idx3 = np.zeros((max(n, 1), 3), np.int32)
+        cen = np.zeros((max(n, 1), 4), np.float32)
+        nv = C.c_int32()
+        self.lib.oracle_voxelize(C.byref(params), _p(a), n, _p(key), _p(beg), _p(pts), _p(av), _p(cov), _p(idx3),
+                                 _p(cen), C.byref(nv))
+        v = nv.value
+        return dict(vox_key=key[:v], vox_pt_begin=beg[:v + 1], vox_pts=pts[:n], vox_av=av[:v], vox_cov=cov[:v],
+                    idx3=idx3[:v], center=cen[:v])
+
+    def pose_delta(self, pre, nxt):
+        a = np.ascontiguousarray(pre, np.float32)
+        b = np.ascontiguousarray(nxt, np.float32)
+        T = np.zeros(12, np.float32)
+        self.lib.oracle_pose_delta(_p(a), _p(b), _p(T))
+        return T
+
+    def track_probe(self, params, xyzi, offsets, T, next_keys, next_labels):
+        a = np.ascontiguousarray(xyzi, np.float32)
+        o = np.ascontiguousarray(offsets, np.int32)
+        t = np.ascontiguousarray(T, np.float32)
+        k = np.ascontiguousarray(next_keys, np.int32)
+        l = np.ascontiguousarray(next_labels, np.int32)
+        n_pts = int(o[-1])
+        hit = np.zeros(max(n_pts, 1), np.int32)
+        uq = np.zeros(max(n_pts, 1), np.int32)
+        ub = np.zeros(o.shape[0], np.int32)
+        self.lib.oracle_track_probe(C.byref(params), _p(a), _p(o), o.shape[0] - 1, _p(t), _p(k), _p(l), k.shape[0],
+                                    _p(hit), _p(uq), _p(ub))
+        return hit[:n_pts], uq[:ub[-1]], ub
+
+    def cluster(self, params, apri):
+        a = np.ascontiguousarray(apri)
+        n = a.shape[0]
+        out = np.zeros(max(n, 1), np.int32)
+        mx = C.c_int32()
+        nc = self.lib.oracle_cluster(C.byref(params), _p(a), n, _p(out), C.byref(mx))
+        return out[:n], nc, mx.value
+
+    def nn_search(self, map_xyz, query_xyz, radius):
+        m = np.ascontiguousarray(map_xyz, np.float32)
+        q = np.ascontiguousarray(query_xyz, np.float32)
+        nq = q.shape[0]
+        idx = np.zeros(max(nq, 1), np.int32)
+        sq = np.zeros(max(nq, 1), np.float32)
+        w = np.zeros(max(nq, 1), np.uint8)
+        self.lib.oracle_nn_search(_p(m), m.shape[0], _p(q), nq, C.c_float(radius), _p(idx), _p(sq), _p(w))
+        return idx[:nq], sq[:nq], w[:nq]
+
+    def svd3(self, cov):
+        c = np.ascontiguousarray(cov, np.float32).reshape(9)
+        sv = np.zeros(3, np.float32)
+        U = np.zeros(9, np.float32)
+        self.lib.oracle_svd3(_p(c), _p(sv), _p(U))
+        return sv, U.reshape(3, 3)
+
+    def time_process(self, params, xyzi, offsets):
+        a = np.ascontiguousarray(xyzi, np.float32)
+        o = np.ascontiguousarray(offsets, np.int32)
+        st = (C.c_double * 3)()
+        cs = C.c_int64()
+        self.lib.oracle_time_process(C.byref(params), _p(a), _p(o), o.shape[0] - 1, st, C.byref(cs))
+        return [st[0], st[1], st[2]], cs.value

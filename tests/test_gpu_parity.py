@@ -1,0 +1,171 @@
+"""GPU parity tests proper: the HIP path, driven through the C-ABI (libscvod.so), against the
+oracle on the same seeded inputs.  Bit-exact everywhere (integer indices AND descriptor floats)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(scvod, preset):
+    return scvod.make_params(preset)
+
+
+def _check_scan(orc, P, x, r, tag=""):
+    o = orc.patchwork(P, x, 1)
+    assert np.array_equal(r["cls"], o["cls"]), f"{tag} cls"
+    assert np.array_equal(r["ground_idx"], o["ground_idx"]), f"{tag} ground order"
+    assert np.array_equal(r["nonground_idx"], o["nonground_idx"]), f"{tag} nonground order"
+    assert r["n_dropped"] == int((o["cls"] == 2).sum())
+    assert r["planes"].shape == o["planes"].shape
+    for f in ("n_pts", "n_ground", "status"):
+        assert np.array_equal(r["planes"][f], o["planes"][f]), f"{tag} planes.{f}"
+    live = o["planes"]["status"] > 0
+    for f in ("normal", "mean", "sv"):
+        assert np.array_equal(r["planes"][f][live].view(np.uint32), o["planes"][f][live].view(np.uint32)), f"{tag} planes.{f}"
+    ng = x[o["nonground_idx"]]
+    b = orc.bin(P, ng, True)
+    assert r["n_apri"] == len(b["apri"])
+    assert np.array_equal(r["apri"].view(np.uint8), b["apri"].view(np.uint8)), f"{tag} apri_vec"
+    assert np.array_equal(r["apri_src"], o["nonground_idx"][b["src"]]), f"{tag} apri_src"
+    assert np.array_equal(r["rejected_src"], o["nonground_idx"][b["rejected"]]), f"{tag} rejected"
+    v = orc.voxelize(P, b["apri"])
+    assert np.array_equal(r["vox_key"], v["vox_key"]), f"{tag} vox keys"
+    assert np.array_equal(r["vox_pt_begin"], v["vox_pt_begin"]), f"{tag} vox offsets"
+    assert np.array_equal(r["vox_pts"], v["vox_pts"]), f"{tag} ptIdx lists"
+    assert np.array_equal(r["vox_av"].view(np.uint32), v["vox_av"].view(np.uint32)), f"{tag} intensity_av"
+    assert np.array_equal(r["vox_cov"].view(np.uint32), v["vox_cov"].view(np.uint32)), f"{tag} intensity_cov"
+    return o, b, v
+
+
+@pytest.mark.parametrize("kind,preset,seq,idx", [("K64", "semantickitti", 5, 0), ("K64", "semantickitti", 0, 431),
+                                                 ("PARK", "parkinglot", 3, 12), ("OS128", "os128_fine", 5, 40)])
+def test_process_scan_parity(scvod, oracle, kind, preset, seq, idx):
+    import synth
+    P = _params(scvod, preset)
+    pts, _, _ = synth.make_scan(seq, idx, kind)
+    x = pts.numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    _check_scan(oracle, P, x, r, f"{kind}/{seq}/{idx}")
+    ctx.close()
+
+
+def test_batch_matches_per_scan(scvod, oracle):
+    import torch
+    import synth
+    P = _params(scvod, "semantickitti")
+    pts, offs, poses, _ = synth.make_batch(5, 200, 5, "K64")
+    x = pts.numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=8)
+    d = pts.cuda()
+    ctx.batch_process(d, offs)
+    cnt = ctx.batch_counts()
+    for s in range(5):
+        r = ctx.batch_fetch(s)
+        xs = x[offs[s]:offs[s + 1]]
+        assert r["n_points"] == xs.shape[0] == cnt[s, 0]
+        _check_scan(oracle, P, xs, r, f"batch scan {s}")
+        assert cnt[s, 4] == r["n_apri"] and cnt[s, 6] == r["n_voxels"]
+    # idempotence: running the same batch again gives the same counters
+    ctx.batch_process(d, offs)
+    assert np.array_equal(cnt, ctx.batch_counts())
+    ctx.close()
+
+
+def test_edge_cases(scvod, oracle):
+    rng = np.random.default_rng(7)
+    P = _params(scvod, "semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=60000, max_scans=1)
+    # empty and tiny scans
+    r = ctx.process_scan(np.zeros((0, 4), np.float32))
+    assert r["n_points"] == 0 and r["n_apri"] == 0 and r["n_voxels"] == 0
+    tiny = rng.uniform(-10, 10, (9, 4)).astype(np.float32)
+    _check_scan(oracle, P, tiny, ctx.process_scan(tiny), "tiny")
+    # one huge patch (> 8192 points: global-memory tier), with many exact z ties and bin-edge values
+    n = 20000
+    ang = rng.uniform(0.01, 0.38, n)
+    rad = rng.uniform(3.0, 7.0, n)
+    z = np.round(rng.normal(-1.7, 0.05, n), 2)
+    big = np.stack([rad * np.cos(ang), rad * np.sin(ang), z, rng.integers(0, 255, n)], 1).astype(np.float32)
+    big[:50, 1] = 0.0  # angle == 0 -> sector_idx -1 (aliased keys)
+    big[50:60, 0] = 1.5
+    big[50:60, 1] = 0.0  # dis == min_dis -> range_idx -1, below Patchwork's min range
+    _check_scan(oracle, P, big, ctx.process_scan(big), "huge patch")
+    # a wall: every patch tilted -> rejected patches (ground part re-emitted as non-ground)
+    m = 30000
+    wall = np.stack([np.full(m, 6.0) + rng.normal(0, 0.01, m), rng.uniform(-8, 8, m), rng.uniform(-1.7, 1.0, m),
+                     rng.integers(0, 255, m)], 1).astype(np.float32)
+    o, _, _ = _check_scan(oracle, P, wall, ctx.process_scan(wall), "wall")
+    assert (o["planes"]["status"] == 2).any()
+    ctx.close()
+
+
+def test_bin_scan_unfiltered_and_filtered(scvod, oracle):
+    rng = np.random.default_rng(3)
+    P = _params(scvod, "parkinglot")
+    x = rng.uniform(-45, 45, (30000, 4)).astype(np.float32)
+    x[:, 2] = rng.uniform(-3, 6, 30000)
+    x[:100, 1] = 0.0
+    x[100:110, :2] = 0.0
+    ctx = scvod.Ctx(P, max_points_total=40000, max_scans=1)
+    for filt in (True, False):
+        r = ctx.bin_scan(x, apply_filter=filt, with_voxels=True)
+        b = oracle.bin(P, x, filt)
+        assert np.array_equal(r["apri"].view(np.uint8), b["apri"].view(np.uint8))
+        assert np.array_equal(r["apri_src"], b["src"])
+        v = oracle.voxelize(P, b["apri"])
+        assert np.array_equal(r["vox_key"], v["vox_key"])
+        assert np.array_equal(r["vox_pts"], v["vox_pts"])
+        assert np.array_equal(r["vox_av"].view(np.uint32), v["vox_av"].view(np.uint32))
+        assert np.array_equal(r["vox_cov"].view(np.uint32), v["vox_cov"].view(np.uint32))
+    ctx.close()
+
+
+def test_track_probe_parity(scvod, oracle):
+    import synth
+    P = _params(scvod, "semantickitti")
+    a, _, pose_a = synth.make_scan(5, 300, "K64")
+    b, _, pose_b = synth.make_scan(5, 301, "K64")
+    xa, xb = a.numpy(), b.numpy()
+    ctx = scvod.Ctx(P, max_points_total=max(len(xa), len(xb)) + 64, max_scans=1)
+    ra = ctx.process_scan(xa)
+    rb = ctx.process_scan(xb)
+    T = ctx.pose_delta(pose_a, pose_b)
+    assert np.array_equal(T.view(np.uint32), oracle.pose_delta(pose_a, pose_b).view(np.uint32))
+    # clusters of scan a from the oracle's CVC restatement; labels of scan b likewise
+    ca, _, _ = oracle.cluster(P, ra["apri"])
+    cb, _, _ = oracle.cluster(P, rb["apri"])
+    names = [c for c in np.unique(ca) if 30 <= (ca == c).sum() <= 4000][:40]
+    pts, offs = [], [0]
+    for c in names:
+        m = np.nonzero(ca == c)[0]
+        pts.append(np.stack([ra["apri"]["x"][m], ra["apri"]["y"][m], ra["apri"]["z"][m], ra["apri"]["intensity"][m]], 1))
+        offs.append(offs[-1] + len(m))
+    pts = np.concatenate(pts).astype(np.float32)
+    labels = np.full(rb["n_voxels"], -1, np.int32)
+    first_pt = rb["vox_pts"][rb["vox_pt_begin"][:-1]]
+    labels[:] = cb[first_pt]
+    labels[::7] = -1  # some voxels unlabeled (refined away)
+    hit, uq, ub = ctx.track_probe(pts, offs, T, rb["vox_key"], labels)
+    ohit, ouq, oub = oracle.track_probe(P, pts, offs, T, rb["vox_key"], labels)
+    assert np.array_equal(hit, ohit)
+    assert np.array_equal(ub, oub)
+    assert np.array_equal(uq, ouq)
+    assert (hit >= 0).sum() > 0
+    ctx.close()
+
+
+def test_nn_search_parity(scvod, oracle):
+    rng = np.random.default_rng(11)
+    m = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+    q = np.concatenate([m[:500] + rng.normal(0, 0.05, (500, 3)).astype(np.float32),
+                        rng.uniform(-20, 20, (700, 3)).astype(np.float32)])
+    P = _params(scvod, "semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=1024, max_scans=1)
+    for radius in (0.15, 0.1):
+        i, d, w = ctx.nn_search(m, q, radius)
+        oi, od, ow = oracle.nn_search(m, q, radius)
+        assert np.array_equal(i, oi)
+        assert np.array_equal(d.view(np.uint32), od.view(np.uint32))
+        assert np.array_equal(w, ow)
+    ctx.close()
