@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -212,6 +213,16 @@ void build_dev_params(scvod_ctx* c) {
 
 void timer_hook(void* user, const char* name, int begin) {
     scvod_ctx* c = (scvod_ctx*)user;
+    static const bool trace = getenv("SCVOD_TRACE") != nullptr;
+    if (trace) {  // debugging aid: name every launch and synchronise after it
+        if (!begin) {
+            hipError_t e = hipStreamSynchronize(c->last_stream);
+            fprintf(stderr, "[scvod] %s done: %s\n", name, hipGetErrorString(e));
+        } else {
+            fprintf(stderr, "[scvod] %s ...\n", name);
+        }
+        fflush(stderr);
+    }
     if (!c->timing) return;
     hipStream_t st = c->last_stream;
     if (begin) {

@@ -759,13 +759,18 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     for (int c0 = 0; c0 < m; c0 += THREADS) {
         int j = c0 + threadIdx.x;
         int head = 0;
-        if (j < m) head = (j == 0) || ((uint32_t)(keys[j] >> 32) != (uint32_t)(keys[j - 1] >> 32));
+        if (j < m) {
+            // never form keys[-1]: with flat addressing that leaves the LDS aperture
+            const uint64_t prev = keys[j > 0 ? j - 1 : 0];
+            head = (j == 0) || ((uint32_t)(keys[j] >> 32) != (uint32_t)(prev >> 32));
+        }
         int th;
         int eh = block_excl_scan<THREADS>(head, th, wsum);
         if (j < m) A.vox_pts[(size_t)base + off + j] = (int32_t)(uint32_t)keys[j];
         if (head) vbeg[run + eh] = j;
         run += th;
     }
+    __syncthreads();
     const int nv = run;
     // per voxel: sequential fp32 mean, then population variance accumulated as float += double
     for (int v = threadIdx.x; v < nv; v += THREADS) {
@@ -904,7 +909,8 @@ __global__ __launch_bounds__(THREADS) void k_track_unique(TrackJob J) {
         uint32_t v = 0xffffffffu;
         if (j < m) {
             v = keys[j];
-            head = (v != 0xffffffffu) && (j == 0 || keys[j - 1] != v);
+            const uint32_t prev = keys[j > 0 ? j - 1 : 0];
+            head = (v != 0xffffffffu) && (j == 0 || prev != v);
         }
         int th;
         int eh = block_excl_scan<THREADS>(head, th, wsum);

@@ -75,14 +75,14 @@ SCVOD_HD double fabs_d(double x) { return u2d(d2u(x) & 0x7fffffffffffffffull); }
 // default -fhip-fp32-correctly-rounded-divide-sqrt; on the host they are SSE sqrtss/sd.
 SCVOD_HD float sqrt_f(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
+    return __builtin_sqrtf(x);  // llvm.sqrt.f32, correctly rounded (HIP's __fsqrt_rn is the 1-ulp native sqrt)
 #else
     return __builtin_sqrtf(x);
 #endif
 }
 SCVOD_HD double sqrt_d(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __dsqrt_rn(x);
+    return __builtin_sqrt(x);
 #else
     return __builtin_sqrt(x);
 #endif
