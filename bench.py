@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/s of the SCV-OD hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): a SemanticKITTI-seq-05-shaped sequence -- 2761 scans of a
+64-beam sensor, ~110-120 k returns per scan, config/semantickitti.yaml parameters -- synthetic
+(no dataset exists in this environment), resident in HBM before the timed region starts.
+One "step" = one pass of the hot path over the rank's whole sequence shard:
+    Patchwork ground segmentation -> curved-voxel binning -> per-voxel descriptors
+    -> scan-vs-next-scan occupancy probe for every consecutive pair,
+processed in chunks of --chunk scans through the C-ABI (libscvod.so).  With N > 1 GPUs every
+rank owns its own seq-05-shaped sequence (scans are independent: weak scaling, no data-path
+collective); value = scans of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline      HBM roofline of the dominant kernel, measured live with hipEvents on the launch stream
+  cpu_baseline  the oracle (CPU restatement of the reference, single thread) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# Algorithmic (compulsory) bytes per scan, SURVEY.md 8(d), split by stage so that a kernel is priced
+# against the bytes of ITS stage (DESIGN.md "Roofline accounting"):
+#   patchwork : 16 N (read xyzi) + 1 N (class)                         -> pw_* and emit kernels
+#   binning   : 4 N (voxel_idx) + 1 N (dynamic/static label)           -> emit (fused)
+#   voxels    : 20 V                                                   -> vx_* kernels
+#   tracking  : 16 N_car + 4 N_car + 64                                -> track_* kernels
+STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter": "patchwork",
+            "pw_patch_small": "patchwork", "pw_patch_large": "patchwork", "emit_offsets": "patchwork",
+            "emit": "binning", "vx_count": "voxels", "vx_offsets": "voxels", "vx_scatter": "voxels",
+            "vx_bucket_small": "voxels", "vx_bucket_large": "voxels", "vx_final_offsets": "voxels",
+            "vx_final": "voxels", "track_probe": "tracking", "track_unique": "tracking"}
+
+
+def stage_bytes(n_pts, n_vox, n_car, n_scans):
+    return {"patchwork": 17.0 * n_pts, "binning": 5.0 * n_pts, "voxels": 20.0 * n_vox,
+            "tracking": 20.0 * n_car + 64.0 * n_scans}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scans", type=int, default=2761, help="scans per rank (seq 05 has 2761)")
+    ap.add_argument("--chunk", type=int, default=256, help="scans per C-ABI batch call")
+    ap.add_argument("--kind", default="K64")
+    ap.add_argument("--preset", default="semantickitti")
+    ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the SCV-OD path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    import scvod_py
+    import synth
+
+    P = scvod_py.make_params(args.preset)
+    seq = 5 + 11 * rank  # every rank scans its own seq-05-shaped sequence
+    dev = torch.device("cuda", local)
+
+    # ---- synthetic sequence, resident in HBM ----
+    t0 = time.time()
+    chunks = []
+    for c0 in range(0, args.scans, args.chunk):
+        cnt = min(args.chunk, args.scans - c0)
+        pts, offs, poses, _ = synth.make_batch(seq, c0, cnt, args.kind, device=dev)
+        chunks.append(dict(pts=pts, offs=np.asarray(offs, np.int32), poses=poses, first=c0))
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    max_pts = max(int(c["offs"][-1]) for c in chunks)
+    total_pts = sum(int(c["offs"][-1]) for c in chunks)
+    ctx = scvod_py.Ctx(P, max_points_total=max_pts + 1024, max_scans=args.chunk, device=local)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- pseudo "potentially mobile" clusters for the differencing stage: every 5th apri point of a
+    # scan, in runs of 256 (the reference tracks only `car` clusters: ~5-6 k points per scan) ----
+    tot_vox = 0
+    tot_car = 0
+    for c in chunks:
+        ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=True)
+        cnt = ctx.batch_counts()
+        tot_vox += int(cnt[:, 6].sum())
+        n_sc = cnt.shape[0]
+        members, cbegin, pbegin = [], [0], [0]
+        for s in range(n_sc - 1):
+            m = np.arange(0, cnt[s, 4], 5, dtype=np.int32)
+            members.append(m)
+            for k in range(0, len(m), 256):
+                cbegin.append(cbegin[-1] + min(256, len(m) - k))
+            pbegin.append(len(cbegin) - 1)
+        mem = np.concatenate(members) if members else np.zeros(0, np.int32)
+        tot_car += len(mem)
+        T = np.stack([ctx.pose_delta(c["poses"][s], c["poses"][s + 1]) for s in range(n_sc - 1)]) if n_sc > 1 else np.zeros((0, 12), np.float32)
+        c["members"] = torch.from_numpy(mem if len(mem) else np.zeros(1, np.int32)).to(dev)
+        c["cbegin"] = np.asarray(cbegin, np.int32)
+        c["pbegin"] = np.asarray(pbegin, np.int32)
+        c["T"] = T.astype(np.float32)
+        c["n_sc"] = n_sc
+
+    def step():
+        for c in chunks:
+            ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=False)
+            if c["n_sc"] > 1:
+                ctx.batch_track(c["members"], c["cbegin"], c["pbegin"], c["T"], stream=stream, sync=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # per-kernel hipEvent timing on the launch stream for the timed steps
+    ctx.set_timing(True)
+    kt = {}
+
+    def timed_step():
+        for c in chunks:
+            ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=False)
+            for name, ms in ctx.timings():
+                a = kt.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += 1
+            if c["n_sc"] > 1:
+                ctx.batch_track(c["members"], c["cbegin"], c["pbegin"], c["T"], stream=stream, sync=False)
+                for name, ms in ctx.timings():
+                    a = kt.setdefault(name, [0.0, 0])
+                    a[0] += ms
+                    a[1] += 1
+
+    # timed region 1 (the number reported): no per-kernel events, async launches
+    ctx.set_timing(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # timed region 2: the same steps with hipEvents around every kernel (roofline attribution)
+    ctx.set_timing(True)
+    barrier()
+    for _ in range(args.steps):
+        timed_step()
+    barrier()
+    ctx.set_timing(False)
+
+    if dist is not None:
+        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+        agg = torch.tensor([float(args.scans), float(total_pts)], device=dev, dtype=torch.float64)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        all_scans, all_pts = float(agg[0].item()), float(agg[1].item())
+    else:
+        all_scans, all_pts = float(args.scans), float(total_pts)
+
+    if rank == 0:
+        scans_per_s = all_scans * args.steps / dt
+        # dominant kernel and its HBM roofline
+        n_chunks = len(chunks)
+        sb = stage_bytes(total_pts, tot_vox, tot_car, args.scans)  # bytes per step (this rank)
+        dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else None
+        roof = None
+        kernels = {}
+        for name, (ms, cnt) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
+            kernels[name] = {"avg_ms": ms / cnt, "launches": cnt, "share": ms / sum(v[0] for v in kt.values())}
+        if dom:
+            name, (ms, cnt) = dom
+            stage = STAGE_OF.get(name, "patchwork")
+            bytes_per_launch = sb[stage] / n_chunks  # one launch processes one chunk of the sequence
+            avg_s = ms / cnt / 1e3
+            ach = bytes_per_launch / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": name, "stage": stage, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms_per_launch": ms / cnt,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "path_GBps": (sum(sb.values()) * args.steps / dt) / 1e9}
+        cpu = None
+        if not args.no_cpu and world == 1:
+            import oracle_py
+            orc = oracle_py.load()
+            ns = min(args.cpu_scans, int(chunks[0]["n_sc"]))
+            offs = chunks[0]["offs"][: ns + 1]
+            x = chunks[0]["pts"][: int(offs[-1])].cpu().numpy()
+            t1 = time.perf_counter()
+            stages, _ = orc.time_process(P, x, offs)
+            cpu_dt = time.perf_counter() - t1
+            cpu = {"value": ns / cpu_dt, "unit": "scans/s", "cores": 1, "kind": "port",
+                   "sample": f"first {ns} scans of the same synthetic seq-05 sequence (Patchwork+binning+voxel descriptors, "
+                             f"oracle/liboracle.so, g++ -O3 no -march, 1 thread; {os.cpu_count()} host cores present)",
+                   "stage_ms_per_scan": {"patchwork": 1e3 * stages[0] / ns, "bin": 1e3 * stages[1] / ns,
+                                         "voxelize": 1e3 * stages[2] / ns}}
+        out = {"metric": "scans/sec on SemanticKITTI-seq-05-shaped input (SCV-OD hot path)", "value": scans_per_s,
+               "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"seq05-shaped {args.kind} sequence, {args.scans} scans/rank, {args.preset}.yaml grid, "
+                                      f"chunks of {args.chunk} scans", "scans_per_rank": args.scans,
+                          "points_per_scan": total_pts / args.scans, "voxels_per_scan": tot_vox / args.scans,
+                          "car_points_per_scan": tot_car / args.scans, "sharding": f"1 sequence per GPU x{world}"},
+               "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
+               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
