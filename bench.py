@@ -37,7 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 #   voxels    : 20 V                                                   -> vx_* kernels
 #   tracking  : 16 N_car + 4 N_car + 64                                -> track_* kernels
 STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter": "patchwork",
-            "pw_patch_small": "patchwork", "pw_patch_large": "patchwork", "emit_offsets": "patchwork",
+            "pw_sort_small": "patchwork", "pw_sort_large": "patchwork", "pw_order": "patchwork", "pw_fit": "patchwork",
+            "pw_arrange": "patchwork", "emit_offsets": "patchwork",
             "emit": "binning", "vx_count": "voxels", "vx_offsets": "voxels", "vx_scatter": "voxels",
             "vx_bucket_small": "voxels", "vx_bucket_large": "voxels", "vx_final_offsets": "voxels",
             "vx_final": "voxels", "track_probe": "tracking", "track_unique": "tracking"}
@@ -54,7 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scans", type=int, default=2761, help="scans per rank (seq 05 has 2761)")
-    ap.add_argument("--chunk", type=int, default=256, help="scans per C-ABI batch call")
+    ap.add_argument("--chunk", type=int, default=1024, help="scans per C-ABI batch call")
     ap.add_argument("--kind", default="K64")
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")

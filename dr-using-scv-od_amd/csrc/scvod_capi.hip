@@ -109,8 +109,12 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.pid = k.take<int16_t>(N);
     A.keys = k.take<uint64_t>(N);
     A.seg = k.take<uint32_t>(N);
-    A.scratch_xyz = k.take<float>(4 * N);
-    A.scratch_mask = k.take<uint8_t>(N);
+    A.sorted = k.take<float4>(N);
+    A.fit_thd = k.take<float>(B * kMaxPatches);
+    A.order = k.take<int32_t>(B * kMaxPatches);
+    A.order_hist = k.take<int32_t>(64);
+    A.order_cursor = k.take<int32_t>(64);
+    A.order_off = k.take<int32_t>(65);
     A.patch_count = k.take<int32_t>(B * kMaxPatches);
     A.patch_cursor = k.take<int32_t>(B * kMaxPatches);
     A.patch_off = k.take<int32_t>(B * (kMaxPatches + 1));
@@ -554,7 +558,7 @@ int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offset
     hipStream_t st = c->stream;
     c->last_stream = st;
     c->tim_used = 0;
-    float4* d_pts = (float4*)c->A.scratch_xyz;
+    float4* d_pts = c->A.sorted;
     if (n_pts) HIPCHK(c, hipMemcpyAsync(d_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_pts, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_begin, h_offsets, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_T, T, sizeof(float) * 12, hipMemcpyHostToDevice, st));

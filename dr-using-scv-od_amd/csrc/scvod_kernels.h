@@ -45,8 +45,12 @@ struct Arena {
     int16_t* pid;             // [N] patch id or -1
     uint64_t* keys;           // [N] (sortable z << 32 | local idx), patch-major per scan
     uint32_t* seg;            // [N] per patch: [ground part | non-ground part], bit31 = passes bin filter
-    float* scratch_xyz;       // [4N] spill (x|y|z|idx) for patches larger than the LDS tier
-    uint8_t* scratch_mask;    // [N]
+    float4* sorted;           // [N] per patch: points in (z, idx) order as {x, y, z, idx | keep << 31}
+    float* fit_thd;           // [B][kMaxPatches] th_dist_d_ of the last plane fit
+    int32_t* order;           // [B * kMaxPatches] live patches ordered by size class (descending)
+    int32_t* order_hist;      // [64]
+    int32_t* order_cursor;    // [64]
+    int32_t* order_off;       // [65]  ([64] = number of live patches)
     int32_t* patch_count;     // [B][kMaxPatches]
     int32_t* patch_cursor;    // [B][kMaxPatches]
     int32_t* patch_off;       // [B][kMaxPatches+1]

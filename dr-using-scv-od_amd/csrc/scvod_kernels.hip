@@ -57,19 +57,50 @@ __device__ __forceinline__ int block_excl_scan(int v, int& total, int* wsum) {
     return wsum[w] + inc - v;
 }
 
-// Normalised bitonic network (every comparator puts the minimum at the lower index), valid
-// for any n: indices >= n act as +inf.  Works on LDS or global (flat) storage.
+// Normalised bitonic network (every comparator puts the minimum at the lower index), valid for any n:
+// indices >= n act as +inf (all-ones key) and are never read or written.  Works on LDS or global (flat)
+// storage.  Register blocking: runs of 8 are sorted in registers (19-comparator network = stages
+// k = 2, 4, 8), and the butterfly steps of each later stage are taken three levels (8 elements per
+// thread) at a time, which cuts barriers and LDS traffic ~2.3x against one level per pass.
+template <typename T>
+__device__ __forceinline__ void cswap(T& x, T& y) {
+    const T lo = x < y ? x : y;
+    const T hi = x < y ? y : x;
+    x = lo;
+    y = hi;
+}
+
 template <int THREADS, typename T>
 __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
     if (n <= 1) return;
-    int np2 = 1;
+    const T INF = ~(T)0;
+    int np2 = 8;
     while (np2 < n) np2 <<= 1;
+    // stage k <= 8: in-register sort of aligned runs of 8
+    for (int g = threadIdx.x; g < (np2 >> 3); g += THREADS) {
+        const int b = g << 3;
+        if (b >= n) continue;
+        T e[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) e[m] = (b + m < n) ? a[b + m] : INF;
+        cswap(e[0], e[1]); cswap(e[2], e[3]); cswap(e[4], e[5]); cswap(e[6], e[7]);
+        cswap(e[0], e[2]); cswap(e[1], e[3]); cswap(e[4], e[6]); cswap(e[5], e[7]);
+        cswap(e[1], e[2]); cswap(e[5], e[6]);
+        cswap(e[0], e[4]); cswap(e[1], e[5]); cswap(e[2], e[6]); cswap(e[3], e[7]);
+        cswap(e[2], e[4]); cswap(e[3], e[5]);
+        cswap(e[1], e[2]); cswap(e[3], e[4]); cswap(e[5], e[6]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+            if (b + m < n) a[b + m] = e[m];
+    }
+    __syncthreads();
     const int half = np2 >> 1;
-    for (int k = 2; k <= np2; k <<= 1) {
+    for (int k = 16; k <= np2; k <<= 1) {
         const int hk = k >> 1;
+        // mirror step
         for (int t = threadIdx.x; t < half; t += THREADS) {
-            int blk = t / hk, off = t - blk * hk;
-            int i = blk * k + off, j = blk * k + (k - 1 - off);
+            const int blk = t / hk, off = t - blk * hk;
+            const int i = blk * k + off, j = blk * k + (k - 1 - off);
             if (j < n) {
                 T x = a[i], y = a[j];
                 if (x > y) {
@@ -79,17 +110,50 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
             }
         }
         __syncthreads();
-        for (int jj = k >> 2; jj >= 1; jj >>= 1) {
-            for (int t = threadIdx.x; t < half; t += THREADS) {
-                int i = ((t / jj) * 2 * jj) + (t % jj);
-                int j = i + jj;
-                if (j < n) {
-                    T x = a[i], y = a[j];
-                    if (x > y) {
-                        a[i] = y;
-                        a[j] = x;
+        int j = k >> 2;  // first butterfly distance of this stage (>= 4 because k >= 16)
+        while (j >= 1) {
+            if (j >= 4) {
+                const int jl = j >> 2;  // three levels: distances 4*jl, 2*jl, jl
+                for (int t = threadIdx.x; t < (np2 >> 3); t += THREADS) {
+                    const int b = (t / jl) * (jl << 3) + (t % jl);
+                    if (b >= n) continue;
+                    T e[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) e[m] = (b + m * jl < n) ? a[b + m * jl] : INF;
+                    cswap(e[0], e[4]); cswap(e[1], e[5]); cswap(e[2], e[6]); cswap(e[3], e[7]);
+                    cswap(e[0], e[2]); cswap(e[1], e[3]); cswap(e[4], e[6]); cswap(e[5], e[7]);
+                    cswap(e[0], e[1]); cswap(e[2], e[3]); cswap(e[4], e[5]); cswap(e[6], e[7]);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+                        if (b + m * jl < n) a[b + m * jl] = e[m];
+                }
+                j >>= 3;
+            } else if (j == 2) {
+                for (int t = threadIdx.x; t < (np2 >> 2); t += THREADS) {
+                    const int b = t << 2;
+                    if (b >= n) continue;
+                    T e[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) e[m] = (b + m < n) ? a[b + m] : INF;
+                    cswap(e[0], e[2]); cswap(e[1], e[3]);
+                    cswap(e[0], e[1]); cswap(e[2], e[3]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (b + m < n) a[b + m] = e[m];
+                }
+                j = 0;
+            } else {  // j == 1
+                for (int t = threadIdx.x; t < half; t += THREADS) {
+                    const int i = t << 1;
+                    if (i + 1 < n) {
+                        T x = a[i], y = a[i + 1];
+                        if (x > y) {
+                            a[i] = y;
+                            a[i + 1] = x;
+                        }
                     }
                 }
+                j = 0;
             }
             __syncthreads();
         }
@@ -177,44 +241,127 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 }
 
 // ------------------------------------------------------------------------------------------
-// Patchwork stage 2: one workgroup per (scan, patch).
-//   sort by (z, idx) -> seeds -> 3 x {sequential fp32 moments, mean/cov, 3x3 Jacobi SVD,
-//   plane distance test} -> gating -> [ground part | non-ground part] + bin-filter bits.
-// Two tiers are launched over the same grid: CAP=1024/64 threads (9 WG per CU) takes patches
-// with n <= 1024, CAP=8192/512 threads (1 WG per CU) the rest; a patch larger than 8192 points
-// runs the same code on global scratch.
+// Patchwork stage 2 (extract_piecewiseground + gating), split so that every phase has the
+// parallel shape that fits it:
+//   k_pw_sort     one workgroup per (scan, patch): LDS bitonic sort by (z, idx), then writes the
+//                 patch's points in sorted order as float4 {x, y, z, idx | keep-bit} (keep = verdict
+//                 of makeApriVec's range/FOV test).  Tiers: 1024 keys/64 threads, 8192/512, global.
+//   k_pw_order_*  orders the live patches of the whole batch by size class so that the 64 lanes of a
+//                 wave of k_pw_fit walk patches of similar length.
+//   k_pw_fit      ONE THREAD PER PATCH.  The reference's plane fit is a strictly sequential fp32
+//                 computation per patch (9 running sums in z order, 3x3 Jacobi SVD, repeat 3x); it
+//                 cannot be tree-reduced without changing bits, but 504 x B patches are independent,
+//                 so each lane streams its own patch (16 B per point) and keeps the 9 accumulators in
+//                 registers.  No LDS, no cross-lane traffic, SVD runs in all 64 lanes at once.
+//   k_pw_arrange  one wave per patch: final plane test, [ground part | non-ground part] arrangement
+//                 and the per-patch counters the ordered emission needs.
 // ------------------------------------------------------------------------------------------
-struct PatchStore {
-    uint64_t* keys;  // sorted in place
-    float* x;
-    float* y;
-    float* z;
-    uint32_t* idx;
-    uint8_t* mask;
-};
+template <int CAP, int THREADS, int MIN_N>
+__global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int p = blockIdx.x, s = blockIdx.y;
+    const int n = A.patch_count[s * kMaxPatches + p];
+    if (n <= P.czm.num_min_pts || n <= MIN_N) return;
+    if (MIN_N == 0 && n > CAP) return;  // left to the large tier
+    const int base = A.scan_off[s];
+    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+    uint64_t* keys;
+    if (n <= CAP) {
+        keys = (uint64_t*)smem;
+        for (int j = threadIdx.x; j < n; j += THREADS) keys[j] = A.keys[(size_t)base + off + j];
+        __syncthreads();
+    } else {
+        keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
+    }
+    block_bitonic_sort<THREADS>(keys, n);
+    float4* dst = A.sorted + (size_t)base + off;
+    for (int j = threadIdx.x; j < n; j += THREADS) {
+        const uint32_t id = (uint32_t)keys[j];
+        const float4 q = A.pts[base + id];
+        Apri a;
+        const int keep = apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
+        dst[j] = make_float4(q.x, q.y, q.z, u2f(id | (keep ? 0x80000000u : 0u)));
+    }
+}
 
-template <int THREADS>
-__device__ void patch_body(const DevParams& P, const Arena& A, int s, int p, int base, int off, int n, PatchStore S,
-                           int* wsum, float* sh /* >= 32 floats */) {
-    const int tid = threadIdx.x;
-    // ---- sort (z ascending, ties by input index) ----
-    block_bitonic_sort<THREADS>(S.keys, n);
-    // ---- gather sorted points (x/y alias the key storage in the LDS tiers: extract every idx
-    // first, then overwrite) ----
-    for (int j = tid; j < n; j += THREADS) {
-        uint32_t id = (uint32_t)S.keys[j];
-        S.idx[j] = id;
-        S.z[j] = A.pts[base + id].z;
+__device__ __forceinline__ int pw_size_class(int n) {  // quarter-octave classes, 0..63
+    int lg = 31 - __clz(n);
+    int frac = (lg >= 2) ? ((n >> (lg - 2)) & 3) : 0;
+    int c = lg * 4 + frac;
+    return c > 63 ? 63 : c;
+}
+
+__global__ __launch_bounds__(256) void k_pw_order_count(DevParams P, Arena A) {
+    __shared__ int hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < A.n_scans * P.n_patches) {
+        const int s = t / P.n_patches, p = t - s * P.n_patches;
+        const int n = A.patch_count[s * kMaxPatches + p];
+        if (n <= P.czm.num_min_pts) {  // skipped patch (patchwork.h:331): record only
+            PatchRec r = {n, 0, 0, 0, 0};
+            A.patch_rec[s * kMaxPatches + p] = r;
+            scvod_patch_plane pl = {};
+            pl.n_pts = n;
+            A.planes[s * kMaxPatches + p] = pl;
+        } else {
+            atomicAdd(&hist[pw_size_class(n)], 1);
+        }
     }
     __syncthreads();
-    for (int j = tid; j < n; j += THREADS) {
-        float4 q = A.pts[base + S.idx[j]];
-        S.x[j] = q.x;
-        S.y[j] = q.y;
+    if (threadIdx.x < 64 && hist[threadIdx.x]) atomicAdd(&A.order_hist[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void k_pw_order_offsets(Arena A) {
+    // descending size: class 63 first
+    const int c = 63 - threadIdx.x;
+    const int v = A.order_hist[c];
+    const int inc = wave_incl_scan(v);
+    A.order_off[c] = inc - v;
+    if (threadIdx.x == 63) A.order_off[64] = inc;  // number of live patches
+}
+
+__global__ __launch_bounds__(256) void k_pw_order_scatter(DevParams P, Arena A) {
+    __shared__ int hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    int c = -1, rank = 0, code = 0;
+    if (t < A.n_scans * P.n_patches) {
+        const int s = t / P.n_patches, p = t - s * P.n_patches;
+        const int n = A.patch_count[s * kMaxPatches + p];
+        if (n > P.czm.num_min_pts) {
+            c = pw_size_class(n);
+            rank = atomicAdd(&hist[c], 1);
+            code = s * kMaxPatches + p;
+        }
     }
     __syncthreads();
+    if (threadIdx.x < 64 && hist[threadIdx.x])
+        hist[threadIdx.x] = A.order_off[threadIdx.x] + atomicAdd(&A.order_cursor[threadIdx.x], hist[threadIdx.x]);
+    __syncthreads();
+    if (c >= 0) A.order[hist[c] + rank] = code;
+}
 
-    // zone of this patch
+// per-point plane residual, Eigen GEMV order: fl(fl(x*n0 + y*n1) + z*n2)
+__device__ __forceinline__ float plane_res(const float4& q, float n0, float n1, float n2) {
+    float r = q.x * n0;
+    r = r + q.y * n1;
+    r = r + q.z * n2;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= A.order_off[64]) return;
+    const int code = A.order[t];
+    const int s = code / kMaxPatches, p = code - s * kMaxPatches;
+    const int n = A.patch_count[s * kMaxPatches + p];
+    const int base = A.scan_off[s];
+    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+    const float4* __restrict__ sp = A.sorted + (size_t)base + off;
+
     int zone = 0;
     while (zone < 3 && p >= P.czm.patch_base[zone + 1]) ++zone;
     const int ring = (p - P.czm.patch_base[zone]) / P.czm.num_sectors[zone];
@@ -222,259 +369,197 @@ __device__ void patch_body(const DevParams& P, const Arena& A, int s, int p, int
     for (int k = 0; k < zone; ++k) concentric_idx += P.czm.num_rings[k];
 
     // ---- extract_initial_seeds_ (patchwork.h:235-268) ----
-    if (tid == 0) {
-        int init_idx = 0;
-        if (zone == 0) {
-            while (init_idx < n && (double)S.z[init_idx] < P.czm.seed_margin_z) ++init_idx;
-        }
-        double sum = 0;
-        int cnt = 0;
-        for (int i = init_idx; i < n && cnt < P.czm.num_lpr; ++i) {
-            sum += (double)S.z[i];
-            ++cnt;
-        }
-        double lpr = cnt != 0 ? sum / cnt : 0.0;
-        double thr = lpr + P.czm.th_seeds;
-        ((double*)sh)[0] = thr;
+    int init_idx = 0;
+    if (zone == 0) {
+        while (init_idx < n && (double)sp[init_idx].z < P.czm.seed_margin_z) ++init_idx;
     }
-    __syncthreads();
-    {
-        const double thr = ((double*)sh)[0];
-        for (int j = tid; j < n; j += THREADS) S.mask[j] = ((double)S.z[j] < thr) ? 1 : 0;
+    double sum = 0;
+    int cnt = 0;
+    for (int i = init_idx; i < n && cnt < P.czm.num_lpr; ++i) {
+        sum += (double)sp[i].z;
+        ++cnt;
     }
-    __syncthreads();
+    const double lpr = cnt != 0 ? sum / cnt : 0.0;
+    const double seed_thr = lpr + P.czm.th_seeds;
 
-    // persistent plane state of this patch (sh[8..]): cov[9], mean[3], normal[3], sv[3], th_dist_d
-    float* st_cov = sh + 8;      // 9
-    float* st_mean = sh + 17;    // 3
-    float* st_normal = sh + 20;  // 3
-    float* st_sv = sh + 23;      // 3
-    float* st_thd = sh + 26;     // 1
-    if (tid < 19) sh[8 + tid] = 0.f;
-    __syncthreads();
+    float cov[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mean0 = 0.f, mean1 = 0.f, mean2 = 0.f;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, thd = 0.f;
+    float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f;
 
     for (int iter = 0; iter < P.czm.num_iter; ++iter) {
-        // ---- pcl::computeMeanAndCovarianceMatrix: 9 sequential fp32 chains, lanes 0..8 of
-        // wave 0 each own one accumulator; points are broadcast reads from the store ----
-        if (tid < 64) {
-            const int k = tid;
-            // accumulator k multiplies a_k * b_k : (xx, xy, xz, yy, yz, zz, x, y, z)
-            const int sa = (k < 3) ? 0 : (k < 5) ? 1 : (k == 5) ? 2 : (k - 6);
-            const int sb = (k < 3) ? k : (k < 5) ? (k - 2) : (k == 5) ? 2 : 3;
-            float acc = 0.f;
-            int cnt = 0;
-            if (k < 9) {
-                for (int j = 0; j < n; ++j) {
-                    float px = S.x[j], py = S.y[j], pz = S.z[j];
-                    int m = S.mask[j];
-                    float a = (sa == 0) ? px : (sa == 1) ? py : pz;
-                    float b = (sb == 0) ? px : (sb == 1) ? py : (sb == 2) ? pz : 1.0f;
-                    float term = a * b;
-                    if (m) {
-                        acc = acc + term;
-                        ++cnt;
-                    }
-                }
+        // pcl::computeMeanAndCovarianceMatrix over the current ground set, strictly in z order
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f;
+        int m = 0;
+        // The lane streams its patch in blocks of PF points, next block in flight while the current
+        // one is accumulated (the only loop-carried dependence is the 9 fp32 adds).  Indices are
+        // clamped so every load is valid; membership is a select, adding +0.0f is exact here
+        // because the accumulators can never be -0.0f.
+        constexpr int PF = 8;
+        float4 cur[PF], nxt[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) cur[k] = sp[min(k, n - 1)];
+        for (int j0 = 0; j0 < n; j0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) nxt[k] = sp[min(j0 + PF + k, n - 1)];
+            if (iter == 0 && !((double)cur[0].z < seed_thr)) break;  // seeds are a prefix (z-sorted)
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const float4 q = cur[k];
+                bool in = (j0 + k < n);
+                if (iter == 0)
+                    in = in && ((double)q.z < seed_thr);
+                else
+                    in = in && (plane_res(q, n0, n1, n2) < thd);
+                const float t0 = q.x * q.x, t1 = q.x * q.y, t2 = q.x * q.z, t3 = q.y * q.y, t4 = q.y * q.z,
+                            t5 = q.z * q.z;
+                a0 += in ? t0 : 0.f;
+                a1 += in ? t1 : 0.f;
+                a2 += in ? t2 : 0.f;
+                a3 += in ? t3 : 0.f;
+                a4 += in ? t4 : 0.f;
+                a5 += in ? t5 : 0.f;
+                a6 += in ? q.x : 0.f;
+                a7 += in ? q.y : 0.f;
+                a8 += in ? q.z : 0.f;
+                m += in ? 1 : 0;
             }
-            // gather the 9 accumulators on lane 0
-            float acc_all[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) acc_all[q] = __shfl(acc, q, 64);
-            cnt = __shfl(cnt, 0, 64);
-            if (tid == 0) {
-                if (cnt != 0) {
-                    float fn = (float)cnt;
-                    float accu[9];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) accu[q] = acc_all[q] / fn;
-                    st_mean[0] = accu[6];
-                    st_mean[1] = accu[7];
-                    st_mean[2] = accu[8];
-                    float c00 = accu[0] - accu[6] * accu[6];
-                    float c01 = accu[1] - accu[6] * accu[7];
-                    float c02 = accu[2] - accu[6] * accu[8];
-                    float c11 = accu[3] - accu[7] * accu[7];
-                    float c12 = accu[4] - accu[7] * accu[8];
-                    float c22 = accu[5] - accu[8] * accu[8];
-                    st_cov[0] = c00;
-                    st_cov[1] = c01;
-                    st_cov[2] = c02;
-                    st_cov[3] = c01;
-                    st_cov[4] = c11;
-                    st_cov[5] = c12;
-                    st_cov[6] = c02;
-                    st_cov[7] = c12;
-                    st_cov[8] = c22;
-                }
-                float cov[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) cov[q] = st_cov[q];
-                Svd3 sv;
-                svd3_jacobi(cov, sv);
-                float n0 = sv.U[2], n1 = sv.U[5], n2 = sv.U[8];
-                st_normal[0] = n0;
-                st_normal[1] = n1;
-                st_normal[2] = n2;
-                st_sv[0] = sv.sv[0];
-                st_sv[1] = sv.sv[1];
-                st_sv[2] = sv.sv[2];
-                float dot = n0 * st_mean[0];
-                dot = dot + n1 * st_mean[1];
-                dot = dot + n2 * st_mean[2];
-                float d = -dot;
-                st_thd[0] = (float)(P.czm.th_dist - (double)d);
-            }
+            for (int k = 0; k < PF; ++k) cur[k] = nxt[k];
         }
-        __syncthreads();
-        // ---- plane distance test on every point of the patch (Eigen GEMV order) ----
-        {
-            const float n0 = st_normal[0], n1 = st_normal[1], n2 = st_normal[2], thd = st_thd[0];
-            for (int j = tid; j < n; j += THREADS) {
-                float res = S.x[j] * n0;
-                res = res + S.y[j] * n1;
-                res = res + S.z[j] * n2;
-                S.mask[j] = (res < thd) ? 1 : 0;
-            }
+        if (m != 0) {  // an empty set leaves cov_/pc_mean_ untouched (PCL)
+            const float fn = (float)m;
+            a0 = a0 / fn;
+            a1 = a1 / fn;
+            a2 = a2 / fn;
+            a3 = a3 / fn;
+            a4 = a4 / fn;
+            a5 = a5 / fn;
+            a6 = a6 / fn;
+            a7 = a7 / fn;
+            a8 = a8 / fn;
+            mean0 = a6;
+            mean1 = a7;
+            mean2 = a8;
+            cov[0] = a0 - a6 * a6;
+            cov[1] = a1 - a6 * a7;
+            cov[2] = a2 - a6 * a8;
+            cov[4] = a3 - a7 * a7;
+            cov[5] = a4 - a7 * a8;
+            cov[8] = a5 - a8 * a8;
+            cov[3] = cov[1];
+            cov[6] = cov[2];
+            cov[7] = cov[5];
         }
-        __syncthreads();
+        Svd3 sv;
+        svd3_jacobi(cov, sv);
+        n0 = sv.U[2];
+        n1 = sv.U[5];
+        n2 = sv.U[8];
+        sv0 = sv.sv[0];
+        sv1 = sv.sv[1];
+        sv2 = sv.sv[2];
+        float dot = n0 * mean0;
+        dot = dot + n1 * mean1;
+        dot = dot + n2 * mean2;
+        const float d = -dot;
+        thd = (float)(P.czm.th_dist - (double)d);
     }
 
     // ---- gating (patchwork.h:339-384) ----
     int status;
     {
-        const double ground_z_vec = (double)fabs_f(st_normal[2]);
-        const double ground_z_elevation = (double)st_mean[2];
-        float svmin = st_sv[0];
-        if (st_sv[1] < svmin) svmin = st_sv[1];
-        if (st_sv[2] < svmin) svmin = st_sv[2];
-        const double surface_variable = (double)(svmin / (st_sv[0] + st_sv[1] + st_sv[2]));
+        const double ground_z_vec = (double)fabs_f(n2);
+        const double ground_z_elevation = (double)mean2;
+        float svmin = sv0;
+        if (sv1 < svmin) svmin = sv1;
+        if (sv2 < svmin) svmin = sv2;
+        const double surface_variable = (double)(svmin / (sv0 + sv1 + sv2));
         if (ground_z_vec < P.czm.uprightness_thr) {
             status = 2;
         } else if (concentric_idx < P.czm.num_rings_of_interest) {
             const int e = ring + 2 * zone;
-            if (ground_z_elevation > P.czm.elevation_thr[e]) {
+            if (ground_z_elevation > P.czm.elevation_thr[e])
                 status = (P.czm.flatness_thr[e] > surface_variable) ? 1 : 3;
-            } else {
+            else
                 status = 1;
-            }
         } else {
             status = 1;
         }
     }
+    scvod_patch_plane pl;
+    pl.normal[0] = n0;
+    pl.normal[1] = n1;
+    pl.normal[2] = n2;
+    pl.mean[0] = mean0;
+    pl.mean[1] = mean1;
+    pl.mean[2] = mean2;
+    pl.sv[0] = sv0;
+    pl.sv[1] = sv1;
+    pl.sv[2] = sv2;
+    pl.n_pts = n;
+    pl.n_ground = 0;  // filled by k_pw_arrange
+    pl.status = status;
+    A.planes[s * kMaxPatches + p] = pl;
+    A.fit_thd[s * kMaxPatches + p] = thd;
+}
 
-    // ---- arrange [ground part | non-ground part] keeping the sorted order, attach the
-    // makeApriVec range/FOV verdict of every point (used by k_emit for ordered compaction) ----
+// one wave per (scan, patch): final plane test of every point (patchwork.h:488-501), keeps the
+// z order inside the ground part and the non-ground part, counts what k_emit_offsets needs.
+__global__ __launch_bounds__(64) void k_pw_arrange(DevParams P, Arena A) {
+    const int p = blockIdx.x, s = blockIdx.y;
+    const int n = A.patch_count[s * kMaxPatches + p];
+    if (n <= P.czm.num_min_pts) return;
+    const int base = A.scan_off[s];
+    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+    const float4* __restrict__ sp = A.sorted + (size_t)base + off;
+    const scvod_patch_plane pl = A.planes[s * kMaxPatches + p];
+    const float n0 = pl.normal[0], n1 = pl.normal[1], n2 = pl.normal[2];
+    const float thd = A.fit_thd[s * kMaxPatches + p];
+    const int lane = threadIdx.x;
+    // pass 1: size of the ground part and the filter counts
     int n_g = 0, a_g = 0, a_ng = 0;
-    {
-        // first pass: count ground
-        int run_g = 0, run_ag = 0, run_ang = 0;
-        for (int j0 = 0; j0 < n; j0 += THREADS) {
-            int j = j0 + tid;
-            int g = 0, keep = 0;
-            if (j < n) {
-                g = S.mask[j];
-                Apri a;
-                float4 q = A.pts[base + S.idx[j]];
-                keep = apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-            }
-            int tg, tk;
-            int eg = block_excl_scan<THREADS>(g, tg, wsum);
-            int ekg = block_excl_scan<THREADS>(g & keep, tk, wsum);
-            int tkn;
-            int ekn = block_excl_scan<THREADS>((!g) & keep, tkn, wsum);
-            (void)ekg;
-            (void)ekn;
-            if (j < n) {
-                // stash rank and flags: low 2 bits flags, rest = rank among same class
-                int rank = g ? (run_g + eg) : ((j - (run_g + eg)));
-                S.keys[j] = ((uint64_t)(uint32_t)rank << 2) | (uint64_t)(g ? 1 : 0) | (uint64_t)(keep ? 2 : 0);
-            }
-            run_g += tg;
-            run_ag += tk;
-            run_ang += tkn;
-            __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        int g = 0, keep = 0;
+        if (j < n) {
+            const float4 q = sp[j];
+            g = plane_res(q, n0, n1, n2) < thd;
+            keep = (int)(f2u(q.w) >> 31);
         }
-        n_g = run_g;
-        a_g = run_ag;
-        a_ng = run_ang;
+        n_g += __popcll(__ballot(g));
+        a_g += __popcll(__ballot(g && keep));
+        a_ng += __popcll(__ballot(!g && keep && j < n));
     }
-    // NOTE: S.keys aliases S.x/S.y in the LDS tiers; x/y are dead from here on.
-    for (int j = tid; j < n; j += THREADS) {
-        uint64_t v = S.keys[j];
-        int g = (int)(v & 1), keep = (int)((v >> 1) & 1);
-        int rank = (int)(v >> 2);
-        int dst = g ? rank : (n_g + rank);
-        A.seg[(size_t)base + off + dst] = S.idx[j] | (keep ? 0x80000000u : 0u);
+    // pass 2: ordered placement
+    int run_g = 0;
+    uint32_t* seg = A.seg + (size_t)base + off;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        int g = 0;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < n) {
+            q = sp[j];
+            g = plane_res(q, n0, n1, n2) < thd;
+        }
+        const unsigned long long bg = __ballot(g);
+        const int eg = __popcll(bg & ((1ull << lane) - 1ull));
+        if (j < n) {
+            const int dst = g ? (run_g + eg) : (n_g + (j - (run_g + eg)));
+            seg[dst] = f2u(q.w);
+        }
+        run_g += __popcll(bg);
     }
-    if (tid == 0) {
+    if (lane == 0) {
         PatchRec r;
         r.n = n;
         r.n_g = n_g;
-        r.status = status;
+        r.status = pl.status;
         r.a_g = a_g;
         r.a_ng = a_ng;
         A.patch_rec[s * kMaxPatches + p] = r;
-        scvod_patch_plane pl;
-        for (int c = 0; c < 3; ++c) {
-            pl.normal[c] = st_normal[c];
-            pl.mean[c] = st_mean[c];
-            pl.sv[c] = st_sv[c];
-        }
-        pl.n_pts = n;
-        pl.n_ground = n_g;
-        pl.status = status;
-        A.planes[s * kMaxPatches + p] = pl;
+        A.planes[s * kMaxPatches + p].n_ground = n_g;
     }
-}
-
-template <int CAP, int THREADS, int MIN_N>
-__global__ __launch_bounds__(THREADS) void k_pw_patch(DevParams P, Arena A) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int p = blockIdx.x, s = blockIdx.y;
-    const int n = A.patch_count[s * kMaxPatches + p];
-    const int base = A.scan_off[s];
-    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
-    if (MIN_N == 0 && n <= P.czm.num_min_pts) {
-        // skipped patch (patchwork.h:331): record only
-        if (threadIdx.x == 0) {
-            PatchRec r = {n, 0, 0, 0, 0};
-            A.patch_rec[s * kMaxPatches + p] = r;
-            scvod_patch_plane pl = {};
-            pl.n_pts = n;
-            A.planes[s * kMaxPatches + p] = pl;
-        }
-        return;
-    }
-    if (n <= MIN_N || n <= P.czm.num_min_pts) return;
-    if (MIN_N == 0 && n > CAP) return;  // left to the large tier
-    // carve LDS: keys (aliased by x,y) | z | idx | mask | wsum | sh
-    uint64_t* l_keys = (uint64_t*)smem;
-    float* l_z = (float*)(smem + (size_t)CAP * 8);
-    uint32_t* l_idx = (uint32_t*)(smem + (size_t)CAP * 12);
-    uint8_t* l_mask = (uint8_t*)(smem + (size_t)CAP * 16);
-    int* wsum = (int*)(smem + (size_t)CAP * 17);
-    float* sh = (float*)(smem + (size_t)CAP * 17 + 128);
-    PatchStore S;
-    if (n <= CAP) {
-        // stage keys in LDS
-        for (int j = threadIdx.x; j < n; j += THREADS) l_keys[j] = A.keys[(size_t)base + off + j];
-        __syncthreads();
-        S.keys = l_keys;
-        S.x = (float*)l_keys;
-        S.y = (float*)l_keys + CAP;
-        S.z = l_z;
-        S.idx = l_idx;
-        S.mask = l_mask;
-    } else {
-        // oversize patch: same algorithm on global storage (rare; correctness path)
-        S.keys = A.keys + (size_t)base + off;
-        S.x = A.scratch_xyz + 4 * ((size_t)base + off);
-        S.y = S.x + n;
-        S.z = S.y + n;
-        S.idx = (uint32_t*)(S.z + n);
-        S.mask = A.scratch_mask + (size_t)base + off;
-    }
-    patch_body<THREADS>(P, A, s, p, base, off, n, S, wsum, sh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -974,9 +1059,8 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(const float* __restrict
 #define TH_END(name) \
     if (th) th(tu, name, 0)
 
-constexpr int kPatchCapS = 1024, kPatchThreadsS = 64;
-constexpr int kPatchCapL = 8192, kPatchThreadsL = 512;
-constexpr size_t patch_lds_bytes(int cap) { return (size_t)cap * 17 + 128 + 256; }
+constexpr int kSortCapS = 1024, kSortThreadsS = 64;
+constexpr int kSortCapL = 8192, kSortThreadsL = 512;
 constexpr int kVoxCapS = 1024, kVoxThreadsS = 64;
 constexpr int kVoxCapL = 8192, kVoxThreadsL = 512;
 constexpr size_t vox_lds_bytes(int cap) { return (size_t)cap * 12 + 16 + 128; }
@@ -999,16 +1083,29 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_scatter, gcls, dim3(kClsThreads), 0, st, P, A);
         TH_END("pw_scatter");
         dim3 gp(P.n_patches, B);
-        hipFuncSetAttribute((const void*)k_pw_patch<kPatchCapL, kPatchThreadsL, kPatchCapS>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)patch_lds_bytes(kPatchCapL));
-        TH_BEGIN("pw_patch_small");
-        hipLaunchKernelGGL((k_pw_patch<kPatchCapS, kPatchThreadsS, 0>), gp, dim3(kPatchThreadsS),
-                           patch_lds_bytes(kPatchCapS), st, P, A);
-        TH_END("pw_patch_small");
-        TH_BEGIN("pw_patch_large");
-        hipLaunchKernelGGL((k_pw_patch<kPatchCapL, kPatchThreadsL, kPatchCapS>), gp, dim3(kPatchThreadsL),
-                           patch_lds_bytes(kPatchCapL), st, P, A);
-        TH_END("pw_patch_large");
+        hipMemsetAsync(A.order_hist, 0, sizeof(int32_t) * 64, st);
+        hipMemsetAsync(A.order_cursor, 0, sizeof(int32_t) * 64, st);
+        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL, kSortCapS>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCapL * 8);
+        TH_BEGIN("pw_sort_small");
+        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS, 0>), gp, dim3(kSortThreadsS), kSortCapS * 8, st, P, A);
+        TH_END("pw_sort_small");
+        TH_BEGIN("pw_sort_large");
+        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL, kSortCapS>), gp, dim3(kSortThreadsL), kSortCapL * 8, st,
+                           P, A);
+        TH_END("pw_sort_large");
+        const int n_all = B * P.n_patches;
+        TH_BEGIN("pw_order");
+        hipLaunchKernelGGL(k_pw_order_count, dim3((n_all + 255) / 256), dim3(256), 0, st, P, A);
+        hipLaunchKernelGGL(k_pw_order_offsets, dim3(1), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(k_pw_order_scatter, dim3((n_all + 255) / 256), dim3(256), 0, st, P, A);
+        TH_END("pw_order");
+        TH_BEGIN("pw_fit");
+        hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
+        TH_END("pw_fit");
+        TH_BEGIN("pw_arrange");
+        hipLaunchKernelGGL(k_pw_arrange, gp, dim3(64), 0, st, P, A);
+        TH_END("pw_arrange");
         TH_BEGIN("emit_offsets");
         hipLaunchKernelGGL(k_emit_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("emit_offsets");
