@@ -73,6 +73,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import scvod_py
+    import shard
     import synth
 
     P = scvod_py.make_params(args.preset)
@@ -166,15 +167,7 @@ def main():
     barrier()
     ctx.set_timing(False)
 
-    if dist is not None:
-        tdt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
-        agg = torch.tensor([float(args.scans), float(total_pts)], device=dev, dtype=torch.float64)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        all_scans, all_pts = float(agg[0].item()), float(agg[1].item())
-    else:
-        all_scans, all_pts = float(args.scans), float(total_pts)
+    dt, all_scans, all_pts = shard.aggregate(dist, dev, dt, args.scans, total_pts)
 
     if rank == 0:
         scans_per_s = all_scans * args.steps / dt

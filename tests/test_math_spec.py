@@ -1,0 +1,96 @@
+"""The product's arithmetic spec header (scvod_math.h, compiled for the CPU) against glibc -- what
+the reference calls -- and against the oracle.  Not gpu."""
+import ctypes as C
+
+import numpy as np
+
+
+def _cmp32(spec, y, x):
+    fb = C.c_long(-1)
+    return spec.spec_cmp_atan2f(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_long(len(y)), C.byref(fb))
+
+
+def test_atan2f_bit_identical_to_glibc(spec):
+    rng = np.random.default_rng(1)
+    n = 2_000_000
+    sets = [
+        (rng.uniform(-80, 80, n), rng.uniform(-80, 80, n)),
+        (rng.uniform(-5, 5, n), rng.uniform(0, 80, n)),                       # getAzimuth(z, dis)
+        (rng.choice([-1, 1], n) * np.exp(rng.uniform(-40, 40, n)), rng.choice([-1, 1], n) * np.exp(rng.uniform(-40, 40, n))),
+    ]
+    for y, x in sets:
+        assert _cmp32(spec, y.astype(np.float32), x.astype(np.float32)) == 0
+    bits = lambda: rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    assert _cmp32(spec, bits(), bits()) == 0
+    assert _cmp32(spec, bits(), np.ones(n, np.float32)) == 0                   # atanf path
+    edge = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 1e-45, -1e-45, 3.4e38, 0.4375, 0.6875, 1.1875, 2.4375,
+                     2.0**25, 2.0**-29, 1.5, 30.0, 80.0], np.float32)
+    yy, xx = np.meshgrid(edge, edge)
+    assert _cmp32(spec, yy.ravel().copy(), xx.ravel().copy()) == 0
+
+
+def test_atan2_f64_within_one_ulp_of_glibc(spec):
+    rng = np.random.default_rng(2)
+    n = 2_000_000
+    y = rng.uniform(-80, 80, n).astype(np.float32).astype(np.float64)
+    x = rng.uniform(-80, 80, n).astype(np.float32).astype(np.float64)
+    worst = spec.spec_cmp_atan2(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_long(n))
+    assert worst <= 1.0
+    # exact directions land exactly on sector boundaries: both must agree bit for bit there
+    for yy, xx in [(0.0, 1.0), (1.0, 0.0), (1.0, 1.0), (0.0, -1.0), (-1.0, 0.0), (-1.0, -1.0), (2.5, 2.5), (-3.0, 3.0)]:
+        assert spec.spec_atan2(yy, xx) == np.arctan2(yy, xx)
+
+
+def test_svd3_spec_equals_oracle(spec, oracle):
+    rng = np.random.default_rng(3)
+    for k in range(2000):
+        if k % 4 == 0:   # nearly planar cloud (the Patchwork case)
+            p = rng.normal(0, [3.0, 2.0, 0.02], (50, 3))
+        elif k % 4 == 1:
+            p = rng.normal(0, 1, (20, 3)) * rng.uniform(0.01, 30)
+        elif k % 4 == 2:  # rank deficient
+            p = np.outer(rng.normal(0, 1, 30), rng.normal(0, 1, 3))
+        else:
+            p = rng.normal(0, 1, (10, 3)) + rng.uniform(-60, 60, 3)
+        cov = np.cov(p.T, bias=True).astype(np.float32)
+        sv = np.zeros(3, np.float32)
+        U = np.zeros(9, np.float32)
+        c = np.ascontiguousarray(cov.reshape(9))
+        spec.spec_svd3(c.ctypes.data_as(C.c_void_p), sv.ctypes.data_as(C.c_void_p), U.ctypes.data_as(C.c_void_p))
+        osv, oU = oracle.svd3(cov)
+        assert np.array_equal(sv.view(np.uint32), osv.view(np.uint32))
+        assert np.array_equal(U.view(np.uint32), oU.reshape(9).view(np.uint32))
+        # and it is an SVD: singular values descending, U orthonormal, cov ~= U S U^T up to sign
+        assert sv[0] >= sv[1] >= sv[2] >= 0
+        Um = U.reshape(3, 3).astype(np.float64)
+        assert np.allclose(Um.T @ Um, np.eye(3), atol=1e-5)
+        assert np.allclose(np.sort(np.linalg.svd(cov.astype(np.float64), compute_uv=False))[::-1], sv, rtol=2e-4,
+                           atol=2e-6 * max(1.0, float(sv[0])))
+
+
+def test_apri_spec_equals_oracle_binning(spec, oracle, scvod):
+    rng = np.random.default_rng(4)
+    for preset in ("semantickitti", "parkinglot", "os128_fine"):
+        P = scvod.make_params(preset)
+        dims = oracle.grid_dims(P)
+        x = rng.uniform(-45, 45, (20000, 4)).astype(np.float32)
+        x[:, 2] = rng.uniform(-4, 8, 20000)
+        x[:50, 1] = 0.0
+        x[50:60, :2] = 0.0
+        x[60:70, 0], x[60:70, 1] = P.min_dis, 0.0
+        b = oracle.bin(P, x, False)
+        g = (C.c_float * 9)(P.min_dis, P.max_dis, P.min_angle, P.max_angle, P.min_azimuth, P.max_azimuth, P.range_res,
+                            P.sector_res, P.azimuth_res)
+        d = (C.c_int * 4)(*dims)
+        of, oi = (C.c_float * 7)(), (C.c_int * 4)()
+        keep_o = oracle.bin(P, x, True)["src"]
+        keep_set = set(keep_o.tolist())
+        for i in range(0, 20000, 7):
+            p = (C.c_float * 4)(*x[i])
+            keep = spec.spec_apri(g, d, p, of, oi)
+            a = b["apri"][i]
+            got = np.array(list(of), np.float32)
+            exp = np.array([a["x"], a["y"], a["z"], a["range"], a["angle"], a["azimuth"], a["intensity"]], np.float32)
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (preset, i)
+            assert list(oi) == [a["range_idx"], a["sector_idx"], a["azimuth_idx"], a["voxel_idx"]]
+            assert bool(keep) == (i in keep_set)

@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: two gloo ranks shard a sequence with the same helpers bench.py uses, each rank
+runs the (oracle) hot path on its shard, and the summary reduction (SUM of units, MAX of time) matches
+the single-process run.  Not gpu."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_scans, q):
+    sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_py
+    import scvod_py
+    import shard
+    import synth
+    orc = oracle_py.load()
+    P = scvod_py.make_params("parkinglot")
+    lo, hi = shard.block_range(n_scans, rank, world)
+    counts = []
+    for i in range(lo, hi):
+        pts, _, _ = synth.make_scan(3, i, "PARK")
+        x = pts.numpy()
+        o = orc.patchwork(P, x, 1)
+        b = orc.bin(P, x[o["nonground_idx"]], True)
+        v = orc.voxelize(P, b["apri"])
+        counts.append([x.shape[0], len(o["ground_idx"]), len(b["apri"]), len(v["vox_key"])])
+    counts = np.asarray(counts, np.int64).reshape(-1, 4)
+    dt, scans, pts_total = shard.aggregate(dist, torch.device("cpu"), 1.0 + rank, hi - lo, int(counts[:, 0].sum()))
+    # gather the per-scan counters to check nothing was lost or duplicated
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, counts.tolist()))
+    rr = shard.round_robin(n_scans, rank, world)
+    allrr = [None] * world
+    dist.all_gather_object(allrr, rr.tolist())
+    if rank == 0:
+        q.put(dict(dt=dt, scans=scans, pts=pts_total, gathered=gathered, rr=allrr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reduction(oracle, scvod):
+    import shard
+    import synth
+    n_scans, world = 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_scans, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["dt"] == 2.0 and res["scans"] == n_scans          # MAX of (1.0, 2.0), SUM of shard sizes
+    blocks = sorted((lo, hi) for lo, hi, _ in res["gathered"])
+    assert blocks[0][0] == 0 and blocks[-1][1] == n_scans and blocks[0][1] == blocks[1][0]
+    assert sorted(sum(res["rr"], [])) == list(range(n_scans))
+    P = scvod.make_params("parkinglot")
+    single = []
+    for i in range(n_scans):
+        pts, _, _ = synth.make_scan(3, i, "PARK")
+        x = pts.numpy()
+        o = oracle.patchwork(P, x, 1)
+        b = oracle.bin(P, x[o["nonground_idx"]], True)
+        v = oracle.voxelize(P, b["apri"])
+        single.append([x.shape[0], len(o["ground_idx"]), len(b["apri"]), len(v["vox_key"])])
+    sharded = sum((c for _, _, c in sorted(res["gathered"])), [])
+    assert sharded == single
+    assert res["pts"] == sum(s[0] for s in single)
+
+
+def test_block_range_properties():
+    import shard
+    for n in (0, 1, 7, 2761):
+        for w in (1, 2, 3, 8):
+            rs = [shard.block_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
