@@ -248,7 +248,7 @@ void timer_hook(void* user, const char* name, int begin) {
 int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_scans, hipStream_t st,
               int do_patchwork, int apply_filter, int do_voxels, int sync) {
     if (!c) return SCVOD_ERR_INVALID;
-    if (n_scans <= 0 || !h_off || !d_xyzi) return fail(c, SCVOD_ERR_INVALID, "empty batch");
+    if (n_scans <= 0 || !h_off || (!d_xyzi && do_patchwork != 2)) return fail(c, SCVOD_ERR_INVALID, "empty batch");
     if (n_scans > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "n_scans %d > capacity %d", n_scans, c->cap_scans);
     int64_t total = (int64_t)h_off[n_scans] - h_off[0];
     if (h_off[0] != 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets[0] must be 0");
@@ -510,6 +510,23 @@ int scvod_patchwork(scvod_ctx* c, const float* h_xyzi, int32_t n, scvod_scan_res
 int scvod_bin_scan(scvod_ctx* c, const float* h_xyzi, int32_t n, int32_t apply_filter, int32_t with_voxels,
                    scvod_scan_result* out) {
     return host_scan(c, h_xyzi, n, 0, apply_filter ? 1 : 0, with_voxels ? 1 : 0, out);
+}
+
+int scvod_voxelize(scvod_ctx* c, const scvod_apri* h_apri, int32_t n, scvod_scan_result* out) {
+    if (!c || !out || n < 0 || (n > 0 && !h_apri)) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (n > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%d points > capacity %lld", n, (long long)c->cap_pts);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int32_t counts[8] = {n, 0, 0, 0, n, 0, 0, 0};
+    if (n) HIPCHK(c, hipMemcpyAsync(c->A.apri, h_apri, sizeof(scvod_apri) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->A.counts, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t off[2] = {0, n};
+    int rc = run_batch(c, nullptr, off, 1, c->stream, 2, 0, 1, 1);
+    if (rc) return rc;
+    rc = fetch_scan(c, 0, out);
+    if (rc) return rc;
+    out->n_patches = 0;
+    return SCVOD_OK;
 }
 
 void scvod_pose_delta(const float pose_pre[6], const float pose_next[6], float T_out[12]) {

@@ -106,6 +106,8 @@ struct TrackJob {          // scan-vs-next-scan probe
 typedef void (*TimerHook)(void* user, const char* name, int begin);
 
 // Launches.  `th`/`tu` optional per-kernel timing hook (called before and after each launch).
+// do_patchwork: 1 = Patchwork + fused binning, 0 = binning of the input cloud in input order,
+// 2 = neither (apri / counts already in the arena: voxel stage only).
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,

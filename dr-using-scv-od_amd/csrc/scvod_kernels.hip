@@ -1069,7 +1069,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
                     int do_voxels, TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0) return;
-    if (do_patchwork) {
+    if (do_patchwork == 1) {
         hipMemsetAsync(A.patch_count, 0, sizeof(int32_t) * (size_t)B * kMaxPatches, st);
         hipMemsetAsync(A.patch_cursor, 0, sizeof(int32_t) * (size_t)B * kMaxPatches, st);
         dim3 gcls((A.max_scan_pts + kClsThreads * kClsItems - 1) / (kClsThreads * kClsItems), B);
@@ -1112,7 +1112,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_BEGIN("emit");
         hipLaunchKernelGGL(k_emit, gp, dim3(kEmitThreads), 0, st, P, A);
         TH_END("emit");
-    } else {
+    } else if (do_patchwork == 0) {
         TH_BEGIN("bin_direct");
         hipLaunchKernelGGL(k_bin_direct, dim3(B), dim3(1024), 0, st, P, A, apply_filter);
         TH_END("bin_direct");

@@ -1,0 +1,55 @@
+// ssc.h -- `class SSC : public Utility` with the reference's member names and the signatures of the
+// hot-path methods (/root/reference/include/ssc.h:7-105).  Only the methods SURVEY.md section 8 puts
+// on the hot path are implemented here (each is a thin call through include/scvod.h); segment(),
+// recognize(), I/O and the writers stay the reference's own host code (INTEGRATION.md shows the patch).
+#ifndef SCVOD_HOST_SSC_H_
+#define SCVOD_HOST_SSC_H_
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "patchwork.h"
+#include "utility.h"
+
+class SSC : public Utility {
+  public:
+    static int id;
+
+    int range_num = 0, sector_num = 0, azimuth_num = 0, bin_num = 0;  // ssc.h:11-14
+
+    std::vector<pcl::PointCloud<pcl::PointXYZI>::Ptr> g_cloud_vec;     // ssc.h:26
+    std::vector<PointAPRI> apri_vec;                                   // ssc.h:28
+    std::unordered_map<int, Voxel> hash_cloud;                         // ssc.h:29
+    Frame frame_ssc;                                                   // ssc.h:30
+    std::shared_ptr<PatchWork<pcl::PointXYZI>> PatchworkGroundSeg;     // ssc.h:32
+    pcl::PointCloud<pcl::PointXYZI>::Ptr cloud_use;                    // ssc.h:33
+    pcl::PointCloud<pcl::PointXYZI>::Ptr cloud_eva_static;             // ssc.h:45
+    int name = 0;                                                      // ssc.h:50
+    std::vector<Frame> frame_set;                                      // ssc.h:51
+
+    ~SSC();
+    // The reference's SSC() reads the ROS parameter server; here the YAML file is named explicitly.
+    // max_points: capacity of the device arena (points per scan).
+    explicit SSC(const std::string& yaml_path, int device = 0, int max_points = 400000);
+
+    void allocateMemory();  // ssc.cpp:67-77
+    void reset();           // ssc.cpp:79-86
+
+    // hot path (ssc.h:63-68, 91)
+    void process(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloudIn_);
+    pcl::PointCloud<pcl::PointXYZI>::Ptr extractGroudByPatchWork(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloudIn_);
+    void makeApriVec(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_);
+    void makeHashCloud(const std::vector<PointAPRI>& apriIn_);
+    void tracking(Frame& frame_pre_, Frame& frame_next_, Pose pose_pre_, Pose pose_next_);
+
+    scvod_ctx* ctx() const { return ctx_; }
+    int dynamic_num_last = 0;  // what the reference only logs (ssc.cpp:1424)
+
+  private:
+    void fillHashCloud(const scvod_scan_result& r, const PointAPRI* apri);
+    static void cloudToXyzi(const pcl::PointCloud<pcl::PointXYZI>& c, std::vector<float>& out);
+    scvod_ctx* ctx_ = nullptr;
+    std::vector<float> stage_;
+};
+#endif

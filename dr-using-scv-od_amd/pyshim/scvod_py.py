@@ -95,6 +95,7 @@ def load_lib():
         "scvod_process_scan": (C.c_int, [vp, vp, i32, C.POINTER(ScanResult)]),
         "scvod_patchwork": (C.c_int, [vp, vp, i32, C.POINTER(ScanResult)]),
         "scvod_bin_scan": (C.c_int, [vp, vp, i32, i32, i32, C.POINTER(ScanResult)]),
+        "scvod_voxelize": (C.c_int, [vp, vp, i32, C.POINTER(ScanResult)]),
         "scvod_pose_delta": (None, [vp, vp, vp]),
         "scvod_track_probe": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
         "scvod_batch_process": (C.c_int, [vp, vp, vp, i32, vp, i32]),
@@ -116,7 +117,7 @@ def load_lib():
 
 EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_grid_dims", "scvod_create",
                     "scvod_destroy", "scvod_last_error", "scvod_arena_bytes", "scvod_process_scan", "scvod_patchwork",
-                    "scvod_bin_scan", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
+                    "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_track", "scvod_batch_track_counts",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search"]
 
@@ -232,6 +233,12 @@ class Ctx:
         a, p = self._f32(xyzi)
         r = ScanResult()
         self._chk(self.lib.scvod_bin_scan(self.h, p, a.shape[0], int(apply_filter), int(with_voxels), C.byref(r)))
+        return _unpack(r)
+
+    def voxelize(self, apri):
+        a = np.ascontiguousarray(apri)
+        r = ScanResult()
+        self._chk(self.lib.scvod_voxelize(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], C.byref(r)))
         return _unpack(r)
 
     def pose_delta(self, pose_pre, pose_next):

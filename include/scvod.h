@@ -176,6 +176,10 @@ int scvod_patchwork(scvod_ctx* ctx, const float* h_xyzi, int32_t n, scvod_scan_r
 int scvod_bin_scan(scvod_ctx* ctx, const float* h_xyzi, int32_t n, int32_t apply_filter,
                    int32_t with_voxels, scvod_scan_result* out);
 
+/* Replaces SSC::makeHashCloud (ssc.cpp:253-289) on an apri_vec the caller already holds.  Fills the
+ * voxel fields of `out` (and echoes the apri fields). */
+int scvod_voxelize(scvod_ctx* ctx, const scvod_apri* h_apri, int32_t n, scvod_scan_result* out);
+
 /* T = getTransformation(next)^-1 * getTransformation(pre), src/ssc.cpp:1255-1257
  * (pcl::getTransformation + Eigen::Affine3f inverse/product restated on the host).
  * pose = {x, y, z, roll, pitch, yaw}; T_out is row-major 3x4. */

@@ -1,0 +1,118 @@
+"""The C++ facade (dr-using-scv-od_amd/host: class SSC / PatchWork with the reference's signatures)
+on the GPU box: members after SSC::process must equal what the oracle computes; the three separate
+entry points must agree with the fused call; SSC::tracking bookkeeping invariants."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dr-using-scv-od_amd", "host")
+
+YAML = """common:
+  out_path_: "/tmp/scvod_out/"
+  kNumOmpCores_: 8   # cores
+  skip_: 5
+
+session:
+  start_: 0
+  end_: 2
+
+ssc:
+  sensor_height_: {sensor_height}
+  min_dis_:  {min_dis}  # /m
+  max_dis_: {max_dis}
+  min_angle_: 0.0  # /deg
+  max_angle_: 360.0
+  min_azimuth_: {min_azimuth}
+  max_azimuth_: {max_azimuth}
+  range_res_: {range_res}
+  sector_res_: {sector_res}
+  azimuth_res_: {azimuth_res}
+  occupancy_: {occupancy}
+  building_: 0  # cluster map
+  tree_: 1
+  car_: 2
+  dynamic_label_: [252, 253, 254, 255, 256, 257, 258, 259]
+  tr_: [1, 0, 0, 0,
+            0, 1, 0, 0,
+            0, 0, 1, 0,
+            0, 0, 0, 1]
+"""
+
+
+def test_facade_members_match_oracle(scvod, oracle, tmp_path):
+    import synth
+    exe = os.path.join(HOST, "facade_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST])
+    P = scvod.make_params("semantickitti")
+    cfg = tmp_path / "semantickitti.yaml"
+    cfg.write_text(YAML.format(**scvod.PRESETS["semantickitti"]))
+    scans = []
+    for k, idx in enumerate((120, 121)):
+        pts, _, _ = synth.make_scan(5, idx, "K64")
+        x = pts.numpy()
+        x.tofile(tmp_path / f"s{k}.f32")
+        scans.append(x)
+    pre = str(tmp_path / "out")
+    res = subprocess.run([exe, str(cfg), str(tmp_path / "s0.f32"), str(tmp_path / "s1.f32"), pre], capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    out = dict(l.split(" ", 1) for l in res.stdout.strip().splitlines())
+    assert out["grid"] == "72 300 60 1296000"
+    assert out["stepwise_equals_fused"] == "1"
+    for tag, x in zip(("a", "b"), scans):
+        o = oracle.patchwork(P, x, 1)
+        b = oracle.bin(P, x[o["nonground_idx"]], True)
+        v = oracle.voxelize(P, b["apri"])
+        f = lambda n: np.fromfile(f"{pre}_{tag}_{n}.f32", np.float32).reshape(-1, 4)
+        assert np.array_equal(f("ground").view(np.uint32), x[o["ground_idx"]].view(np.uint32))
+        use = x[o["nonground_idx"]][b["src"]]
+        assert np.array_equal(f("cloud_use").view(np.uint32), use.view(np.uint32))
+        apri = np.fromfile(f"{pre}_{tag}_apri.bin", scvod.APRI_DTYPE)
+        assert np.array_equal(apri.view(np.uint8), b["apri"].view(np.uint8))
+        rows = [l.split() for l in open(f"{pre}_{tag}_hash.txt")]
+        assert [int(r[0]) for r in rows] == v["vox_key"].tolist()
+        for i, r in enumerate(rows):
+            assert [int(r[1]), int(r[2]), int(r[3])] == v["idx3"][i].tolist()
+            assert int(r[4]) == -1
+            assert int(r[5]) == int(v["vox_av"][i:i + 1].view(np.uint32)[0])
+            assert int(r[6]) == int(v["vox_cov"][i:i + 1].view(np.uint32)[0])
+            assert [int(t) for t in r[7:11]] == v["center"][i].view(np.uint32).tolist()   # host libm, as ssc.cpp:271-277
+            n = int(r[11])
+            assert [int(t) for t in r[12:12 + n]] == v["vox_pts"][v["vox_pt_begin"][i]:v["vox_pt_begin"][i + 1]].tolist()
+    # eva_static accumulates over both scans (never cleared by reset(), like the reference member)
+    rej = []
+    for x in scans:
+        o = oracle.patchwork(P, x, 1)
+        b = oracle.bin(P, x[o["nonground_idx"]], True)
+        rej.append(x[o["nonground_idx"]][b["rejected"]])
+    eva_b = np.fromfile(f"{pre}_b_eva_static.f32", np.float32).reshape(-1, 4)
+    # scan a is processed twice (fused + stepwise) before scan b
+    expect = np.concatenate([rej[0], rej[0], rej[1]])
+    assert np.array_equal(eva_b.view(np.uint32), expect.view(np.uint32))
+    # tracking bookkeeping: a frame tracked against itself with identical poses confirms every car static
+    t = out["self_tracking"].split()
+    assert int(t[1]) > 0 and int(t[1]) == int(t[3]) and int(t[5]) == 0
+    t = out["pair_tracking"].split()
+    assert int(t[1]) > 0 and int(t[3]) == int(t[5])
+
+
+def test_voxelize_entry_point(scvod, oracle):
+    import synth
+    P = scvod.make_params("parkinglot")
+    pts, _, _ = synth.make_scan(3, 5, "PARK")
+    x = pts.numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    b = oracle.bin(P, x, True)
+    r = ctx.voxelize(b["apri"])
+    v = oracle.voxelize(P, b["apri"])
+    assert np.array_equal(r["vox_key"], v["vox_key"]) and np.array_equal(r["vox_pts"], v["vox_pts"])
+    assert np.array_equal(r["vox_av"].view(np.uint32), v["vox_av"].view(np.uint32))
+    assert np.array_equal(r["vox_cov"].view(np.uint32), v["vox_cov"].view(np.uint32))
+    r0 = ctx.voxelize(np.zeros(0, scvod.APRI_DTYPE))
+    assert r0["n_voxels"] == 0
+    ctx.close()
