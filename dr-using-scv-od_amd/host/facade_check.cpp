@@ -1,6 +1,6 @@
 // facade_check.cpp -- drives the SSC facade the way SSC::segDF drives the reference (process per scan,
 // tracking per pair) on raw float32 scans and dumps what the reference would hold in its members, so
-// that tests/test_gpu_facade.py can compare them with the oracle.
+// that tests/test_gpu_facade.py can check them against the CPU restatement.
 //   usage: facade_check <config.yaml> <scan_a.f32> <scan_b.f32> <out_prefix>
 #include <algorithm>
 #include <cstdio>
