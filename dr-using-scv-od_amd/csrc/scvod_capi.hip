@@ -126,6 +126,8 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.nonground_idx = k.take<int32_t>(N);
     A.apri = k.take<scvod_apri>(N);
     A.apri_src = k.take<int32_t>(N);
+    A.apri_key = k.take<int32_t>(N);
+    A.apri_int = k.take<float>(N);
     A.rejected_src = k.take<int32_t>(N);
     A.counts = k.take<int32_t>(B * 8);
     A.vb_count = k.take<int32_t>(B * kMaxBuckets);
@@ -133,6 +135,10 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vb_off = k.take<int32_t>(B * (kMaxBuckets + 1));
     A.vb_nvox = k.take<int32_t>(B * kMaxBuckets);
     A.vox_off = k.take<int32_t>(B * (kMaxBuckets + 1));
+    A.vorder = k.take<int32_t>(B * kMaxBuckets);
+    A.vorder_hist = k.take<int32_t>(64);
+    A.vorder_cursor = k.take<int32_t>(64);
+    A.vorder_off = k.take<int32_t>(65);
     A.vkeys = k.take<uint64_t>(N);
     A.tmp_vox_key = k.take<int32_t>(N);
     A.tmp_vox_begin = k.take<int32_t>(N);

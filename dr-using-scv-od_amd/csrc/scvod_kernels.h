@@ -63,6 +63,8 @@ struct Arena {
     int32_t* nonground_idx;   // [N]
     scvod_apri* apri;         // [N]
     int32_t* apri_src;        // [N]
+    int32_t* apri_key;        // [N] PointAPRI::voxel_idx, compact copy for the voxel stage
+    float* apri_int;          // [N] PointAPRI::intensity, compact copy for the voxel stage
     int32_t* rejected_src;    // [N]
     int32_t* counts;          // [B][8]
     // voxel stage
@@ -71,6 +73,10 @@ struct Arena {
     int32_t* vb_off;          // [B][kMaxBuckets+1]
     int32_t* vb_nvox;         // [B][kMaxBuckets]
     int32_t* vox_off;         // [B][kMaxBuckets+1]
+    int32_t* vorder;          // [B * kMaxBuckets] non-empty buckets by descending size class
+    int32_t* vorder_hist;     // [64]
+    int32_t* vorder_cursor;   // [64]
+    int32_t* vorder_off;      // [65]
     uint64_t* vkeys;          // [N] (biased voxel key << 32 | apri idx), bucket-major per scan
     int32_t* tmp_vox_key;     // [N] per-bucket voxel records before compaction
     int32_t* tmp_vox_begin;   // [N]

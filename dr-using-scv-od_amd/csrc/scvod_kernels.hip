@@ -70,8 +70,17 @@ __device__ __forceinline__ void cswap(T& x, T& y) {
     y = hi;
 }
 
-template <int THREADS, typename T>
+// PAD: LDS layout with one spare slot after every 8 elements (slot(i) = i + i/8).  With 8-byte keys the
+// strided butterfly passes (runs of jl lanes every 8*jl elements) and the runs-of-8 passes would otherwise
+// put a half-wave on 4-8 banks; with the pad every pass is conflict-free or at worst 2-way.
+template <bool PAD>
+__device__ __forceinline__ int sort_slot(int i) {
+    return PAD ? i + (i >> 3) : i;
+}
+
+template <int THREADS, bool PAD, typename T>
 __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
+#define IX(i) sort_slot<PAD>(i)
     if (n <= 1) return;
     const T INF = ~(T)0;
     int np2 = 8;
@@ -82,7 +91,7 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
         if (b >= n) continue;
         T e[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) e[m] = (b + m < n) ? a[b + m] : INF;
+        for (int m = 0; m < 8; ++m) e[m] = (b + m < n) ? a[IX(b + m)] : INF;
         cswap(e[0], e[1]); cswap(e[2], e[3]); cswap(e[4], e[5]); cswap(e[6], e[7]);
         cswap(e[0], e[2]); cswap(e[1], e[3]); cswap(e[4], e[6]); cswap(e[5], e[7]);
         cswap(e[1], e[2]); cswap(e[5], e[6]);
@@ -91,7 +100,7 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
         cswap(e[1], e[2]); cswap(e[3], e[4]); cswap(e[5], e[6]);
 #pragma unroll
         for (int m = 0; m < 8; ++m)
-            if (b + m < n) a[b + m] = e[m];
+            if (b + m < n) a[IX(b + m)] = e[m];
     }
     __syncthreads();
     const int half = np2 >> 1;
@@ -102,10 +111,10 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
             const int blk = t / hk, off = t - blk * hk;
             const int i = blk * k + off, j = blk * k + (k - 1 - off);
             if (j < n) {
-                T x = a[i], y = a[j];
+                T x = a[IX(i)], y = a[IX(j)];
                 if (x > y) {
-                    a[i] = y;
-                    a[j] = x;
+                    a[IX(i)] = y;
+                    a[IX(j)] = x;
                 }
             }
         }
@@ -119,13 +128,13 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
                     if (b >= n) continue;
                     T e[8];
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) e[m] = (b + m * jl < n) ? a[b + m * jl] : INF;
+                    for (int m = 0; m < 8; ++m) e[m] = (b + m * jl < n) ? a[IX(b + m * jl)] : INF;
                     cswap(e[0], e[4]); cswap(e[1], e[5]); cswap(e[2], e[6]); cswap(e[3], e[7]);
                     cswap(e[0], e[2]); cswap(e[1], e[3]); cswap(e[4], e[6]); cswap(e[5], e[7]);
                     cswap(e[0], e[1]); cswap(e[2], e[3]); cswap(e[4], e[5]); cswap(e[6], e[7]);
 #pragma unroll
                     for (int m = 0; m < 8; ++m)
-                        if (b + m * jl < n) a[b + m * jl] = e[m];
+                        if (b + m * jl < n) a[IX(b + m * jl)] = e[m];
                 }
                 j >>= 3;
             } else if (j == 2) {
@@ -134,22 +143,22 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
                     if (b >= n) continue;
                     T e[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) e[m] = (b + m < n) ? a[b + m] : INF;
+                    for (int m = 0; m < 4; ++m) e[m] = (b + m < n) ? a[IX(b + m)] : INF;
                     cswap(e[0], e[2]); cswap(e[1], e[3]);
                     cswap(e[0], e[1]); cswap(e[2], e[3]);
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        if (b + m < n) a[b + m] = e[m];
+                        if (b + m < n) a[IX(b + m)] = e[m];
                 }
                 j = 0;
             } else {  // j == 1
                 for (int t = threadIdx.x; t < half; t += THREADS) {
                     const int i = t << 1;
                     if (i + 1 < n) {
-                        T x = a[i], y = a[i + 1];
+                        T x = a[IX(i)], y = a[IX(i + 1)];
                         if (x > y) {
-                            a[i] = y;
-                            a[i + 1] = x;
+                            a[IX(i)] = y;
+                            a[IX(i + 1)] = x;
                         }
                     }
                 }
@@ -159,6 +168,7 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
         }
     }
 }
+#undef IX
 
 // ------------------------------------------------------------------------------------------
 // Patchwork stage 1: per point patch id + per-(scan, patch) histogram.
@@ -256,31 +266,46 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 //   k_pw_arrange  one wave per patch: final plane test, [ground part | non-ground part] arrangement
 //                 and the per-patch counters the ordered emission needs.
 // ------------------------------------------------------------------------------------------
-template <int CAP, int THREADS, int MIN_N>
+// size classes (pw_size_class) that bound the sort tiers: class 40 <=> n >= 1024, class 48 <=> n >= 4096
+constexpr int kClassM = 40, kClassL = 48;
+
+// order[] lists live items by descending size class; positions of classes [C_LO, C_HI]
+__device__ __forceinline__ void order_range(const int32_t* off, int c_lo, int c_hi, int& lo, int& hi) {
+    lo = off[c_hi];
+    hi = (c_lo == 0) ? off[64] : off[c_lo - 1];
+}
+
+template <int CAP, int THREADS, int C_LO, int C_HI>
 __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int p = blockIdx.x, s = blockIdx.y;
-    const int n = A.patch_count[s * kMaxPatches + p];
-    if (n <= P.czm.num_min_pts || n <= MIN_N) return;
-    if (MIN_N == 0 && n > CAP) return;  // left to the large tier
-    const int base = A.scan_off[s];
-    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
-    uint64_t* keys;
-    if (n <= CAP) {
-        keys = (uint64_t*)smem;
-        for (int j = threadIdx.x; j < n; j += THREADS) keys[j] = A.keys[(size_t)base + off + j];
-        __syncthreads();
-    } else {
-        keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
-    }
-    block_bitonic_sort<THREADS>(keys, n);
-    float4* dst = A.sorted + (size_t)base + off;
-    for (int j = threadIdx.x; j < n; j += THREADS) {
-        const uint32_t id = (uint32_t)keys[j];
-        const float4 q = A.pts[base + id];
-        Apri a;
-        const int keep = apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-        dst[j] = make_float4(q.x, q.y, q.z, u2f(id | (keep ? 0x80000000u : 0u)));
+    int lo, hi;
+    order_range(A.order_off, C_LO, C_HI, lo, hi);
+    for (int w = lo + blockIdx.x; w < hi; w += gridDim.x) {
+        const int code = A.order[w];
+        const int s = code / kMaxPatches, p = code - s * kMaxPatches;
+        const int n = A.patch_count[s * kMaxPatches + p];
+        const int base = A.scan_off[s];
+        const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+        const bool in_lds = (n <= CAP);
+        uint64_t* keys;
+        if (in_lds) {
+            keys = (uint64_t*)smem;
+            for (int j = threadIdx.x; j < n; j += THREADS) keys[sort_slot<true>(j)] = A.keys[(size_t)base + off + j];
+            __syncthreads();
+            block_bitonic_sort<THREADS, true>(keys, n);
+        } else {
+            keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
+            block_bitonic_sort<THREADS, false>(keys, n);
+        }
+        float4* dst = A.sorted + (size_t)base + off;
+        for (int j = threadIdx.x; j < n; j += THREADS) {
+            const uint32_t id = (uint32_t)keys[in_lds ? sort_slot<true>(j) : j];
+            const float4 q = A.pts[base + id];
+            Apri a;
+            const int keep = apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
+            dst[j] = make_float4(q.x, q.y, q.z, u2f(id | (keep ? 0x80000000u : 0u)));
+        }
+        __syncthreads();  // LDS is reused by the next item
     }
 }
 
@@ -342,6 +367,54 @@ __global__ __launch_bounds__(256) void k_pw_order_scatter(DevParams P, Arena A) 
         hist[threadIdx.x] = A.order_off[threadIdx.x] + atomicAdd(&A.order_cursor[threadIdx.x], hist[threadIdx.x]);
     __syncthreads();
     if (c >= 0) A.order[hist[c] + rank] = code;
+}
+
+// the same ordering for voxel buckets (counts in vb_count, min size 1)
+__global__ __launch_bounds__(256) void k_vx_order_count(DevParams P, Arena A) {
+    __shared__ int hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < A.n_scans * P.n_buckets) {
+        const int s = t / P.n_buckets, b = t - s * P.n_buckets;
+        const int m = A.vb_count[s * kMaxBuckets + b];
+        if (m > 0)
+            atomicAdd(&hist[pw_size_class(m)], 1);
+        else
+            A.vb_nvox[s * kMaxBuckets + b] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && hist[threadIdx.x]) atomicAdd(&A.vorder_hist[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void k_vx_order_offsets(Arena A) {
+    const int c = 63 - threadIdx.x;
+    const int v = A.vorder_hist[c];
+    const int inc = wave_incl_scan(v);
+    A.vorder_off[c] = inc - v;
+    if (threadIdx.x == 63) A.vorder_off[64] = inc;
+}
+
+__global__ __launch_bounds__(256) void k_vx_order_scatter(DevParams P, Arena A) {
+    __shared__ int hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    int c = -1, rank = 0, code = 0;
+    if (t < A.n_scans * P.n_buckets) {
+        const int s = t / P.n_buckets, b = t - s * P.n_buckets;
+        const int m = A.vb_count[s * kMaxBuckets + b];
+        if (m > 0) {
+            c = pw_size_class(m);
+            rank = atomicAdd(&hist[c], 1);
+            code = s * kMaxBuckets + b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && hist[threadIdx.x])
+        hist[threadIdx.x] = A.vorder_off[threadIdx.x] + atomicAdd(&A.vorder_cursor[threadIdx.x], hist[threadIdx.x]);
+    __syncthreads();
+    if (c >= 0) A.vorder[hist[c] + rank] = code;
 }
 
 // per-point plane residual, Eigen GEMV order: fl(fl(x*n0 + y*n1) + z*n2)
@@ -506,59 +579,63 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
 
 // one wave per (scan, patch): final plane test of every point (patchwork.h:488-501), keeps the
 // z order inside the ground part and the non-ground part, counts what k_emit_offsets needs.
-__global__ __launch_bounds__(64) void k_pw_arrange(DevParams P, Arena A) {
-    const int p = blockIdx.x, s = blockIdx.y;
-    const int n = A.patch_count[s * kMaxPatches + p];
-    if (n <= P.czm.num_min_pts) return;
-    const int base = A.scan_off[s];
-    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
-    const float4* __restrict__ sp = A.sorted + (size_t)base + off;
-    const scvod_patch_plane pl = A.planes[s * kMaxPatches + p];
-    const float n0 = pl.normal[0], n1 = pl.normal[1], n2 = pl.normal[2];
-    const float thd = A.fit_thd[s * kMaxPatches + p];
-    const int lane = threadIdx.x;
-    // pass 1: size of the ground part and the filter counts
-    int n_g = 0, a_g = 0, a_ng = 0;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        int g = 0, keep = 0;
-        if (j < n) {
-            const float4 q = sp[j];
-            g = plane_res(q, n0, n1, n2) < thd;
-            keep = (int)(f2u(q.w) >> 31);
+__global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int total = A.order_off[64];
+    for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
+        const int code = A.order[w];
+        const int s = code / kMaxPatches, p = code - s * kMaxPatches;
+        const int n = A.patch_count[s * kMaxPatches + p];
+        const int base = A.scan_off[s];
+        const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+        const float4* __restrict__ sp = A.sorted + (size_t)base + off;
+        const scvod_patch_plane pl = A.planes[s * kMaxPatches + p];
+        const float n0 = pl.normal[0], n1 = pl.normal[1], n2 = pl.normal[2];
+        const float thd = A.fit_thd[s * kMaxPatches + p];
+        // pass 1: size of the ground part and the filter counts
+        int n_g = 0, a_g = 0, a_ng = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            int g = 0, keep = 0;
+            if (j < n) {
+                const float4 q = sp[j];
+                g = plane_res(q, n0, n1, n2) < thd;
+                keep = (int)(f2u(q.w) >> 31);
+            }
+            n_g += __popcll(__ballot(g));
+            a_g += __popcll(__ballot(g && keep));
+            a_ng += __popcll(__ballot(!g && keep && j < n));
         }
-        n_g += __popcll(__ballot(g));
-        a_g += __popcll(__ballot(g && keep));
-        a_ng += __popcll(__ballot(!g && keep && j < n));
-    }
-    // pass 2: ordered placement
-    int run_g = 0;
-    uint32_t* seg = A.seg + (size_t)base + off;
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        int g = 0;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < n) {
-            q = sp[j];
-            g = plane_res(q, n0, n1, n2) < thd;
+        // pass 2: ordered placement
+        int run_g = 0;
+        uint32_t* seg = A.seg + (size_t)base + off;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            int g = 0;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < n) {
+                q = sp[j];
+                g = plane_res(q, n0, n1, n2) < thd;
+            }
+            const unsigned long long bg = __ballot(g);
+            const int eg = __popcll(bg & ((1ull << lane) - 1ull));
+            if (j < n) {
+                const int dst = g ? (run_g + eg) : (n_g + (j - (run_g + eg)));
+                seg[dst] = f2u(q.w);
+            }
+            run_g += __popcll(bg);
         }
-        const unsigned long long bg = __ballot(g);
-        const int eg = __popcll(bg & ((1ull << lane) - 1ull));
-        if (j < n) {
-            const int dst = g ? (run_g + eg) : (n_g + (j - (run_g + eg)));
-            seg[dst] = f2u(q.w);
+        if (lane == 0) {
+            PatchRec r;
+            r.n = n;
+            r.n_g = n_g;
+            r.status = pl.status;
+            r.a_g = a_g;
+            r.a_ng = a_ng;
+            A.patch_rec[s * kMaxPatches + p] = r;
+            A.planes[s * kMaxPatches + p].n_ground = n_g;
         }
-        run_g += __popcll(bg);
-    }
-    if (lane == 0) {
-        PatchRec r;
-        r.n = n;
-        r.n_g = n_g;
-        r.status = pl.status;
-        r.a_g = a_g;
-        r.a_ng = a_ng;
-        A.patch_rec[s * kMaxPatches + p] = r;
-        A.planes[s * kMaxPatches + p].n_ground = n_g;
     }
 }
 
@@ -613,66 +690,72 @@ __global__ __launch_bounds__(1024) void k_emit_offsets(DevParams P, Arena A) {
 
 constexpr int kEmitThreads = 256;
 __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
-    __shared__ int wsum[8];
-    const int p = blockIdx.x, s = blockIdx.y;
-    const PatchRec r = A.patch_rec[s * kMaxPatches + p];
-    if (r.status == 0) return;
-    const int base = A.scan_off[s];
-    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
-    const int* o = A.emit_off + ((size_t)s * kMaxPatches + p) * 4;
-    const int xg = o[0], xng = o[1], xa = o[2], xr = o[3];
-    const bool kept = (r.status == 1);
-    const uint32_t* seg = A.seg + (size_t)base + off;
-    // ground part of a kept patch -> cloud_out
-    if (kept) {
-        for (int e = threadIdx.x; e < r.n_g; e += kEmitThreads) {
-            uint32_t id = seg[e] & 0x7fffffffu;
-            A.ground_idx[(size_t)base + xg + e] = (int32_t)id;
-            A.cls[base + id] = SCVOD_CLS_GROUND;
-        }
-    }
-    // non-ground stream of this patch: elements [e0, n)
-    const int e0 = kept ? r.n_g : 0;
-    int run_keep = 0;
-    for (int c0 = e0; c0 < r.n; c0 += kEmitThreads) {
-        int e = c0 + threadIdx.x;
-        uint32_t v = 0;
-        int keep = 0;
-        if (e < r.n) {
-            v = seg[e];
-            keep = (int)(v >> 31);
-        }
-        int tk;
-        int ek = block_excl_scan<kEmitThreads>(keep, tk, wsum);
-        if (e < r.n) {
-            uint32_t id = v & 0x7fffffffu;
-            int spos = e - e0;  // position in the non-ground stream of this patch
-            A.nonground_idx[(size_t)base + xng + spos] = (int32_t)id;
-            A.cls[base + id] = SCVOD_CLS_NONGROUND;
-            if (keep) {
-                float4 q = A.pts[base + id];
-                Apri a;
-                apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-                size_t dst = (size_t)base + xa + run_keep + ek;
-                scvod_apri out;
-                out.x = a.x;
-                out.y = a.y;
-                out.z = a.z;
-                out.range = a.range;
-                out.angle = a.angle;
-                out.azimuth = a.azimuth;
-                out.intensity = a.intensity;
-                out.range_idx = a.range_idx;
-                out.sector_idx = a.sector_idx;
-                out.azimuth_idx = a.azimuth_idx;
-                out.voxel_idx = a.voxel_idx;
-                A.apri[dst] = out;
-                A.apri_src[dst] = (int32_t)id;
-            } else {
-                A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int total = A.order_off[64];
+    for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
+        const int code = A.order[w];
+        const int s = code / kMaxPatches, p = code - s * kMaxPatches;
+        const PatchRec r = A.patch_rec[s * kMaxPatches + p];
+        const int base = A.scan_off[s];
+        const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+        const int* o = A.emit_off + ((size_t)s * kMaxPatches + p) * 4;
+        const int xg = o[0], xng = o[1], xa = o[2], xr = o[3];
+        const bool kept = (r.status == 1);
+        const uint32_t* seg = A.seg + (size_t)base + off;
+        // ground part of a kept patch -> cloud_out
+        if (kept) {
+            for (int e = lane; e < r.n_g; e += 64) {
+                const uint32_t id = seg[e] & 0x7fffffffu;
+                A.ground_idx[(size_t)base + xg + e] = (int32_t)id;
+                A.cls[base + id] = SCVOD_CLS_GROUND;
             }
         }
-        run_keep += tk;
+        // non-ground stream of this patch: elements [e0, n)
+        const int e0 = kept ? r.n_g : 0;
+        int run_keep = 0;
+        for (int c0 = e0; c0 < r.n; c0 += 64) {
+            const int e = c0 + lane;
+            uint32_t v = 0;
+            int keep = 0;
+            if (e < r.n) {
+                v = seg[e];
+                keep = (int)(v >> 31);
+            }
+            const unsigned long long bk = __ballot(keep);
+            const int ek = __popcll(bk & ((1ull << lane) - 1ull));
+            if (e < r.n) {
+                const uint32_t id = v & 0x7fffffffu;
+                const int spos = e - e0;  // position in the non-ground stream of this patch
+                A.nonground_idx[(size_t)base + xng + spos] = (int32_t)id;
+                A.cls[base + id] = SCVOD_CLS_NONGROUND;
+                if (keep) {
+                    const float4 q = A.pts[base + id];
+                    Apri a;
+                    apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
+                    const size_t dst = (size_t)base + xa + run_keep + ek;
+                    scvod_apri out;
+                    out.x = a.x;
+                    out.y = a.y;
+                    out.z = a.z;
+                    out.range = a.range;
+                    out.angle = a.angle;
+                    out.azimuth = a.azimuth;
+                    out.intensity = a.intensity;
+                    out.range_idx = a.range_idx;
+                    out.sector_idx = a.sector_idx;
+                    out.azimuth_idx = a.azimuth_idx;
+                    out.voxel_idx = a.voxel_idx;
+                    A.apri[dst] = out;
+                    A.apri_src[dst] = (int32_t)id;
+                    A.apri_key[dst] = a.voxel_idx;
+                    A.apri_int[dst] = a.intensity;
+                } else {
+                    A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
+                }
+            }
+            run_keep += __popcll(bk);
+        }
     }
 }
 
@@ -712,6 +795,8 @@ __global__ __launch_bounds__(1024) void k_bin_direct(DevParams P, Arena A, int a
                 out.voxel_idx = a.voxel_idx;
                 A.apri[dst] = out;
                 A.apri_src[dst] = i;
+                A.apri_key[dst] = a.voxel_idx;
+                A.apri_int[dst] = a.intensity;
             } else {
                 A.rejected_src[(size_t)base + (i - (run + ek))] = i;
             }
@@ -728,6 +813,18 @@ __global__ __launch_bounds__(1024) void k_bin_direct(DevParams P, Arena A, int a
         c[5] = n - run;
         c[6] = 0;
         c[7] = 0;
+    }
+}
+
+// apri_vec supplied by the caller (scvod_voxelize): derive the compact key / intensity arrays
+__global__ __launch_bounds__(256) void k_apri_split(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const scvod_apri& a = A.apri[(size_t)base + i];
+        A.apri_key[(size_t)base + i] = a.voxel_idx;
+        A.apri_int[(size_t)base + i] = a.intensity;
     }
 }
 
@@ -759,7 +856,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_count(DevParams P, Arena A) {
 #pragma unroll
     for (int it = 0; it < kVxItems; ++it) {
         int i = start + it * kVxThreads + threadIdx.x;
-        if (i < n) atomicAdd(&hist[vx_bucket_of(P, A.apri[(size_t)base + i].voxel_idx)], 1);
+        if (i < n) atomicAdd(&hist[vx_bucket_of(P, A.apri_key[(size_t)base + i])], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < P.n_buckets; b += kVxThreads) {
@@ -793,7 +890,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
         int i = start + it * kVxThreads + threadIdx.x;
         bk[it] = -1;
         if (i < n) {
-            key[it] = A.apri[(size_t)base + i].voxel_idx;
+            key[it] = A.apri_key[(size_t)base + i];
             bk[it] = vx_bucket_of(P, key[it]);
             rank[it] = atomicAdd(&hist[bk[it]], 1);
         }
@@ -811,76 +908,94 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
     }
 }
 
-template <int CAP, int THREADS, int MIN_N>
+template <int CAP, int THREADS, int C_LO, int C_HI>
 __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* l_keys = (uint64_t*)smem;
-    int* l_vbeg = (int*)(smem + (size_t)CAP * 8);
-    int* wsum = (int*)(smem + (size_t)CAP * 12 + 16);
-    const int b = blockIdx.x, s = blockIdx.y;
+    constexpr int SLOTS = CAP + CAP / 8;
+    uint64_t* l_keys = (uint64_t*)smem;                       // padded layout
+    int* l_vbeg = (int*)(smem + (size_t)SLOTS * 8);           // [CAP]
+    float* l_int = (float*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 4);  // [CAP] intensity in sorted order
+    int* wsum = (int*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 8);
+    int lo, hi;
+    order_range(A.vorder_off, C_LO, C_HI, lo, hi);
+    for (int w = lo + blockIdx.x; w < hi; w += gridDim.x) {
+    const int code = A.vorder[w];
+    const int s = code / kMaxBuckets, b = code - s * kMaxBuckets;
     const int m = A.vb_count[s * kMaxBuckets + b];
-    if (MIN_N == 0 && m == 0) {
-        if (threadIdx.x == 0) A.vb_nvox[s * kMaxBuckets + b] = 0;
-        return;
-    }
-    if (m <= MIN_N) return;
-    if (MIN_N == 0 && m > CAP) return;
     const int base = A.scan_off[s];
     const int off = A.vb_off[s * (kMaxBuckets + 1) + b];
+    const bool in_lds = (m <= CAP);
     uint64_t* keys;
     int* vbeg;
-    if (m <= CAP) {
-        for (int j = threadIdx.x; j < m; j += THREADS) l_keys[j] = A.vkeys[(size_t)base + off + j];
+    float* ints;
+    if (in_lds) {
+        for (int j = threadIdx.x; j < m; j += THREADS) l_keys[sort_slot<true>(j)] = A.vkeys[(size_t)base + off + j];
         __syncthreads();
         keys = l_keys;
         vbeg = l_vbeg;
+        ints = l_int;
+        block_bitonic_sort<THREADS, true>(keys, m);
     } else {
         keys = A.vkeys + (size_t)base + off;
         vbeg = A.tmp_vox_begin + (size_t)base + off;  // rewritten below with final values
+        ints = A.tmp_vox_av + (size_t)base + off;     // m >= nv entries: used as staging, rewritten below
+        block_bitonic_sort<THREADS, false>(keys, m);
     }
-    block_bitonic_sort<THREADS>(keys, m);
-    // head flags + compaction of voxel starts
+#define KX(j) (in_lds ? sort_slot<true>(j) : (j))
+    // head flags + compaction of voxel starts; stage the intensities in sorted order
     int run = 0;
     for (int c0 = 0; c0 < m; c0 += THREADS) {
         int j = c0 + threadIdx.x;
         int head = 0;
         if (j < m) {
             // never form keys[-1]: with flat addressing that leaves the LDS aperture
-            const uint64_t prev = keys[j > 0 ? j - 1 : 0];
-            head = (j == 0) || ((uint32_t)(keys[j] >> 32) != (uint32_t)(prev >> 32));
+            const uint64_t cur = keys[KX(j)];
+            const uint64_t prev = keys[KX(j > 0 ? j - 1 : 0)];
+            head = (j == 0) || ((uint32_t)(cur >> 32) != (uint32_t)(prev >> 32));
+            const uint32_t idx = (uint32_t)cur;
+            A.vox_pts[(size_t)base + off + j] = (int32_t)idx;
         }
         int th;
         int eh = block_excl_scan<THREADS>(head, th, wsum);
-        if (j < m) A.vox_pts[(size_t)base + off + j] = (int32_t)(uint32_t)keys[j];
         if (head) vbeg[run + eh] = j;
         run += th;
     }
     __syncthreads();
     const int nv = run;
+    if (in_lds) {
+        for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + (uint32_t)keys[KX(j)]];
+        __syncthreads();
+    }
     // per voxel: sequential fp32 mean, then population variance accumulated as float += double
     for (int v = threadIdx.x; v < nv; v += THREADS) {
-        int j0 = vbeg[v];
-        int j1 = (v + 1 < nv) ? vbeg[v + 1] : m;
+        const int j0 = vbeg[v];
+        const int j1 = (v + 1 < nv) ? vbeg[v + 1] : m;
         float av = 0.f;
-        for (int j = j0; j < j1; ++j) av += A.apri[(size_t)base + (uint32_t)keys[j]].intensity;
+        if (in_lds) {
+            for (int j = j0; j < j1; ++j) av += ints[j];
+        } else {
+            for (int j = j0; j < j1; ++j) av += A.apri_int[(size_t)base + (uint32_t)keys[j]];
+        }
         const float fn = (float)(j1 - j0);
         av = av / fn;
         float cov = 0.f;
         for (int j = j0; j < j1; ++j) {
-            float in = A.apri[(size_t)base + (uint32_t)keys[j]].intensity;
-            double d = (double)(in - av);
+            const float in = in_lds ? ints[j] : A.apri_int[(size_t)base + (uint32_t)keys[j]];
+            const double d = (double)(in - av);
             cov = (float)((double)cov + d * d);
         }
         cov = cov / fn;
-        int32_t vkey = vx_unbias((uint32_t)(keys[j0] >> 32));
-        A.tmp_vox_key[(size_t)base + off + v] = vkey;
-        A.tmp_vox_av[(size_t)base + off + v] = av;
+        A.tmp_vox_key[(size_t)base + off + v] = vx_unbias((uint32_t)(keys[KX(j0)] >> 32));
         A.tmp_vox_cov[(size_t)base + off + v] = cov;
+        A.tmp_vox_av[(size_t)base + off + v] = av;
     }
     __syncthreads();
     // vbeg aliases tmp_vox_begin in the oversize path: every thread rewrites only its own entries
     for (int v = threadIdx.x; v < nv; v += THREADS) A.tmp_vox_begin[(size_t)base + off + v] = off + vbeg[v];
     if (threadIdx.x == 0) A.vb_nvox[s * kMaxBuckets + b] = nv;
+    __syncthreads();  // LDS is reused by the next item
+    }
+#undef KX
 }
 
 __global__ __launch_bounds__(1024) void k_vx_final_offsets(DevParams P, Arena A) {
@@ -986,7 +1101,7 @@ __global__ __launch_bounds__(THREADS) void k_track_unique(TrackJob J) {
     // misses sort to the end as 0xffffffff
     for (int j = threadIdx.x; j < m; j += THREADS) keys[j] = (uint32_t)J.hit_slot[k0 + j];
     __syncthreads();
-    block_bitonic_sort<THREADS>(keys, m);
+    block_bitonic_sort<THREADS, false>(keys, m);
     int run = 0;
     for (int c0 = 0; c0 < m; c0 += THREADS) {
         int j = c0 + threadIdx.x;
@@ -1059,11 +1174,15 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(const float* __restrict
 #define TH_END(name) \
     if (th) th(tu, name, 0)
 
+constexpr int kPersistCUs = 256;  // MI355X: 256 CUs; list-driven kernels launch a few workgroups per CU
 constexpr int kSortCapS = 1024, kSortThreadsS = 64;
+constexpr int kSortCapM = 4096, kSortThreadsM = 256;
 constexpr int kSortCapL = 8192, kSortThreadsL = 512;
+constexpr size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8; }
 constexpr int kVoxCapS = 1024, kVoxThreadsS = 64;
+constexpr int kVoxCapM = 4096, kVoxThreadsM = 256;
 constexpr int kVoxCapL = 8192, kVoxThreadsL = 512;
-constexpr size_t vox_lds_bytes(int cap) { return (size_t)cap * 12 + 16 + 128; }
+constexpr size_t vox_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8 + (size_t)cap * 8 + 128; }
 
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu) {
@@ -1082,35 +1201,39 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_BEGIN("pw_scatter");
         hipLaunchKernelGGL(k_pw_scatter, gcls, dim3(kClsThreads), 0, st, P, A);
         TH_END("pw_scatter");
-        dim3 gp(P.n_patches, B);
         hipMemsetAsync(A.order_hist, 0, sizeof(int32_t) * 64, st);
         hipMemsetAsync(A.order_cursor, 0, sizeof(int32_t) * 64, st);
-        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL, kSortCapS>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCapL * 8);
-        TH_BEGIN("pw_sort_small");
-        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS, 0>), gp, dim3(kSortThreadsS), kSortCapS * 8, st, P, A);
-        TH_END("pw_sort_small");
-        TH_BEGIN("pw_sort_large");
-        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL, kSortCapS>), gp, dim3(kSortThreadsL), kSortCapL * 8, st,
-                           P, A);
-        TH_END("pw_sort_large");
         const int n_all = B * P.n_patches;
         TH_BEGIN("pw_order");
         hipLaunchKernelGGL(k_pw_order_count, dim3((n_all + 255) / 256), dim3(256), 0, st, P, A);
         hipLaunchKernelGGL(k_pw_order_offsets, dim3(1), dim3(64), 0, st, A);
         hipLaunchKernelGGL(k_pw_order_scatter, dim3((n_all + 255) / 256), dim3(256), 0, st, P, A);
         TH_END("pw_order");
+        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL, kClassL, 63>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortCapL));
+        TH_BEGIN("pw_sort_large");  // largest first: their tail overlaps the smaller tiers' launches
+        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL, kClassL, 63>), dim3(kPersistCUs * 2), dim3(kSortThreadsL),
+                           sort_lds_bytes(kSortCapL), st, P, A);
+        TH_END("pw_sort_large");
+        TH_BEGIN("pw_sort_mid");
+        hipLaunchKernelGGL((k_pw_sort<kSortCapM, kSortThreadsM, kClassM, kClassL - 1>), dim3(kPersistCUs * 4),
+                           dim3(kSortThreadsM), sort_lds_bytes(kSortCapM), st, P, A);
+        TH_END("pw_sort_mid");
+        TH_BEGIN("pw_sort_small");
+        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS, 0, kClassM - 1>), dim3(kPersistCUs * 16),
+                           dim3(kSortThreadsS), sort_lds_bytes(kSortCapS), st, P, A);
+        TH_END("pw_sort_small");
         TH_BEGIN("pw_fit");
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");
-        hipLaunchKernelGGL(k_pw_arrange, gp, dim3(64), 0, st, P, A);
+        hipLaunchKernelGGL(k_pw_arrange, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
         TH_END("pw_arrange");
         TH_BEGIN("emit_offsets");
         hipLaunchKernelGGL(k_emit_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("emit_offsets");
         TH_BEGIN("emit");
-        hipLaunchKernelGGL(k_emit, gp, dim3(kEmitThreads), 0, st, P, A);
+        hipLaunchKernelGGL(k_emit, dim3(kPersistCUs * 8), dim3(kEmitThreads), 0, st, P, A);
         TH_END("emit");
     } else if (do_patchwork == 0) {
         TH_BEGIN("bin_direct");
@@ -1118,6 +1241,9 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_END("bin_direct");
     }
     if (do_voxels) {
+        if (do_patchwork == 2) {
+            hipLaunchKernelGGL(k_apri_split, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A);
+        }
         hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
         hipMemsetAsync(A.vb_cursor, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
         dim3 gv((A.max_scan_pts + kVxThreads * kVxItems - 1) / (kVxThreads * kVxItems), B);
@@ -1131,16 +1257,30 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_scatter, gv, dim3(kVxThreads), 0, st, P, A);
         TH_END("vx_scatter");
         dim3 gb(P.n_buckets, B);
-        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL, kVoxCapS>,
+        hipMemsetAsync(A.vorder_hist, 0, sizeof(int32_t) * 64, st);
+        hipMemsetAsync(A.vorder_cursor, 0, sizeof(int32_t) * 64, st);
+        const int nb_all = B * P.n_buckets;
+        TH_BEGIN("vx_order");
+        hipLaunchKernelGGL(k_vx_order_count, dim3((nb_all + 255) / 256), dim3(256), 0, st, P, A);
+        hipLaunchKernelGGL(k_vx_order_offsets, dim3(1), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(k_vx_order_scatter, dim3((nb_all + 255) / 256), dim3(256), 0, st, P, A);
+        TH_END("vx_order");
+        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL, kClassL, 63>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
-        TH_BEGIN("vx_bucket_small");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS, 0>), gb, dim3(kVoxThreadsS), vox_lds_bytes(kVoxCapS),
-                           st, P, A);
-        TH_END("vx_bucket_small");
+        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapM, kVoxThreadsM, kClassM, kClassL - 1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapM));
         TH_BEGIN("vx_bucket_large");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL, kVoxCapS>), gb, dim3(kVoxThreadsL),
+        hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL, kClassL, 63>), dim3(kPersistCUs), dim3(kVoxThreadsL),
                            vox_lds_bytes(kVoxCapL), st, P, A);
         TH_END("vx_bucket_large");
+        TH_BEGIN("vx_bucket_mid");
+        hipLaunchKernelGGL((k_vx_bucket<kVoxCapM, kVoxThreadsM, kClassM, kClassL - 1>), dim3(kPersistCUs * 2),
+                           dim3(kVoxThreadsM), vox_lds_bytes(kVoxCapM), st, P, A);
+        TH_END("vx_bucket_mid");
+        TH_BEGIN("vx_bucket_small");
+        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS, 0, kClassM - 1>), dim3(kPersistCUs * 8),
+                           dim3(kVoxThreadsS), vox_lds_bytes(kVoxCapS), st, P, A);
+        TH_END("vx_bucket_small");
         TH_BEGIN("vx_final_offsets");
         hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("vx_final_offsets");
