@@ -185,8 +185,19 @@ def main():
             bytes_per_launch = sb[stage] / n_chunks  # one launch processes one chunk of the sequence
             avg_s = ms / cnt / 1e3
             ach = bytes_per_launch / avg_s / 1e9
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+            # gfx950 FETCH doubling per MI355X_MICROARCH.md), stored per scan in profiles/*pmc_traffic.json
+            traffic = None
+            try:
+                pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
+                if pm:
+                    per_scan = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["by_bench_label"].get(name)
+                    if per_scan is not None:
+                        traffic = per_scan * (args.scans / n_chunks)
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": name, "stage": stage, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms_per_launch": ms / cnt,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_ms_per_launch": ms / cnt,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "path_GBps": (sum(sb.values()) * args.steps / dt) / 1e9}
         cpu = None
