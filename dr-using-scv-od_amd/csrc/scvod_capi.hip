@@ -39,6 +39,7 @@ struct scvod_ctx {
     float4* d_in = nullptr;        // ctx-owned input buffer for the per-scan host API
     int32_t* d_scan_off = nullptr; // [cap_scans+1]
     // tracking buffers
+    float4* t_pts = nullptr;
     int32_t* t_hit = nullptr;
     uint64_t* t_work = nullptr;
     int32_t* t_uniq = nullptr;
@@ -109,7 +110,10 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.pid = k.take<int16_t>(N);
     A.keys = k.take<uint64_t>(N);
     A.seg = k.take<uint32_t>(N);
-    A.sorted = k.take<float4>(N);
+    A.sorted_xyz = k.take<Xyz>(N + 8);
+    A.sorted_idx = k.take<uint32_t>(N);
+    A.zkey = k.take<uint32_t>(N);
+    c->t_pts = k.take<float4>(N);
     A.fit_thd = k.take<float>(B * kMaxPatches);
     A.order = k.take<int32_t>(B * kMaxPatches);
     A.order_hist = k.take<int32_t>(64);
@@ -581,7 +585,7 @@ int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offset
     hipStream_t st = c->stream;
     c->last_stream = st;
     c->tim_used = 0;
-    float4* d_pts = c->A.sorted;
+    float4* d_pts = c->t_pts;
     if (n_pts) HIPCHK(c, hipMemcpyAsync(d_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_pts, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_begin, h_offsets, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_T, T, sizeof(float) * 12, hipMemcpyHostToDevice, st));

@@ -14,6 +14,10 @@ namespace scvod {
 constexpr int kMaxPatches = SCVOD_MAX_PATCHES;
 constexpr int kMaxBuckets = 1024;
 
+struct Xyz {
+    float x, y, z;
+};
+
 struct DevParams {
     BinParams bin;
     CzmParams czm;
@@ -44,8 +48,10 @@ struct Arena {
     // patchwork
     int16_t* pid;             // [N] patch id or -1
     uint64_t* keys;           // [N] (sortable z << 32 | local idx), patch-major per scan
-    uint32_t* seg;            // [N] per patch: [ground part | non-ground part], bit31 = passes bin filter
-    float4* sorted;           // [N] per patch: points in (z, idx) order as {x, y, z, idx | keep << 31}
+    uint32_t* seg;            // [N] per patch: [ground part -> | <- non-ground part (stored back to front)], bit31 = passes bin filter
+    Xyz* sorted_xyz;          // [N] per patch: points in (z, idx) order, packed 12-byte xyz
+    uint32_t* sorted_idx;     // [N] same order: input index | (passes the range/FOV test) << 31
+    uint32_t* zkey;           // [N] sortable z key per input point
     float* fit_thd;           // [B][kMaxPatches] th_dist_d_ of the last plane fit
     int32_t* order;           // [B * kMaxPatches] live patches ordered by size class (descending)
     int32_t* order_hist;      // [64]

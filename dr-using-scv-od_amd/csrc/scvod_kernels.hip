@@ -193,6 +193,7 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_classify(DevParams P, Arena 
             float4 p = A.pts[base + i];
             int pid = czm_patch_of(P.czm, p.x, p.y, p.z);
             A.pid[base + i] = (int16_t)pid;
+            A.zkey[base + i] = float_sort_key(p.z);
             A.cls[base + i] = SCVOD_CLS_DROPPED;
             if (pid >= 0) atomicAdd(&hist[pid], 1);
         }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
         pid[it] = -1;
         if (i < n) {
             pid[it] = A.pid[base + i];
-            zk[it] = float_sort_key(A.pts[base + i].z);
+            zk[it] = A.zkey[base + i];
             if (pid[it] >= 0) rank[it] = atomicAdd(&hist[pid[it]], 1);
         }
     }
@@ -297,13 +298,19 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
             keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
             block_bitonic_sort<THREADS, false>(keys, n);
         }
-        float4* dst = A.sorted + (size_t)base + off;
+        Xyz* dst = A.sorted_xyz + (size_t)base + off;
+        uint32_t* dsti = A.sorted_idx + (size_t)base + off;
         for (int j = threadIdx.x; j < n; j += THREADS) {
             const uint32_t id = (uint32_t)keys[in_lds ? sort_slot<true>(j) : j];
             const float4 q = A.pts[base + id];
             Apri a;
             const int keep = apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-            dst[j] = make_float4(q.x, q.y, q.z, u2f(id | (keep ? 0x80000000u : 0u)));
+            Xyz o;
+            o.x = q.x;
+            o.y = q.y;
+            o.z = q.z;
+            dst[j] = o;
+            dsti[j] = id | (keep ? 0x80000000u : 0u);
         }
         __syncthreads();  // LDS is reused by the next item
     }
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256) void k_vx_order_scatter(DevParams P, Arena A) 
 }
 
 // per-point plane residual, Eigen GEMV order: fl(fl(x*n0 + y*n1) + z*n2)
-__device__ __forceinline__ float plane_res(const float4& q, float n0, float n1, float n2) {
+__device__ __forceinline__ float plane_res(const Xyz& q, float n0, float n1, float n2) {
     float r = q.x * n0;
     r = r + q.y * n1;
     r = r + q.z * n2;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
     const int n = A.patch_count[s * kMaxPatches + p];
     const int base = A.scan_off[s];
     const int off = A.patch_off[s * (kMaxPatches + 1) + p];
-    const float4* __restrict__ sp = A.sorted + (size_t)base + off;
+    const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
 
     int zone = 0;
     while (zone < 3 && p >= P.czm.patch_base[zone + 1]) ++zone;
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
         // clamped so every load is valid; membership is a select, adding +0.0f is exact here
         // because the accumulators can never be -0.0f.
         constexpr int PF = 8;
-        float4 cur[PF], nxt[PF];
+        Xyz cur[PF], nxt[PF];
 #pragma unroll
         for (int k = 0; k < PF; ++k) cur[k] = sp[min(k, n - 1)];
         for (int j0 = 0; j0 < n; j0 += PF) {
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
             if (iter == 0 && !((double)cur[0].z < seed_thr)) break;  // seeds are a prefix (z-sorted)
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
-                const float4 q = cur[k];
+                const Xyz q = cur[k];
                 bool in = (j0 + k < n);
                 if (iter == 0)
                     in = in && ((double)q.z < seed_thr);
@@ -589,42 +596,38 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
         const int n = A.patch_count[s * kMaxPatches + p];
         const int base = A.scan_off[s];
         const int off = A.patch_off[s * (kMaxPatches + 1) + p];
-        const float4* __restrict__ sp = A.sorted + (size_t)base + off;
+        const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
+        const uint32_t* __restrict__ si = A.sorted_idx + (size_t)base + off;
         const scvod_patch_plane pl = A.planes[s * kMaxPatches + p];
         const float n0 = pl.normal[0], n1 = pl.normal[1], n2 = pl.normal[2];
         const float thd = A.fit_thd[s * kMaxPatches + p];
-        // pass 1: size of the ground part and the filter counts
-        int n_g = 0, a_g = 0, a_ng = 0;
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
-            int g = 0, keep = 0;
-            if (j < n) {
-                const float4 q = sp[j];
-                g = plane_res(q, n0, n1, n2) < thd;
-                keep = (int)(f2u(q.w) >> 31);
-            }
-            n_g += __popcll(__ballot(g));
-            a_g += __popcll(__ballot(g && keep));
-            a_ng += __popcll(__ballot(!g && keep && j < n));
-        }
-        // pass 2: ordered placement
-        int run_g = 0;
+        // ONE pass: ground part grows from the front in z order, the non-ground part from the back
+        // (element r of the non-ground part lives at seg[n - 1 - r]; k_emit reads it that way)
+        int n_g = 0, n_ng = 0, a_g = 0, a_ng = 0;
         uint32_t* seg = A.seg + (size_t)base + off;
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            int g = 0;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            int g = 0, keep = 0;
+            uint32_t w = 0;
             if (j < n) {
-                q = sp[j];
+                const Xyz q = sp[j];
+                w = si[j];
                 g = plane_res(q, n0, n1, n2) < thd;
+                keep = (int)(w >> 31);
             }
             const unsigned long long bg = __ballot(g);
-            const int eg = __popcll(bg & ((1ull << lane) - 1ull));
+            const unsigned long long bn = __ballot(!g && j < n);
+            const unsigned long long below = (1ull << lane) - 1ull;
             if (j < n) {
-                const int dst = g ? (run_g + eg) : (n_g + (j - (run_g + eg)));
-                seg[dst] = f2u(q.w);
+                if (g)
+                    seg[n_g + __popcll(bg & below)] = w;
+                else
+                    seg[n - 1 - (n_ng + __popcll(bn & below))] = w;
             }
-            run_g += __popcll(bg);
+            a_g += __popcll(__ballot(g && keep));
+            a_ng += __popcll(__ballot(!g && keep && j < n));
+            n_g += __popcll(bg);
+            n_ng += __popcll(bn);
         }
         if (lane == 0) {
             PatchRec r;
@@ -690,6 +693,7 @@ __global__ __launch_bounds__(1024) void k_emit_offsets(DevParams P, Arena A) {
 
 constexpr int kEmitThreads = 256;
 __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
+    __shared__ uint32_t stage[4 * 64 * 11];  // per wave: up to 64 PointAPRI records (44 B each)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int total = A.order_off[64];
@@ -711,7 +715,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                 A.cls[base + id] = SCVOD_CLS_GROUND;
             }
         }
-        // non-ground stream of this patch: elements [e0, n)
+        // non-ground stream of this patch: for a rejected patch the ground part (front, ascending) followed
+        // by the non-ground part; the latter is stored back to front by k_pw_arrange
         const int e0 = kept ? r.n_g : 0;
         int run_keep = 0;
         for (int c0 = e0; c0 < r.n; c0 += 64) {
@@ -719,11 +724,13 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
             uint32_t v = 0;
             int keep = 0;
             if (e < r.n) {
-                v = seg[e];
+                v = (e < r.n_g) ? seg[e] : seg[r.n - 1 - (e - r.n_g)];
                 keep = (int)(v >> 31);
             }
             const unsigned long long bk = __ballot(keep);
             const int ek = __popcll(bk & ((1ull << lane) - 1ull));
+            const int nk = __popcll(bk);
+            const size_t dst0 = (size_t)base + xa + run_keep;  // first PointAPRI slot of this step
             if (e < r.n) {
                 const uint32_t id = v & 0x7fffffffu;
                 const int spos = e - e0;  // position in the non-ground stream of this patch
@@ -733,28 +740,36 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     const float4 q = A.pts[base + id];
                     Apri a;
                     apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-                    const size_t dst = (size_t)base + xa + run_keep + ek;
-                    scvod_apri out;
-                    out.x = a.x;
-                    out.y = a.y;
-                    out.z = a.z;
-                    out.range = a.range;
-                    out.angle = a.angle;
-                    out.azimuth = a.azimuth;
-                    out.intensity = a.intensity;
-                    out.range_idx = a.range_idx;
-                    out.sector_idx = a.sector_idx;
-                    out.azimuth_idx = a.azimuth_idx;
-                    out.voxel_idx = a.voxel_idx;
-                    A.apri[dst] = out;
-                    A.apri_src[dst] = (int32_t)id;
-                    A.apri_key[dst] = a.voxel_idx;
-                    A.apri_int[dst] = a.intensity;
+                    // stage the 11-dword record in LDS so the wave can store the nk records of this step
+                    // as one contiguous, coalesced run
+                    uint32_t* rec = stage + wave * (64 * 11) + ek * 11;
+                    rec[0] = f2u(a.x);
+                    rec[1] = f2u(a.y);
+                    rec[2] = f2u(a.z);
+                    rec[3] = f2u(a.range);
+                    rec[4] = f2u(a.angle);
+                    rec[5] = f2u(a.azimuth);
+                    rec[6] = f2u(a.intensity);
+                    rec[7] = (uint32_t)a.range_idx;
+                    rec[8] = (uint32_t)a.sector_idx;
+                    rec[9] = (uint32_t)a.azimuth_idx;
+                    rec[10] = (uint32_t)a.voxel_idx;
+                    A.apri_src[dst0 + ek] = (int32_t)id;
+                    A.apri_key[dst0 + ek] = a.voxel_idx;
+                    A.apri_int[dst0 + ek] = a.intensity;
                 } else {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
                 }
             }
-            run_keep += __popcll(bk);
+            // wave-synchronous: all lanes of this wave have written their records (same instruction stream)
+            __builtin_amdgcn_wave_barrier();
+            {
+                uint32_t* out = (uint32_t*)(A.apri + dst0);
+                const uint32_t* src = stage + wave * (64 * 11);
+                for (int k = lane; k < nk * 11; k += 64) out[k] = src[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            run_keep += nk;
         }
     }
 }
