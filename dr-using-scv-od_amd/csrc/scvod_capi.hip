@@ -115,7 +115,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.zkey = k.take<uint32_t>(N);
     c->t_pts = k.take<float4>(N);
     A.fit_thd = k.take<float>(B * kMaxPatches);
-    A.order = k.take<int32_t>(B * kMaxPatches);
+    A.order = k.take<int4>(B * kMaxPatches);
     A.order_hist = k.take<int32_t>(64);
     A.order_cursor = k.take<int32_t>(64);
     A.order_off = k.take<int32_t>(65);
@@ -139,7 +139,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vb_off = k.take<int32_t>(B * (kMaxBuckets + 1));
     A.vb_nvox = k.take<int32_t>(B * kMaxBuckets);
     A.vox_off = k.take<int32_t>(B * (kMaxBuckets + 1));
-    A.vorder = k.take<int32_t>(B * kMaxBuckets);
+    A.vorder = k.take<int4>(B * kMaxBuckets);
     A.vorder_hist = k.take<int32_t>(64);
     A.vorder_cursor = k.take<int32_t>(64);
     A.vorder_off = k.take<int32_t>(65);

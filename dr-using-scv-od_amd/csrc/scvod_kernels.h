@@ -53,7 +53,7 @@ struct Arena {
     uint32_t* sorted_idx;     // [N] same order: input index | (passes the range/FOV test) << 31
     uint32_t* zkey;           // [N] sortable z key per input point
     float* fit_thd;           // [B][kMaxPatches] th_dist_d_ of the last plane fit
-    int32_t* order;           // [B * kMaxPatches] live patches ordered by size class (descending)
+    int4* order;              // [B * kMaxPatches] live patches by descending size class: {scan*1024+patch, n, scan base, patch offset}
     int32_t* order_hist;      // [64]
     int32_t* order_cursor;    // [64]
     int32_t* order_off;       // [65]  ([64] = number of live patches)
@@ -79,7 +79,7 @@ struct Arena {
     int32_t* vb_off;          // [B][kMaxBuckets+1]
     int32_t* vb_nvox;         // [B][kMaxBuckets]
     int32_t* vox_off;         // [B][kMaxBuckets+1]
-    int32_t* vorder;          // [B * kMaxBuckets] non-empty buckets by descending size class
+    int4* vorder;             // [B * kMaxBuckets] non-empty buckets by descending size class (same item layout)
     int32_t* vorder_hist;     // [64]
     int32_t* vorder_cursor;   // [64]
     int32_t* vorder_off;      // [65]

@@ -170,6 +170,94 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
 }
 #undef IX
 
+// ---- power-of-two bitonic sort for the LDS tiers -------------------------------------------------
+// Classic bitonic network on np2 = 2^q slots (slots >= n hold +inf, the LDS tiers always have room
+// for them), every level a butterfly whose direction is given by bit k of the element index, so ALL
+// lg(k) levels of a stage can be register-blocked: a thread takes 2^t elements (t <= 4) that are
+// closed under t consecutive levels, sorts/merges them in registers and writes them back.  Runs of 16
+// are sorted entirely in registers first.  For np2 = 2048 this is 19 LDS passes instead of the 66 of a
+// level-per-pass network; no bounds predicates anywhere.
+template <typename T>
+__device__ __forceinline__ void cswap_dir(T& x, T& y, bool asc) {
+    const bool sw = asc ? (y < x) : (x < y);
+    const T nx = sw ? y : x;
+    const T ny = sw ? x : y;
+    x = nx;
+    y = ny;
+}
+
+template <int LT, typename T>  // butterfly levels with local distances 2^(LT-1) .. 1 on 2^LT registers
+__device__ __forceinline__ void reg_merge(T (&e)[1 << LT], bool asc) {
+#pragma unroll
+    for (int d = (1 << LT) >> 1; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int m = 0; m < (1 << LT); ++m)
+            if ((m & d) == 0) cswap_dir(e[m], e[m + d], asc);
+    }
+}
+
+template <int THREADS, bool PAD, int LT, typename T>
+__device__ __forceinline__ void bitonic_pass(T* a, int np2, int k, int r) {
+    // levels with distances 2^(r-1) .. 2^(r-LT) of stage k
+    constexpr int E = 1 << LT;
+    const int jl = 1 << (r - LT);
+    for (int t = threadIdx.x; t < (np2 >> LT); t += THREADS) {
+        const int b = ((t >> (r - LT)) << r) | (t & (jl - 1));
+        const bool asc = (b & k) == 0;
+        T e[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) e[m] = a[sort_slot<PAD>(b + m * jl)];
+        reg_merge<LT>(e, asc);
+#pragma unroll
+        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + m * jl)] = e[m];
+    }
+    __syncthreads();
+}
+
+template <int THREADS, bool PAD, typename T>
+__device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2 >= 16, power of two
+    // stages k = 2 .. 16 inside registers: runs of 16, run g ascending iff bit 16 of its base is clear
+    for (int g = threadIdx.x; g < (np2 >> 4); g += THREADS) {
+        const int b = g << 4;
+        T e[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) e[m] = a[sort_slot<PAD>(b + m)];
+#pragma unroll
+        for (int kk = 2; kk <= 16; kk <<= 1) {
+#pragma unroll
+            for (int d = kk >> 1; d >= 1; d >>= 1) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    if ((m & d) == 0) {
+                        const bool asc = (kk == 16) ? ((b & 16) == 0) : ((m & kk) == 0);
+                        cswap_dir(e[m], e[m + d], asc);
+                    }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) a[sort_slot<PAD>(b + m)] = e[m];
+    }
+    __syncthreads();
+    int lgk = 5;
+    for (int k = 32; k <= np2; k <<= 1, ++lgk) {
+        int r = lgk;  // levels still to do in this stage (distances 2^(r-1) .. 1)
+        const int first = (r & 3) ? (r & 3) : 4;  // leading partial pass so that the rest are full 4-level passes
+        if (first == 1)
+            bitonic_pass<THREADS, PAD, 1>(a, np2, k, r);
+        else if (first == 2)
+            bitonic_pass<THREADS, PAD, 2>(a, np2, k, r);
+        else if (first == 3)
+            bitonic_pass<THREADS, PAD, 3>(a, np2, k, r);
+        else
+            bitonic_pass<THREADS, PAD, 4>(a, np2, k, r);
+        r -= first;
+        while (r > 0) {
+            bitonic_pass<THREADS, PAD, 4>(a, np2, k, r);
+            r -= 4;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Patchwork stage 1: per point patch id + per-(scan, patch) histogram.
 // grid = (ceil(max_scan_pts / (256*ITEMS)), B), block = 256.  Coalesced float4 loads.
@@ -268,7 +356,7 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 //                 and the per-patch counters the ordered emission needs.
 // ------------------------------------------------------------------------------------------
 // size classes (pw_size_class) that bound the sort tiers: class 40 <=> n >= 1024, class 48 <=> n >= 4096
-constexpr int kClassM = 40, kClassL = 48;
+constexpr int kClassXS = 32, kClassM = 40, kClassM2 = 44, kClassL = 48;  // n >= 256 / 1024 / 2048 / 4096
 
 // order[] lists live items by descending size class; positions of classes [C_LO, C_HI]
 __device__ __forceinline__ void order_range(const int32_t* off, int c_lo, int c_hi, int& lo, int& hi) {
@@ -282,18 +370,18 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
     int lo, hi;
     order_range(A.order_off, C_LO, C_HI, lo, hi);
     for (int w = lo + blockIdx.x; w < hi; w += gridDim.x) {
-        const int code = A.order[w];
-        const int s = code / kMaxPatches, p = code - s * kMaxPatches;
-        const int n = A.patch_count[s * kMaxPatches + p];
-        const int base = A.scan_off[s];
-        const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+        const int4 item = A.order[w];
+        const int n = item.y, base = item.z, off = item.w;
         const bool in_lds = (n <= CAP);
         uint64_t* keys;
         if (in_lds) {
             keys = (uint64_t*)smem;
-            for (int j = threadIdx.x; j < n; j += THREADS) keys[sort_slot<true>(j)] = A.keys[(size_t)base + off + j];
+            int np2 = 16;
+            while (np2 < n) np2 <<= 1;
+            for (int j = threadIdx.x; j < np2; j += THREADS)
+                keys[sort_slot<true>(j)] = (j < n) ? A.keys[(size_t)base + off + j] : ~0ull;
             __syncthreads();
-            block_bitonic_sort<THREADS, true>(keys, n);
+            block_bitonic_sort_pow2<THREADS, true>(keys, np2);
         } else {
             keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
             block_bitonic_sort<THREADS, false>(keys, n);
@@ -303,14 +391,12 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
         for (int j = threadIdx.x; j < n; j += THREADS) {
             const uint32_t id = (uint32_t)keys[in_lds ? sort_slot<true>(j) : j];
             const float4 q = A.pts[base + id];
-            Apri a;
-            const int keep = apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
             Xyz o;
             o.x = q.x;
             o.y = q.y;
             o.z = q.z;
             dst[j] = o;
-            dsti[j] = id | (keep ? 0x80000000u : 0u);
+            dsti[j] = id;
         }
         __syncthreads();  // LDS is reused by the next item
     }
@@ -359,21 +445,22 @@ __global__ __launch_bounds__(256) void k_pw_order_scatter(DevParams P, Arena A) 
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    int c = -1, rank = 0, code = 0;
+    int c = -1, rank = 0;
+    int4 item = make_int4(0, 0, 0, 0);
     if (t < A.n_scans * P.n_patches) {
         const int s = t / P.n_patches, p = t - s * P.n_patches;
         const int n = A.patch_count[s * kMaxPatches + p];
         if (n > P.czm.num_min_pts) {
             c = pw_size_class(n);
             rank = atomicAdd(&hist[c], 1);
-            code = s * kMaxPatches + p;
+            item = make_int4(s * kMaxPatches + p, n, A.scan_off[s], A.patch_off[s * (kMaxPatches + 1) + p]);
         }
     }
     __syncthreads();
     if (threadIdx.x < 64 && hist[threadIdx.x])
         hist[threadIdx.x] = A.order_off[threadIdx.x] + atomicAdd(&A.order_cursor[threadIdx.x], hist[threadIdx.x]);
     __syncthreads();
-    if (c >= 0) A.order[hist[c] + rank] = code;
+    if (c >= 0) A.order[hist[c] + rank] = item;  // {scan*1024 + patch, n, scan base, patch offset}
 }
 
 // the same ordering for voxel buckets (counts in vb_count, min size 1)
@@ -407,21 +494,22 @@ __global__ __launch_bounds__(256) void k_vx_order_scatter(DevParams P, Arena A) 
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    int c = -1, rank = 0, code = 0;
+    int c = -1, rank = 0;
+    int4 item = make_int4(0, 0, 0, 0);
     if (t < A.n_scans * P.n_buckets) {
         const int s = t / P.n_buckets, b = t - s * P.n_buckets;
         const int m = A.vb_count[s * kMaxBuckets + b];
         if (m > 0) {
             c = pw_size_class(m);
             rank = atomicAdd(&hist[c], 1);
-            code = s * kMaxBuckets + b;
+            item = make_int4(s * kMaxBuckets + b, m, A.scan_off[s], A.vb_off[s * (kMaxBuckets + 1) + b]);
         }
     }
     __syncthreads();
     if (threadIdx.x < 64 && hist[threadIdx.x])
         hist[threadIdx.x] = A.vorder_off[threadIdx.x] + atomicAdd(&A.vorder_cursor[threadIdx.x], hist[threadIdx.x]);
     __syncthreads();
-    if (c >= 0) A.vorder[hist[c] + rank] = code;
+    if (c >= 0) A.vorder[hist[c] + rank] = item;
 }
 
 // per-point plane residual, Eigen GEMV order: fl(fl(x*n0 + y*n1) + z*n2)
@@ -435,11 +523,10 @@ __device__ __forceinline__ float plane_res(const Xyz& q, float n0, float n1, flo
 __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= A.order_off[64]) return;
-    const int code = A.order[t];
+    const int4 item = A.order[t];
+    const int code = item.x;
     const int s = code / kMaxPatches, p = code - s * kMaxPatches;
-    const int n = A.patch_count[s * kMaxPatches + p];
-    const int base = A.scan_off[s];
-    const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+    const int n = item.y, base = item.z, off = item.w;
     const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
 
     int zone = 0;
@@ -591,16 +678,16 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
     const int wave = threadIdx.x >> 6;
     const int total = A.order_off[64];
     for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
-        const int code = A.order[w];
+        const int4 item = A.order[w];
+        const int code = item.x;
         const int s = code / kMaxPatches, p = code - s * kMaxPatches;
-        const int n = A.patch_count[s * kMaxPatches + p];
-        const int base = A.scan_off[s];
-        const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+        const int n = item.y, base = item.z, off = item.w;
         const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
         const uint32_t* __restrict__ si = A.sorted_idx + (size_t)base + off;
         const scvod_patch_plane pl = A.planes[s * kMaxPatches + p];
         const float n0 = pl.normal[0], n1 = pl.normal[1], n2 = pl.normal[2];
         const float thd = A.fit_thd[s * kMaxPatches + p];
+        const bool rejected = (pl.status >= 2);
         // ONE pass: ground part grows from the front in z order, the non-ground part from the back
         // (element r of the non-ground part lives at seg[n - 1 - r]; k_emit reads it that way)
         int n_g = 0, n_ng = 0, a_g = 0, a_ng = 0;
@@ -613,7 +700,12 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
                 const Xyz q = sp[j];
                 w = si[j];
                 g = plane_res(q, n0, n1, n2) < thd;
-                keep = (int)(w >> 31);
+                // range/FOV verdict of makeApriVec, only for points that reach the non-ground stream
+                if (!g || rejected) {
+                    Apri a;
+                    keep = apri_of_point(P.bin, q.x, q.y, q.z, 0.f, a);
+                    w |= keep ? 0x80000000u : 0u;
+                }
             }
             const unsigned long long bg = __ballot(g);
             const unsigned long long bn = __ballot(!g && j < n);
@@ -698,11 +790,11 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
     const int wave = threadIdx.x >> 6;
     const int total = A.order_off[64];
     for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
-        const int code = A.order[w];
+        const int4 item = A.order[w];
+        const int code = item.x;
         const int s = code / kMaxPatches, p = code - s * kMaxPatches;
         const PatchRec r = A.patch_rec[s * kMaxPatches + p];
-        const int base = A.scan_off[s];
-        const int off = A.patch_off[s * (kMaxPatches + 1) + p];
+        const int base = item.z, off = item.w;
         const int* o = A.emit_off + ((size_t)s * kMaxPatches + p) * 4;
         const int xg = o[0], xng = o[1], xa = o[2], xr = o[3];
         const bool kept = (r.status == 1);
@@ -934,22 +1026,25 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     int lo, hi;
     order_range(A.vorder_off, C_LO, C_HI, lo, hi);
     for (int w = lo + blockIdx.x; w < hi; w += gridDim.x) {
-    const int code = A.vorder[w];
+    const int4 item = A.vorder[w];
+    const int code = item.x;
     const int s = code / kMaxBuckets, b = code - s * kMaxBuckets;
-    const int m = A.vb_count[s * kMaxBuckets + b];
-    const int base = A.scan_off[s];
-    const int off = A.vb_off[s * (kMaxBuckets + 1) + b];
+    const int m = item.y;
+    const int base = item.z, off = item.w;
     const bool in_lds = (m <= CAP);
     uint64_t* keys;
     int* vbeg;
     float* ints;
     if (in_lds) {
-        for (int j = threadIdx.x; j < m; j += THREADS) l_keys[sort_slot<true>(j)] = A.vkeys[(size_t)base + off + j];
+        int np2 = 16;
+        while (np2 < m) np2 <<= 1;
+        for (int j = threadIdx.x; j < np2; j += THREADS)
+            l_keys[sort_slot<true>(j)] = (j < m) ? A.vkeys[(size_t)base + off + j] : ~0ull;
         __syncthreads();
         keys = l_keys;
         vbeg = l_vbeg;
         ints = l_int;
-        block_bitonic_sort<THREADS, true>(keys, m);
+        block_bitonic_sort_pow2<THREADS, true>(keys, np2);
     } else {
         keys = A.vkeys + (size_t)base + off;
         vbeg = A.tmp_vox_begin + (size_t)base + off;  // rewritten below with final values
@@ -1231,12 +1326,16 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
                            sort_lds_bytes(kSortCapL), st, P, A);
         TH_END("pw_sort_large");
         TH_BEGIN("pw_sort_mid");
-        hipLaunchKernelGGL((k_pw_sort<kSortCapM, kSortThreadsM, kClassM, kClassL - 1>), dim3(kPersistCUs * 4),
-                           dim3(kSortThreadsM), sort_lds_bytes(kSortCapM), st, P, A);
+        hipLaunchKernelGGL((k_pw_sort<4096, 256, kClassM2, kClassL - 1>), dim3(kPersistCUs * 4), dim3(256),
+                           sort_lds_bytes(4096), st, P, A);
+        hipLaunchKernelGGL((k_pw_sort<2048, 128, kClassM, kClassM2 - 1>), dim3(kPersistCUs * 8), dim3(128),
+                           sort_lds_bytes(2048), st, P, A);
         TH_END("pw_sort_mid");
         TH_BEGIN("pw_sort_small");
-        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS, 0, kClassM - 1>), dim3(kPersistCUs * 16),
+        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS, kClassXS, kClassM - 1>), dim3(kPersistCUs * 16),
                            dim3(kSortThreadsS), sort_lds_bytes(kSortCapS), st, P, A);
+        hipLaunchKernelGGL((k_pw_sort<256, 64, 0, kClassXS - 1>), dim3(kPersistCUs * 32), dim3(64), sort_lds_bytes(256), st,
+                           P, A);
         TH_END("pw_sort_small");
         TH_BEGIN("pw_fit");
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
@@ -1282,19 +1381,23 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_END("vx_order");
         hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL, kClassL, 63>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
-        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapM, kVoxThreadsM, kClassM, kClassL - 1>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapM));
+        hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256, kClassM2, kClassL - 1>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
         TH_BEGIN("vx_bucket_large");
         hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL, kClassL, 63>), dim3(kPersistCUs), dim3(kVoxThreadsL),
                            vox_lds_bytes(kVoxCapL), st, P, A);
         TH_END("vx_bucket_large");
         TH_BEGIN("vx_bucket_mid");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapM, kVoxThreadsM, kClassM, kClassL - 1>), dim3(kPersistCUs * 2),
-                           dim3(kVoxThreadsM), vox_lds_bytes(kVoxCapM), st, P, A);
+        hipLaunchKernelGGL((k_vx_bucket<4096, 256, kClassM2, kClassL - 1>), dim3(kPersistCUs * 2), dim3(256),
+                           vox_lds_bytes(4096), st, P, A);
+        hipLaunchKernelGGL((k_vx_bucket<2048, 128, kClassM, kClassM2 - 1>), dim3(kPersistCUs * 4), dim3(128),
+                           vox_lds_bytes(2048), st, P, A);
         TH_END("vx_bucket_mid");
         TH_BEGIN("vx_bucket_small");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS, 0, kClassM - 1>), dim3(kPersistCUs * 8),
+        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS, kClassXS, kClassM - 1>), dim3(kPersistCUs * 8),
                            dim3(kVoxThreadsS), vox_lds_bytes(kVoxCapS), st, P, A);
+        hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st,
+                           P, A);
         TH_END("vx_bucket_small");
         TH_BEGIN("vx_final_offsets");
         hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
