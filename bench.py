@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scans", type=int, default=2761, help="scans per rank (seq 05 has 2761)")
-    ap.add_argument("--chunk", type=int, default=1024, help="scans per C-ABI batch call")
+    ap.add_argument("--chunk", type=int, default=0, help="scans per C-ABI batch call (0 = scans / streams)")
+    ap.add_argument("--streams", type=int, default=1, help="independent ctx + HIP stream pairs the chunks rotate over")
     ap.add_argument("--kind", default="K64")
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")
@@ -80,6 +81,8 @@ def main():
     seq = 5 + 11 * rank  # every rank scans its own seq-05-shaped sequence
     dev = torch.device("cuda", local)
 
+    if args.chunk <= 0:
+        args.chunk = (args.scans + args.streams - 1) // args.streams
     # ---- synthetic sequence, resident in HBM ----
     t0 = time.time()
     chunks = []
@@ -91,14 +94,20 @@ def main():
     gen_s = time.time() - t0
     max_pts = max(int(c["offs"][-1]) for c in chunks)
     total_pts = sum(int(c["offs"][-1]) for c in chunks)
-    ctx = scvod_py.Ctx(P, max_points_total=max_pts + 1024, max_scans=args.chunk, device=local)
-    stream = torch.cuda.current_stream().cuda_stream
+    n_ctx = max(1, min(args.streams, len(chunks)))
+    ctxs = [scvod_py.Ctx(P, max_points_total=max_pts + 1024, max_scans=args.chunk, device=local) for _ in range(n_ctx)]
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_ctx - 1)]
+    for i, c in enumerate(chunks):
+        c["ctx"] = ctxs[i % n_ctx]
+        c["stream"] = tstreams[i % n_ctx].cuda_stream
+    ctx = ctxs[0]
 
     # ---- pseudo "potentially mobile" clusters for the differencing stage: every 5th apri point of a
     # scan, in runs of 256 (the reference tracks only `car` clusters: ~5-6 k points per scan) ----
     tot_vox = 0
     tot_car = 0
     for c in chunks:
+        ctx, stream = c["ctx"], c["stream"]
         ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=True)
         cnt = ctx.batch_counts()
         tot_vox += int(cnt[:, 6].sum())
@@ -121,9 +130,9 @@ def main():
 
     def step():
         for c in chunks:
-            ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=False)
+            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
             if c["n_sc"] > 1:
-                ctx.batch_track(c["members"], c["cbegin"], c["pbegin"], c["T"], stream=stream, sync=False)
+                c["ctx"].batch_track(c["members"], c["cbegin"], c["pbegin"], c["T"], stream=c["stream"], sync=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,11 +143,11 @@ def main():
     for _ in range(args.warmup):
         step()
     # per-kernel hipEvent timing on the launch stream for the timed steps
-    ctx.set_timing(True)
     kt = {}
 
     def timed_step():
         for c in chunks:
+            ctx, stream = c["ctx"], c["stream"]
             ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=False)
             for name, ms in ctx.timings():
                 a = kt.setdefault(name, [0.0, 0])
@@ -152,7 +161,8 @@ def main():
                     a[1] += 1
 
     # timed region 1 (the number reported): no per-kernel events, async launches
-    ctx.set_timing(False)
+    for x in ctxs:
+        x.set_timing(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,12 +170,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # timed region 2: the same steps with hipEvents around every kernel (roofline attribution)
-    ctx.set_timing(True)
+    for x in ctxs:
+        x.set_timing(True)
     barrier()
     for _ in range(args.steps):
         timed_step()
     barrier()
-    ctx.set_timing(False)
+    for x in ctxs:
+        x.set_timing(False)
 
     dt, all_scans, all_pts = shard.aggregate(dist, dev, dt, args.scans, total_pts)
 
@@ -220,13 +232,14 @@ def main():
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"seq05-shaped {args.kind} sequence, {args.scans} scans/rank, {args.preset}.yaml grid, "
-                                      f"chunks of {args.chunk} scans", "scans_per_rank": args.scans,
+                                      f"chunks of {args.chunk} scans on {n_ctx} stream(s)", "scans_per_rank": args.scans,
                           "points_per_scan": total_pts / args.scans, "voxels_per_scan": tot_vox / args.scans,
                           "car_points_per_scan": tot_car / args.scans, "sharding": f"1 sequence per GPU x{world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(out))
-    ctx.close()
+    for x in ctxs:
+        x.close()
     if dist is not None:
         dist.destroy_process_group()
 

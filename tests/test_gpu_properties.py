@@ -1,0 +1,114 @@
+"""Size-independent properties of the HIP path at BASELINE.json's full scan sizes (where the oracle
+would take too long to run on every scan): conservation, ordering, idempotence, checksums."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _invariants(r, x, grid):
+    R, S, A, bins = grid
+    n = r["n_points"]
+    assert n == x.shape[0] == r["n_ground"] + r["n_nonground"] + r["n_dropped"]
+    assert r["n_apri"] + r["n_rejected"] == r["n_nonground"]
+    cls = r["cls"]
+    assert (cls[r["ground_idx"]] == 0).all() and (cls[r["nonground_idx"]] == 1).all()
+    assert int((cls == 0).sum()) == r["n_ground"] and int((cls == 1).sum()) == r["n_nonground"]
+    # index lists are permutations of disjoint subsets
+    assert len(np.unique(r["ground_idx"])) == r["n_ground"] and len(np.unique(r["nonground_idx"])) == r["n_nonground"]
+    # apri_vec is the non-ground cloud filtered IN ORDER
+    pos = np.full(n, -1, np.int64)
+    pos[r["nonground_idx"]] = np.arange(r["n_nonground"])
+    pa, pr = pos[r["apri_src"]], pos[r["rejected_src"]]
+    assert (pa >= 0).all() and (pr >= 0).all() and (np.diff(pa) > 0).all() and (np.diff(pr) > 0).all()
+    assert np.array_equal(np.sort(np.concatenate([pa, pr])), np.arange(r["n_nonground"]))
+    a = r["apri"]
+    assert np.array_equal(a["x"].view(np.uint32), x[r["apri_src"], 0].view(np.uint32))
+    assert np.array_equal(a["voxel_idx"], a["azimuth_idx"] * R * S + a["range_idx"] * S + a["sector_idx"])
+    assert (a["voxel_idx"] < bins).all()
+    # hash cloud: keys strictly ascending, CSR covers every apri point once, ptIdx ascending per voxel
+    k, b, p = r["vox_key"], r["vox_pt_begin"], r["vox_pts"]
+    assert (np.diff(k) > 0).all() and b[0] == 0 and b[-1] == r["n_apri"] and (np.diff(b) > 0).all()
+    assert np.array_equal(np.sort(p), np.arange(r["n_apri"]))
+    vox_of = np.repeat(np.arange(len(k)), np.diff(b))
+    assert np.array_equal(a["voxel_idx"][p], k[vox_of])
+    same = vox_of[1:] == vox_of[:-1]
+    assert (np.diff(p)[same] > 0).all()
+    # descriptor floats against a float64 recomputation (1e-4, north_star tolerance)
+    inten = a["intensity"][p].astype(np.float64)
+    cnt = np.diff(b)
+    mean = np.add.reduceat(inten, b[:-1]) / cnt
+    var = np.add.reduceat((inten - mean[vox_of]) ** 2, b[:-1]) / cnt
+    assert np.allclose(r["vox_av"], mean, rtol=1e-4, atol=1e-3)
+    assert np.allclose(r["vox_cov"], var, rtol=1e-3, atol=1e-2)
+    # Patchwork planes: unit normals, singular values descending, populations add up
+    pl = r["planes"]
+    live = pl["status"] > 0
+    assert np.allclose(np.linalg.norm(pl["normal"][live], axis=1), 1.0, atol=1e-4)
+    assert (pl["sv"][live][:, 0] >= pl["sv"][live][:, 1]).all() and (pl["sv"][live][:, 1] >= pl["sv"][live][:, 2]).all()
+    assert pl["n_pts"][live].sum() == r["n_ground"] + r["n_nonground"]
+    assert (pl["n_ground"][pl["status"] == 1]).sum() == r["n_ground"]
+    return (int(r["n_ground"]), int(r["n_apri"]), int(r["n_voxels"]), int(k.astype(np.int64).sum() % (1 << 31)),
+            int(a["voxel_idx"].astype(np.int64).sum() % (1 << 31)))
+
+
+@pytest.mark.parametrize("kind,preset,count", [("K64", "semantickitti", 48), ("OS128", "os128_fine", 6), ("PARK", "parkinglot", 24)])
+def test_full_size_batches(scvod, kind, preset, count):
+    import torch
+    import synth
+    P = scvod.make_params(preset)
+    grid = scvod.grid_dims(P)
+    pts, offs, poses, _ = synth.make_batch(5, 1000, count, kind, device="cuda")
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    ctx.batch_process(pts, offs)
+    c1 = ctx.batch_counts().copy()
+    x = pts.cpu().numpy()
+    sums = []
+    for s in (0, count // 2, count - 1):
+        sums.append(_invariants(ctx.batch_fetch(s), x[offs[s]:offs[s + 1]], grid))
+    # idempotence + order independence: the same scans in reverse batch order give the same per-scan results
+    rev_pts = torch.cat([pts[offs[s]:offs[s + 1]] for s in reversed(range(count))]).contiguous()
+    rev_offs = np.concatenate([[0], np.cumsum([offs[s + 1] - offs[s] for s in reversed(range(count))])]).astype(np.int32)
+    ctx.batch_process(rev_pts, rev_offs)
+    c2 = ctx.batch_counts()
+    assert np.array_equal(c1, c2[::-1])
+    xr = rev_pts.cpu().numpy()
+    s = count - 1
+    assert _invariants(ctx.batch_fetch(0), xr[rev_offs[0]:rev_offs[1]], grid) == sums[2]
+    # scan-vs-next-scan probe over the batch: every cluster's unique-hit count is bounded by its size and by
+    # the next scan's table, and a scan probed against ITSELF (identity transform) hits every own voxel
+    ctx.batch_process(pts, offs)
+    cnt = ctx.batch_counts()
+    members, cbegin, pbegin = [], [0], [0]
+    for s in range(count - 1):
+        m = np.arange(0, cnt[s, 4], 3, dtype=np.int32)
+        members.append(m)
+        for k in range(0, len(m), 500):
+            cbegin.append(cbegin[-1] + min(500, len(m) - k))
+        pbegin.append(len(cbegin) - 1)
+    mem = torch.from_numpy(np.concatenate(members)).cuda()
+    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)])
+    ctx.batch_track(mem, cbegin, pbegin, T)
+    uq = ctx.batch_track_counts()
+    sizes = np.diff(np.asarray(cbegin))
+    assert (uq <= sizes).all() and (uq >= 0).all() and uq.sum() > 0
+    for s in range(count - 1):
+        assert (uq[pbegin[s]:pbegin[s + 1]] <= cnt[s + 1, 6]).all()
+    ctx.close()
+
+
+def test_self_probe_hits_every_voxel(scvod):
+    import synth
+    P = scvod.make_params("semantickitti")
+    pts, _, _ = synth.make_scan(5, 77, "K64")
+    x = pts.numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    a = r["apri"]
+    xyzi = np.stack([a["x"], a["y"], a["z"], a["intensity"]], 1)
+    T = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    hit, uq, ub = ctx.track_probe(xyzi, [0, len(a)], T, r["vox_key"], None)
+    assert (hit >= 0).all()                       # identity transform: every point finds its own voxel
+    assert np.array_equal(r["vox_key"][hit], a["voxel_idx"])
+    assert np.array_equal(uq, np.arange(r["n_voxels"]))
+    ctx.close()
