@@ -274,11 +274,18 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_classify(DevParams P, Arena 
     if (start >= n) return;
     for (int b = threadIdx.x; b < P.n_patches; b += kClsThreads) hist[b] = 0;
     __syncthreads();
+    // all loads first (8 x 16 B in flight per lane), then the fp64 zone / ring / sector arithmetic
+    float4 pt[kClsItems];
 #pragma unroll
     for (int it = 0; it < kClsItems; ++it) {
-        int i = start + it * kClsThreads + threadIdx.x;
+        const int i = start + it * kClsThreads + threadIdx.x;
+        pt[it] = A.pts[base + min(i, n - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < kClsItems; ++it) {
+        const int i = start + it * kClsThreads + threadIdx.x;
         if (i < n) {
-            float4 p = A.pts[base + i];
+            const float4 p = pt[it];
             int pid = czm_patch_of(P.czm, p.x, p.y, p.z);
             A.pid[base + i] = (int16_t)pid;
             A.zkey[base + i] = float_sort_key(p.z);
@@ -318,14 +325,13 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
     uint32_t zk[kClsItems];
 #pragma unroll
     for (int it = 0; it < kClsItems; ++it) {
-        int i = start + it * kClsThreads + threadIdx.x;
-        pid[it] = -1;
-        if (i < n) {
-            pid[it] = A.pid[base + i];
-            zk[it] = A.zkey[base + i];
-            if (pid[it] >= 0) rank[it] = atomicAdd(&hist[pid[it]], 1);
-        }
+        const int i = start + it * kClsThreads + threadIdx.x;
+        pid[it] = (i < n) ? (int)A.pid[base + i] : -1;
+        zk[it] = A.zkey[base + min(i, n - 1)];
     }
+#pragma unroll
+    for (int it = 0; it < kClsItems; ++it)
+        if (pid[it] >= 0) rank[it] = atomicAdd(&hist[pid[it]], 1);
     __syncthreads();
     for (int b = threadIdx.x; b < P.n_patches; b += kClsThreads) {
         int c = hist[b];
@@ -811,14 +817,15 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
         // by the non-ground part; the latter is stored back to front by k_pw_arrange
         const int e0 = kept ? r.n_g : 0;
         int run_keep = 0;
+        auto seg_at = [&](int e) -> uint32_t {
+            return (e < r.n) ? ((e < r.n_g) ? seg[e] : seg[r.n - 1 - (e - r.n_g)]) : 0u;
+        };
+        uint32_t v_next = seg_at(e0 + lane);
         for (int c0 = e0; c0 < r.n; c0 += 64) {
             const int e = c0 + lane;
-            uint32_t v = 0;
-            int keep = 0;
-            if (e < r.n) {
-                v = (e < r.n_g) ? seg[e] : seg[r.n - 1 - (e - r.n_g)];
-                keep = (int)(v >> 31);
-            }
+            const uint32_t v = v_next;
+            v_next = seg_at(e + 64);  // next step's word is in flight while this step computes
+            const int keep = (e < r.n) ? (int)(v >> 31) : 0;
             const unsigned long long bk = __ballot(keep);
             const int ek = __popcll(bk & ((1ull << lane) - 1ull));
             const int nk = __popcll(bk);
