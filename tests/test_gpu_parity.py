@@ -169,3 +169,33 @@ def test_nn_search_parity(scvod, oracle):
         assert np.array_equal(d.view(np.uint32), od.view(np.uint32))
         assert np.array_equal(w, ow)
     ctx.close()
+
+
+def test_error_conventions(scvod):
+    """Status codes instead of exceptions / aborts (SURVEY 8b error conventions)."""
+    import ctypes as C
+    import torch
+    P = _params(scvod, "semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=1000, max_scans=2)
+    lib = ctx.lib
+    r = scvod.ScanResult()
+    x = np.zeros((2000, 4), np.float32)
+    assert lib.scvod_process_scan(ctx.h, x.ctypes.data_as(C.c_void_p), 2000, C.byref(r)) == -4      # capacity
+    assert b"capacity" in lib.scvod_last_error(ctx.h)
+    assert lib.scvod_process_scan(ctx.h, None, 10, C.byref(r)) == -1                                 # invalid
+    assert lib.scvod_batch_fetch(ctx.h, 0, C.byref(r)) in (-5, 0)                                    # state / stale ok
+    d = torch.zeros((100, 4), device="cuda")
+    off = np.array([0, 40, 100, 100, 100], np.int32)                                                 # 4 scans > max_scans 2
+    assert lib.scvod_batch_process(ctx.h, C.c_void_p(d.data_ptr()), off.ctypes.data_as(C.c_void_p), 4, None, 1) == -4
+    off = np.array([0, 60, 40], np.int32)                                                            # not monotone
+    assert lib.scvod_batch_process(ctx.h, C.c_void_p(d.data_ptr()), off.ctypes.data_as(C.c_void_p), 2, None, 1) == -1
+    # a batch with an empty scan in the middle is fine
+    off = np.array([0, 50, 50], np.int32)
+    ctx.batch_process(d, off)
+    c = ctx.batch_counts()
+    assert c[1, 0] == 0 and c[1, 4] == 0 and c[0, 0] == 50
+    # bad grid parameters are rejected at creation
+    bad = scvod.make_params("semantickitti", range_res=0.0)
+    with pytest.raises(scvod.ScvodError):
+        scvod.Ctx(bad, max_points_total=100)
+    ctx.close()
