@@ -179,6 +179,23 @@ def main():
     for x in ctxs:
         x.set_timing(False)
 
+    # "next" row 8(f)-1, reported separately (not part of `value`): curved-voxel clustering on the resident batch
+    cc_ms = None
+    try:
+        barrier()
+        t1 = time.perf_counter()
+        for c in chunks:
+            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
+        barrier()
+        t_proc = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for c in chunks:
+            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
+            c["ctx"].batch_cluster(stream=c["stream"], sync=False)
+        barrier()
+        cc_ms = 1e3 * ((time.perf_counter() - t1) - t_proc)
+    except Exception as e:  # never let the optional stage break the bench line
+        cc_ms = None
     dt, all_scans, all_pts = shard.aggregate(dist, dev, dt, args.scans, total_pts)
 
     if rank == 0:
@@ -236,7 +253,8 @@ def main():
                           "points_per_scan": total_pts / args.scans, "voxels_per_scan": tot_vox / args.scans,
                           "car_points_per_scan": tot_car / args.scans, "sharding": f"1 sequence per GPU x{world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
-               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+               "extras": {"cluster_ms_per_sequence": cc_ms}}
         print(json.dumps(out))
     for x in ctxs:
         x.close()

@@ -52,6 +52,7 @@ struct scvod_ctx {
     std::vector<int32_t> h_scan_off;
     std::vector<int32_t> h_counts;
     bool counts_valid = false;
+    bool clusters_valid = false;
     hipStream_t last_stream = nullptr;
     int32_t last_track_clusters = 0;
     // host staging for scvod_scan_result
@@ -153,6 +154,10 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vox_pts = k.take<int32_t>(N);
     A.vox_av = k.take<float>(N);
     A.vox_cov = k.take<float>(N);
+    A.cc_parent = k.take<int32_t>(N);
+    A.cc_touched = k.take<uint8_t>(N);
+    A.pt_voxel = k.take<int32_t>(N);
+    A.pt_cluster = k.take<int32_t>(N);
     c->t_hit = k.take<int32_t>(N);
     c->t_work = k.take<uint64_t>(N);
     c->t_uniq = k.take<int32_t>(N);
@@ -282,6 +287,7 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->tim_used = 0;
     c->batch_valid = false;
     c->counts_valid = false;
+    c->clusters_valid = false;
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     if (mx == 0) {
@@ -643,6 +649,43 @@ int scvod_batch_counts(scvod_ctx* c, int32_t* h_out) {
 int scvod_batch_fetch(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
     if (!c || !out) return SCVOD_ERR_INVALID;
     return fetch_scan(c, s, out);
+}
+
+int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
+    if (!c) return SCVOD_ERR_INVALID;
+    if (!c->batch_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_cluster needs a processed batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->last_stream = st;
+    c->tim_used = 0;
+    launch_cluster(c->dev, c->A, st, timer_hook, c);
+    HIPCHK(c, hipGetLastError());
+    c->clusters_valid = true;
+    if (sync) HIPCHK(c, hipStreamSynchronize(st));
+    return SCVOD_OK;
+}
+
+int scvod_batch_fetch_clusters(scvod_ctx* c, int32_t s, int32_t* h_pt_cluster, int32_t cap) {
+    if (!c || !h_pt_cluster) return SCVOD_ERR_INVALID;
+    if (!c->clusters_valid) return fail(c, SCVOD_ERR_STATE, "no clusters computed for the last batch");
+    int rc = ensure_counts(c);
+    if (rc) return rc;
+    if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
+    const int32_t n = c->h_counts[(size_t)s * 8 + 4];
+    if (n > cap) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d)", cap, n);
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    if (n) HIPCHK(c, hipMemcpy(h_pt_cluster, c->A.pt_cluster + c->h_scan_off[s], sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int scvod_cluster(scvod_ctx* c, const scvod_apri* h_apri, int32_t n, int32_t* h_pt_cluster) {
+    scvod_scan_result r;
+    int rc = scvod_voxelize(c, h_apri, n, &r);
+    if (rc) return rc;
+    rc = scvod_batch_cluster(c, nullptr, 1);
+    if (rc) return rc;
+    rc = scvod_batch_fetch_clusters(c, 0, h_pt_cluster, n);
+    return rc < 0 ? rc : SCVOD_OK;
 }
 
 int scvod_batch_track(scvod_ctx* c, const int32_t* d_members, const int32_t* h_cluster_begin, int32_t n_clusters,

@@ -93,6 +93,11 @@ struct Arena {
     int32_t* vox_pts;         // [N]
     float* vox_av;            // [N]
     float* vox_cov;           // [N]
+    // clustering (connected components of occupied voxels)
+    int32_t* cc_parent;       // [N] union-find forest over apri indices (scan-local)
+    uint8_t* cc_touched;      // [N] per voxel slot: appeared in a neighbourhood
+    int32_t* pt_voxel;        // [N] voxel slot of every apri point
+    int32_t* pt_cluster;      // [N] canonical cluster name = smallest apri index of the component
 };
 
 struct TrackJob {          // scan-vs-next-scan probe
@@ -122,6 +127,7 @@ typedef void (*TimerHook)(void* user, const char* name, int begin);
 // 2 = neither (apri / counts already in the arena: voxel stage only).
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu);
+void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,

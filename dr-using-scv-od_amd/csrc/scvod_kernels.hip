@@ -1144,6 +1144,134 @@ __global__ __launch_bounds__(256) void k_vx_final(DevParams P, Arena A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Curved-voxel clustering (SSC::clusterAndCreateFrame, src/ssc.cpp:299-352).
+// The reference walks the points in order and merges a point with EVERY point of the occupied voxels
+// in the 3x3x3 neighbourhood of its own (range, sector, azimuth) index, clipped to the grid, no sector
+// wrap-around (findVoxelNeighbors, ssc.cpp:395-411).  The resulting partition is order independent:
+// it is the set of connected components of that relation, computed here with a lock-free union-find
+// (smaller index wins, so the canonical name of a cluster is its smallest apri index).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cc_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int cc_find(int* parent, int x) {
+    int p = cc_load(&parent[x]);
+    while (p != x) {
+        const int gp = cc_load(&parent[p]);
+        if (gp != p) atomicMin(&parent[x], gp);  // path halving (only ever moves towards smaller ancestors)
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void cc_union(int* parent, int a, int b) {
+    for (;;) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&parent[a], a, b) == a) return;  // a was still a root: now hangs under the smaller b
+    }
+}
+
+__device__ __forceinline__ int vox_slot_of(const int32_t* keys, int nv, int key) {
+    int lo = 0, hi = nv;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (lo < nv && keys[lo] == key) ? lo : -1;
+}
+
+__global__ __launch_bounds__(256) void k_cc_init(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        A.cc_parent[(size_t)base + i] = i;
+        A.cc_touched[(size_t)base + i] = 0;
+    }
+}
+
+// one thread per voxel: neighbourhood look-ups with the index triple(s) of its points
+__global__ __launch_bounds__(256) void k_cc_link(DevParams P, Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int nv = A.counts[s * 8 + 6];
+    const int32_t* keys = A.vox_key + base;
+    const int32_t* vbeg = A.vox_pt_begin + base + s;
+    const int32_t* vpts = A.vox_pts + base;
+    int* parent = A.cc_parent + base;
+    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+        const int b0 = vbeg[v], b1 = vbeg[v + 1];
+        int done_r = 0x7fffffff, done_s = 0, done_a = 0;  // triple handled last (voxels are almost always uniform)
+        int leader = -1;
+        for (int k = b0; k < b1; ++k) {
+            const int pt = vpts[k];
+            A.pt_voxel[(size_t)base + pt] = v;
+            const scvod_apri& a = A.apri[(size_t)base + pt];
+            const int ri = a.range_idx, si = a.sector_idx, ai = a.azimuth_idx;
+            if (ri == done_r && si == done_s && ai == done_a) {
+                if (leader >= 0) cc_union(parent, pt, leader);  // same neighbourhood as the leader, which was non-empty
+                continue;
+            }
+            done_r = ri;
+            done_s = si;
+            done_a = ai;
+            leader = -1;
+            for (int x = ri - 1; x <= ri + 1; ++x) {
+                if (x > R - 1 || x < 0) continue;
+                for (int y = si - 1; y <= si + 1; ++y) {
+                    if (y > S - 1 || y < 0) continue;
+                    for (int z = ai - 1; z <= ai + 1; ++z) {
+                        if (z > Az - 1 || z < 0) continue;
+                        const int u = vox_slot_of(keys, nv, x * S + y + z * R * S);
+                        if (u < 0) continue;
+                        A.cc_touched[(size_t)base + u] = 1;  // every point of u joins (ssc.cpp:316)
+                        cc_union(parent, pt, vpts[vbeg[u]]);
+                        leader = pt;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// every point of a voxel that appeared in somebody's neighbourhood is merged with that voxel's first point
+__global__ __launch_bounds__(256) void k_cc_join(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    const int32_t* vbeg = A.vox_pt_begin + base + s;
+    const int32_t* vpts = A.vox_pts + base;
+    int* parent = A.cc_parent + base;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int v = A.pt_voxel[(size_t)base + i];
+        if (A.cc_touched[(size_t)base + v]) cc_union(parent, i, vpts[vbeg[v]]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_flatten(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    int* parent = A.cc_parent + base;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int r = i;
+        for (int p = parent[r]; p != r; p = parent[r]) r = p;  // read-only walk: roots are final after k_cc_join
+        A.pt_cluster[(size_t)base + i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Scan-vs-next-scan differencing, bulk part of SSC::tracking (ssc.cpp:1274-1321)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int cluster_of_point(const int32_t* begin, int n_clusters, int k) {
@@ -1413,6 +1541,24 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_final, gb, dim3(256), 0, st, P, A);
         TH_END("vx_final");
     }
+}
+
+void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
+    const int B = A.n_scans;
+    if (B <= 0 || A.max_scan_pts <= 0) return;
+    dim3 g((A.max_scan_pts + 2047) / 2048, B);
+    TH_BEGIN("cc_init");
+    hipLaunchKernelGGL(k_cc_init, g, dim3(256), 0, st, A);
+    TH_END("cc_init");
+    TH_BEGIN("cc_link");
+    hipLaunchKernelGGL(k_cc_link, dim3((A.max_scan_pts / 4 + 255) / 256 + 1, B), dim3(256), 0, st, P, A);
+    TH_END("cc_link");
+    TH_BEGIN("cc_join");
+    hipLaunchKernelGGL(k_cc_join, g, dim3(256), 0, st, A);
+    TH_END("cc_join");
+    TH_BEGIN("cc_flatten");
+    hipLaunchKernelGGL(k_cc_flatten, g, dim3(256), 0, st, A);
+    TH_END("cc_flatten");
 }
 
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,

@@ -101,6 +101,9 @@ def load_lib():
         "scvod_batch_process": (C.c_int, [vp, vp, vp, i32, vp, i32]),
         "scvod_batch_counts": (C.c_int, [vp, vp]),
         "scvod_batch_fetch": (C.c_int, [vp, i32, C.POINTER(ScanResult)]),
+        "scvod_batch_cluster": (C.c_int, [vp, vp, i32]),
+        "scvod_batch_fetch_clusters": (C.c_int, [vp, i32, vp, i32]),
+        "scvod_cluster": (C.c_int, [vp, vp, i32, vp]),
         "scvod_batch_track": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, i32]),
         "scvod_batch_track_counts": (C.c_int, [vp, vp, i32]),
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
@@ -118,7 +121,8 @@ def load_lib():
 EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_grid_dims", "scvod_create",
                     "scvod_destroy", "scvod_last_error", "scvod_arena_bytes", "scvod_process_scan", "scvod_patchwork",
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
-                    "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_track", "scvod_batch_track_counts",
+                    "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
+                    "scvod_batch_track", "scvod_batch_track_counts",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search"]
 
 
@@ -282,6 +286,22 @@ class Ctx:
         r = ScanResult()
         self._chk(self.lib.scvod_batch_fetch(self.h, int(s), C.byref(r)))
         return _unpack(r)
+
+    def batch_cluster(self, stream=None, sync=True):
+        self._chk(self.lib.scvod_batch_cluster(self.h, C.c_void_p(stream or 0), int(sync)))
+
+    def batch_fetch_clusters(self, s, cap):
+        out = np.zeros(max(cap, 1), np.int32)
+        n = self.lib.scvod_batch_fetch_clusters(self.h, int(s), out.ctypes.data_as(C.c_void_p), int(cap))
+        if n < 0:
+            self._chk(n)
+        return out[:n]
+
+    def cluster(self, apri):
+        a = np.ascontiguousarray(apri)
+        out = np.zeros(max(a.shape[0], 1), np.int32)
+        self._chk(self.lib.scvod_cluster(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out[:a.shape[0]]
 
     def batch_track(self, d_members, cluster_begin, pair_cluster_begin, T, stream=None, sync=True):
         cb, pcb = self._i32(cluster_begin)

@@ -227,6 +227,18 @@ int scvod_batch_track(scvod_ctx* ctx, const int32_t* d_members, const int32_t* h
                       void* stream, int32_t sync);
 int scvod_batch_track_counts(scvod_ctx* ctx, int32_t* h_out_unique, int32_t n_clusters);
 
+/* Curved-voxel clustering of the last batch (SSC::clusterAndCreateFrame, src/ssc.cpp:299-352):
+ * connected components of apri points under the reference's 3x3x3 occupied-voxel neighbourhood (grid
+ * clipped, no sector wrap-around, findVoxelNeighbors ssc.cpp:395-411).  The partition equals the
+ * reference's; cluster NAMES are canonical (smallest apri index of the cluster) instead of the
+ * order-dependent 5, 6, 7... of the reference.  Results stay on the device until fetched. */
+int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
+/* copies the cluster name of every apri point of scan s into h_pt_cluster[cap]; returns the count (>= 0)
+ * or a negative status */
+int scvod_batch_fetch_clusters(scvod_ctx* ctx, int32_t s, int32_t* h_pt_cluster, int32_t cap);
+/* one-shot host version on an apri_vec the caller holds (voxelises it first) */
+int scvod_cluster(scvod_ctx* ctx, const scvod_apri* h_apri, int32_t n, int32_t* h_pt_cluster);
+
 /* hipEvent timing of the kernels of the last batch call, in launch order:
  * names[i] (static strings), ms[i].  Returns the number of entries (<= cap). */
 int scvod_batch_timings(scvod_ctx* ctx, const char** names, float* ms, int32_t cap);

@@ -199,3 +199,55 @@ def test_error_conventions(scvod):
     with pytest.raises(scvod.ScvodError):
         scvod.Ctx(bad, max_points_total=100)
     ctx.close()
+
+
+def _canonical(labels):
+    """cluster names -> smallest member index (partition comparison independent of naming)."""
+    labels = np.asarray(labels)
+    order = np.argsort(labels, kind="stable")
+    first = np.ones(len(labels), bool)
+    first[1:] = labels[order][1:] != labels[order][:-1]
+    mins = np.minimum.reduceat(order, np.nonzero(first)[0])
+    out = np.empty(len(labels), np.int64)
+    out[order] = np.repeat(mins, np.diff(np.append(np.nonzero(first)[0], len(labels))))
+    return out
+
+
+@pytest.mark.parametrize("kind,preset,seq,idx,stride", [("K64", "semantickitti", 5, 10, 3), ("PARK", "parkinglot", 3, 4, 1)])
+def test_cluster_partition_matches_reference_cvc(scvod, oracle, kind, preset, seq, idx, stride):
+    """SURVEY 8(f)-1: GPU connected components == partition of SSC::clusterAndCreateFrame (oracle restatement)."""
+    import synth
+    P = _params(scvod, preset)
+    pts, _, _ = synth.make_scan(seq, idx, kind)
+    x = pts.numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    apri = r["apri"][::stride].copy()          # the oracle's CVC is O(N^2): thin the cloud for the large config
+    got = ctx.cluster(apri)
+    ref, n_ref, _ = oracle.cluster(P, apri)
+    assert np.array_equal(got, _canonical(ref))
+    assert len(np.unique(got)) == n_ref
+    assert (got <= np.arange(len(got))).all()   # canonical name = smallest member
+    # batch entry point gives the same labels for the full-density scan as the one-shot call
+    ctx.process_scan(x)
+    ctx.batch_cluster()
+    full = ctx.batch_fetch_clusters(0, r["n_apri"])
+    assert np.array_equal(full, ctx.cluster(r["apri"]))
+    ctx.close()
+
+
+def test_cluster_edge_aliases(scvod, oracle):
+    """points whose index triple has a -1 (y == +0, dis == min_dis) and a tiny isolated cloud"""
+    rng = np.random.default_rng(21)
+    P = _params(scvod, "semantickitti")
+    a = np.stack([rng.uniform(2, 25, 3000), np.zeros(3000), rng.uniform(-1, 1, 3000), rng.uniform(0, 255, 3000)], 1)
+    b = rng.uniform(-20, 20, (4000, 4))
+    b[:, 2] = rng.uniform(-1.5, 2, 4000)
+    x = np.concatenate([a, b]).astype(np.float32)
+    ctx = scvod.Ctx(P, max_points_total=20000, max_scans=1)
+    bn = oracle.bin(P, x, True)["apri"]
+    got = ctx.cluster(bn)
+    ref, _, _ = oracle.cluster(P, bn)
+    assert np.array_equal(got, _canonical(ref))
+    assert len(ctx.cluster(np.zeros(0, scvod.APRI_DTYPE))) == 0
+    ctx.close()
