@@ -61,18 +61,25 @@ def main():
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_device:
+        local = 0
     assert torch.cuda.is_available(), "bench.py needs a GPU: the SCV-OD path has no CPU fallback"
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     import scvod_py
     import shard
     import synth
@@ -196,7 +203,7 @@ def main():
         cc_ms = 1e3 * ((time.perf_counter() - t1) - t_proc)
     except Exception as e:  # never let the optional stage break the bench line
         cc_ms = None
-    dt, all_scans, all_pts = shard.aggregate(dist, dev, dt, args.scans, total_pts)
+    dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, args.scans, total_pts)
 
     if rank == 0:
         scans_per_s = all_scans * args.steps / dt

@@ -80,6 +80,12 @@ def load_lib():
         pass
     path = os.path.abspath(LIB_PATH)
     if not os.path.exists(path):
+        # the library is a build product (git-ignored): compile it in-tree when a hipcc is around
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            subprocess.check_call(["make", "-C", os.path.dirname(path)])
+    if not os.path.exists(path):
         raise RuntimeError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the SCV-OD hot path has no CPU fallback)")
     lib = C.CDLL(path)
