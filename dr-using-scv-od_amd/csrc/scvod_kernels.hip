@@ -214,34 +214,35 @@ __device__ __forceinline__ void bitonic_pass(T* a, int np2, int k, int r) {
     __syncthreads();
 }
 
-template <int THREADS, bool PAD, typename T>
-__device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2 >= 16, power of two
-    // stages k = 2 .. 16 inside registers: runs of 16, run g ascending iff bit 16 of its base is clear
-    for (int g = threadIdx.x; g < (np2 >> 4); g += THREADS) {
-        const int b = g << 4;
-        T e[16];
+template <int THREADS, bool PAD, int LGE, typename T>
+__device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2 >= 2^LGE, power of two
+    constexpr int E = 1 << LGE;
+    // stages k = 2 .. E inside registers: runs of E, run g ascending iff bit E of its base is clear
+    for (int g = threadIdx.x; g < (np2 >> LGE); g += THREADS) {
+        const int b = g << LGE;
+        T e[E];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) e[m] = a[sort_slot<PAD>(b + m)];
+        for (int m = 0; m < E; ++m) e[m] = a[sort_slot<PAD>(b + m)];
 #pragma unroll
-        for (int kk = 2; kk <= 16; kk <<= 1) {
+        for (int kk = 2; kk <= E; kk <<= 1) {
 #pragma unroll
             for (int d = kk >> 1; d >= 1; d >>= 1) {
 #pragma unroll
-                for (int m = 0; m < 16; ++m)
+                for (int m = 0; m < E; ++m)
                     if ((m & d) == 0) {
-                        const bool asc = (kk == 16) ? ((b & 16) == 0) : ((m & kk) == 0);
+                        const bool asc = (kk == E) ? ((b & E) == 0) : ((m & kk) == 0);
                         cswap_dir(e[m], e[m + d], asc);
                     }
             }
         }
 #pragma unroll
-        for (int m = 0; m < 16; ++m) a[sort_slot<PAD>(b + m)] = e[m];
+        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + m)] = e[m];
     }
     __syncthreads();
-    int lgk = 5;
-    for (int k = 32; k <= np2; k <<= 1, ++lgk) {
+    int lgk = LGE + 1;
+    for (int k = 2 * E; k <= np2; k <<= 1, ++lgk) {
         int r = lgk;  // levels still to do in this stage (distances 2^(r-1) .. 1)
-        const int first = (r & 3) ? (r & 3) : 4;  // leading partial pass so that the rest are full 4-level passes
+        const int first = (r % LGE) ? (r % LGE) : LGE;  // leading partial pass, the rest are full LGE-level passes
         if (first == 1)
             bitonic_pass<THREADS, PAD, 1>(a, np2, k, r);
         else if (first == 2)
@@ -252,8 +253,8 @@ __device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2
             bitonic_pass<THREADS, PAD, 4>(a, np2, k, r);
         r -= first;
         while (r > 0) {
-            bitonic_pass<THREADS, PAD, 4>(a, np2, k, r);
-            r -= 4;
+            bitonic_pass<THREADS, PAD, LGE>(a, np2, k, r);
+            r -= LGE;
         }
     }
 }
@@ -370,7 +371,7 @@ __device__ __forceinline__ void order_range(const int32_t* off, int c_lo, int c_
     hi = (c_lo == 0) ? off[64] : off[c_lo - 1];
 }
 
-template <int CAP, int THREADS, int C_LO, int C_HI>
+template <int CAP, int THREADS, int C_LO, int C_HI, int LGE>
 __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int lo, hi;
@@ -382,12 +383,12 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
         uint64_t* keys;
         if (in_lds) {
             keys = (uint64_t*)smem;
-            int np2 = 16;
+            int np2 = 1 << LGE;
             while (np2 < n) np2 <<= 1;
             for (int j = threadIdx.x; j < np2; j += THREADS)
                 keys[sort_slot<true>(j)] = (j < n) ? A.keys[(size_t)base + off + j] : ~0ull;
             __syncthreads();
-            block_bitonic_sort_pow2<THREADS, true>(keys, np2);
+            block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
         } else {
             keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
             block_bitonic_sort<THREADS, false>(keys, n);
@@ -405,6 +406,42 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
             dsti[j] = id;
         }
         __syncthreads();  // LDS is reused by the next item
+    }
+}
+
+// patches with fewer than 64 points: one key per lane, bitonic network over the wave with xor-shuffles
+// (21 compare-exchange steps, no LDS, no barriers); four patches per 256-thread workgroup
+constexpr int kClassWave = 24;  // pw_size_class(64)
+__global__ __launch_bounds__(256) void k_pw_sort_wave(DevParams P, Arena A) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int lo, hi;
+    order_range(A.order_off, 0, kClassWave - 1, lo, hi);
+    for (int w = lo + blockIdx.x * 4 + wave; w < hi; w += gridDim.x * 4) {
+        const int4 item = A.order[w];
+        const int n = item.y, base = item.z, off = item.w;  // n < 64
+        unsigned long long key = (lane < n) ? A.keys[(size_t)base + off + lane] : ~0ull;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j >= 1; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j, 64);
+                const bool take_min = (((lane & k) == 0) == ((lane & j) == 0));
+                const unsigned long long mn = key < other ? key : other;
+                const unsigned long long mx = key < other ? other : key;
+                key = take_min ? mn : mx;
+            }
+        }
+        if (lane < n) {
+            const uint32_t id = (uint32_t)key;
+            const float4 q = A.pts[base + id];
+            Xyz o;
+            o.x = q.x;
+            o.y = q.y;
+            o.z = q.z;
+            A.sorted_xyz[(size_t)base + off + lane] = o;
+            A.sorted_idx[(size_t)base + off + lane] = id;
+        }
     }
 }
 
@@ -1022,7 +1059,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
     }
 }
 
-template <int CAP, int THREADS, int C_LO, int C_HI>
+template <int CAP, int THREADS, int C_LO, int C_HI, int LGE>
 __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOTS = CAP + CAP / 8;
@@ -1043,7 +1080,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     int* vbeg;
     float* ints;
     if (in_lds) {
-        int np2 = 16;
+        int np2 = 1 << LGE;
         while (np2 < m) np2 <<= 1;
         for (int j = threadIdx.x; j < np2; j += THREADS)
             l_keys[sort_slot<true>(j)] = (j < m) ? A.vkeys[(size_t)base + off + j] : ~0ull;
@@ -1051,7 +1088,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         keys = l_keys;
         vbeg = l_vbeg;
         ints = l_int;
-        block_bitonic_sort_pow2<THREADS, true>(keys, np2);
+        block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
     } else {
         keys = A.vkeys + (size_t)base + off;
         vbeg = A.tmp_vox_begin + (size_t)base + off;  // rewritten below with final values
@@ -1419,6 +1456,12 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(const float* __restrict
 #define TH_END(name) \
     if (th) th(tu, name, 0)
 
+#ifndef SCVOD_SORT_LGE
+#define SCVOD_SORT_LGE 4
+#endif
+constexpr int kLGE = SCVOD_SORT_LGE;           // keys per thread = 2^kLGE in the LDS sorts
+constexpr int kTS = (kLGE == 4) ? 1 : 2;      // thread multiplier: 8 keys per thread -> twice the threads
+constexpr int kLGEv = 3, kTSv = 2;             // voxel-bucket sorts measured faster with 8 keys per thread
 constexpr int kPersistCUs = 256;  // MI355X: 256 CUs; list-driven kernels launch a few workgroups per CU
 constexpr int kSortCapS = 1024, kSortThreadsS = 64;
 constexpr int kSortCapM = 4096, kSortThreadsM = 256;
@@ -1454,23 +1497,24 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_order_offsets, dim3(1), dim3(64), 0, st, A);
         hipLaunchKernelGGL(k_pw_order_scatter, dim3((n_all + 255) / 256), dim3(256), 0, st, P, A);
         TH_END("pw_order");
-        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL, kClassL, 63>,
+        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, 63, kLGE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortCapL));
         TH_BEGIN("pw_sort_large");  // largest first: their tail overlaps the smaller tiers' launches
-        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL, kClassL, 63>), dim3(kPersistCUs * 2), dim3(kSortThreadsL),
+        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, 63, kLGE>), dim3(kPersistCUs * 2), dim3(kSortThreadsL * kTS),
                            sort_lds_bytes(kSortCapL), st, P, A);
         TH_END("pw_sort_large");
         TH_BEGIN("pw_sort_mid");
-        hipLaunchKernelGGL((k_pw_sort<4096, 256, kClassM2, kClassL - 1>), dim3(kPersistCUs * 4), dim3(256),
+        hipLaunchKernelGGL((k_pw_sort<4096, 256 * kTS, kClassM2, kClassL - 1, kLGE>), dim3(kPersistCUs * 4), dim3(256 * kTS),
                            sort_lds_bytes(4096), st, P, A);
-        hipLaunchKernelGGL((k_pw_sort<2048, 128, kClassM, kClassM2 - 1>), dim3(kPersistCUs * 8), dim3(128),
+        hipLaunchKernelGGL((k_pw_sort<2048, 128 * kTS, kClassM, kClassM2 - 1, kLGE>), dim3(kPersistCUs * 8), dim3(128 * kTS),
                            sort_lds_bytes(2048), st, P, A);
         TH_END("pw_sort_mid");
         TH_BEGIN("pw_sort_small");
-        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS, kClassXS, kClassM - 1>), dim3(kPersistCUs * 16),
-                           dim3(kSortThreadsS), sort_lds_bytes(kSortCapS), st, P, A);
-        hipLaunchKernelGGL((k_pw_sort<256, 64, 0, kClassXS - 1>), dim3(kPersistCUs * 32), dim3(64), sort_lds_bytes(256), st,
-                           P, A);
+        hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS * kTS, kClassXS, kClassM - 1, kLGE>), dim3(kPersistCUs * 16),
+                           dim3(kSortThreadsS * kTS), sort_lds_bytes(kSortCapS), st, P, A);
+        hipLaunchKernelGGL((k_pw_sort<256, 64, kClassWave, kClassXS - 1, 3>), dim3(kPersistCUs * 32), dim3(64),
+                           sort_lds_bytes(256), st, P, A);
+        hipLaunchKernelGGL(k_pw_sort_wave, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
         TH_END("pw_sort_small");
         TH_BEGIN("pw_fit");
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
@@ -1514,24 +1558,24 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_order_offsets, dim3(1), dim3(64), 0, st, A);
         hipLaunchKernelGGL(k_vx_order_scatter, dim3((nb_all + 255) / 256), dim3(256), 0, st, P, A);
         TH_END("vx_order");
-        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL, kClassL, 63>,
+        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
-        hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256, kClassM2, kClassL - 1>,
+        hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
         TH_BEGIN("vx_bucket_large");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL, kClassL, 63>), dim3(kPersistCUs), dim3(kVoxThreadsL),
+        hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv>), dim3(kPersistCUs), dim3(kVoxThreadsL * kTSv),
                            vox_lds_bytes(kVoxCapL), st, P, A);
         TH_END("vx_bucket_large");
         TH_BEGIN("vx_bucket_mid");
-        hipLaunchKernelGGL((k_vx_bucket<4096, 256, kClassM2, kClassL - 1>), dim3(kPersistCUs * 2), dim3(256),
+        hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>), dim3(kPersistCUs * 2), dim3(256 * kTSv),
                            vox_lds_bytes(4096), st, P, A);
-        hipLaunchKernelGGL((k_vx_bucket<2048, 128, kClassM, kClassM2 - 1>), dim3(kPersistCUs * 4), dim3(128),
+        hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv>), dim3(kPersistCUs * 4), dim3(128 * kTSv),
                            vox_lds_bytes(2048), st, P, A);
         TH_END("vx_bucket_mid");
         TH_BEGIN("vx_bucket_small");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS, kClassXS, kClassM - 1>), dim3(kPersistCUs * 8),
-                           dim3(kVoxThreadsS), vox_lds_bytes(kVoxCapS), st, P, A);
-        hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st,
+        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS * kTSv, kClassXS, kClassM - 1, kLGEv>), dim3(kPersistCUs * 8),
+                           dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS), st, P, A);
+        hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st,
                            P, A);
         TH_END("vx_bucket_small");
         TH_BEGIN("vx_final_offsets");
