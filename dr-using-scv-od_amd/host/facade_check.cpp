@@ -59,13 +59,16 @@ static void dump_state(const std::string& pre, SSC& s) {
 static void toy_segment(SSC& s, Frame& f) {
     f.hash_cloud = s.hash_cloud;
     f.cluster_set.clear();
-    for (auto& kv : f.hash_cloud) {
-        Voxel& v = kv.second;
+    std::vector<int> vkeys;
+    for (auto& kv : f.hash_cloud) vkeys.push_back(kv.first);
+    std::sort(vkeys.begin(), vkeys.end());  // clusters are created in ascending voxel-key order (deterministic)
+    for (int key : vkeys) {
+        Voxel& v = f.hash_cloud[key];
         int name = 5 + (v.range_idx / 6) * 64 + (v.sector_idx / 12);
         v.label = name;
         Cluster& c = f.cluster_set[name];
         c.name = name;
-        c.occupy_voxels.push_back(kv.first);
+        c.occupy_voxels.push_back(key);
         c.occupy_pts.insert(c.occupy_pts.end(), v.ptIdx.begin(), v.ptIdx.end());
     }
     f.max_name = 5 + 64 * 64;
@@ -134,7 +137,13 @@ int main(int argc, char** argv) {
                 st << nme << " " << c.state << " " << c.occupy_voxels.size() << "\n";
             }
         }
-        std::cout << "pair_tracking cars " << c2 << " dynamic " << d2 << " reported " << ssc.dynamic_num_last << "\n";
+        std::cout << "pair_tracking cars " << c2 << " dynamic " << d2 << " reported " << ssc.dynamic_num_last << " next_clusters "
+                  << fb.cluster_set.size() << "\n";
+        std::vector<int> bkeys;
+        for (auto& kv : fb.hash_cloud) bkeys.push_back(kv.first);
+        std::sort(bkeys.begin(), bkeys.end());
+        std::ofstream nl(pre + "_next_labels.txt");
+        for (int k : bkeys) nl << fb.hash_cloud[k].label << "\n";
     } catch (const std::exception& e) {
         std::cerr << "facade_check failed: " << e.what() << "\n";
         return 1;

@@ -46,6 +46,12 @@ int oracle_track_probe(const scvod_params* params, const float* xyzi, const int3
 int oracle_cluster(const scvod_params* params, const scvod_apri* apri, int32_t n, int32_t* pt_cluster,
                    int32_t* max_name);
 
+/* SSC::tracking incl. the host bookkeeping (src/ssc.cpp:1250-1426) on two frames built from apri vectors with a toy
+ * segmentation (oracle/tracking_oracle.cpp); states = {name, state, |occupy_voxels|} per tracked cluster of frame a. */
+int oracle_toy_tracking(const scvod_params* params, const scvod_apri* apri_a, int32_t n_a, const scvod_apri* apri_b, int32_t n_b,
+                        const float pose_a[6], const float pose_b[6], int32_t car, int32_t tree, int32_t* states, int32_t* n_states,
+                        int32_t* next_labels, int32_t* n_next_vox, int32_t* dynamic_num, int32_t* n_next_clusters);
+
 /* brute-force nearest neighbour / radius test (src/evaluate.cpp:79-145 analogue) */
 int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz, int32_t n_query, float radius,
                      int32_t* nn_idx, float* nn_sqdist, uint8_t* within);

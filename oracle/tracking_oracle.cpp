@@ -1,0 +1,248 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing in the product may include, link or call this.
+//
+// Sequential restatement of SSC::tracking (/root/reference/src/ssc.cpp:1250-1426) including the label
+// bookkeeping that mutates the next frame, on std::unordered_map containers like the reference, so the
+// iteration order of cluster_set is the library's own.  Used to pin the host-side bookkeeping of the
+// product's C++ facade (dr-using-scv-od_amd/host/ssc.cpp) end to end: tests build two frames from the
+// oracle's own binning / voxel table plus the toy segmentation below (a stand-in for SSC::segment /
+// recognize, which are out of scope), run this, and compare cluster states and next-frame labels.
+// PARITY UNPINNED against the real binary.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "oracle.h"
+
+namespace {
+
+struct P3 {
+    float x, y, z, intensity;
+};
+struct VoxelT {
+    int range_idx, sector_idx, azimuth_idx;
+    int label = -1;
+    std::vector<int> ptIdx;
+};
+struct ClusterT {
+    int track_id = -1, name = -1, type = -1, state = -1;
+    std::vector<int> occupy_pts, occupy_voxels;
+    std::vector<P3> cloud;
+};
+struct FrameT {
+    int max_name = 0;
+    std::vector<P3> cloud_use;
+    std::unordered_map<int, VoxelT> hash_cloud;
+    std::unordered_map<int, ClusterT> cluster_set;
+};
+
+// same construction order as the facade: voxels inserted in ascending key order
+void build_frame(const scvod_params& P, const scvod_apri* apri, int n, FrameT& f) {
+    std::vector<int32_t> key(n ? n : 1), beg(n + 1), pts(n ? n : 1), idx3(3 * (n ? n : 1));
+    std::vector<float> av(n ? n : 1), cov(n ? n : 1);
+    int32_t nv = 0;
+    oracle_voxelize(&P, apri, n, key.data(), beg.data(), pts.data(), av.data(), cov.data(), idx3.data(), nullptr, &nv);
+    f.cloud_use.resize(n);
+    for (int i = 0; i < n; ++i) f.cloud_use[i] = P3{apri[i].x, apri[i].y, apri[i].z, apri[i].intensity};
+    f.hash_cloud.reserve(nv);
+    for (int v = 0; v < nv; ++v) {
+        VoxelT vx;
+        vx.range_idx = idx3[3 * v];
+        vx.sector_idx = idx3[3 * v + 1];
+        vx.azimuth_idx = idx3[3 * v + 2];
+        vx.ptIdx.assign(pts.begin() + beg[v], pts.begin() + beg[v + 1]);
+        f.hash_cloud.insert(std::make_pair(key[v], vx));
+    }
+}
+
+// toy stand-in for SSC::segment + recognize (identical rule in host/facade_check.cpp)
+void toy_segment(FrameT& f, int car, int tree) {
+    f.cluster_set.clear();
+    std::vector<int> vkeys;
+    for (auto& kv : f.hash_cloud) vkeys.push_back(kv.first);
+    std::sort(vkeys.begin(), vkeys.end());
+    for (int key : vkeys) {
+        VoxelT& v = f.hash_cloud[key];
+        int name = 5 + (v.range_idx / 6) * 64 + (v.sector_idx / 12);
+        v.label = name;
+        ClusterT& c = f.cluster_set[name];
+        c.name = name;
+        c.occupy_voxels.push_back(key);
+        c.occupy_pts.insert(c.occupy_pts.end(), v.ptIdx.begin(), v.ptIdx.end());
+    }
+    f.max_name = 5 + 64 * 64;
+    for (auto& kv : f.cluster_set) {
+        ClusterT& c = kv.second;
+        std::sort(c.occupy_voxels.begin(), c.occupy_voxels.end());
+        std::sort(c.occupy_pts.begin(), c.occupy_pts.end());
+        for (int p : c.occupy_pts) c.cloud.push_back(f.cloud_use[p]);
+        c.type = (c.occupy_pts.size() < 400) ? car : tree;
+    }
+}
+
+template <typename T>
+void sampleVec(std::vector<T>& v) {  // utility.h:452-456
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+template <typename T>
+void reduceVec(std::vector<T>& central, const std::vector<T>& reduce) {  // utility.h:445-450
+    for (auto it = reduce.begin(); it != reduce.end(); it++) central.erase(std::remove(central.begin(), central.end(), *it), central.end());
+}
+
+float rad2deg_f(float r) { return (float)r * 180.0 / M_PI; }
+float pointDistance2d(const P3& p) { return (float)sqrt(p.x * p.x + p.y * p.y); }
+float getPolarAngle(const P3& p) {
+    if (p.x == 0 && p.y == 0) return 0.f;
+    if (p.y >= 0) return rad2deg_f((float)atan2f(p.y, p.x));
+    double s = (float)atan2f(p.y, p.x) + 2 * M_PI;
+    return (float)((float)s * 180.0 / M_PI);
+}
+float getAzimuth(const P3& p) { return rad2deg_f((float)atan2f(p.z, (float)pointDistance2d(p))); }
+
+int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, const float pose_pre[6], const float pose_next[6], int car,
+             int& name) {
+    int32_t R, S, A, bins;
+    oracle_grid_dims(&P, &R, &S, &A, &bins);
+    float T[12];
+    oracle_pose_delta(pose_pre, pose_next, T);
+    int dynamic_num = 0;
+    for (auto& c : frame_pre_.cluster_set) {
+        if (c.second.type != car) continue;
+        if (c.second.track_id == -1) {
+            c.second.track_id = name;
+            name++;
+        }
+        std::vector<P3> cluster(c.second.cloud.size());
+        for (size_t i = 0; i < cluster.size(); ++i) {  // transformCloud, utility.h:400-405
+            const P3& in = c.second.cloud[i];
+            cluster[i].x = T[0] * in.x + T[1] * in.y + T[2] * in.z + T[3];
+            cluster[i].y = T[4] * in.x + T[5] * in.y + T[6] * in.z + T[7];
+            cluster[i].z = T[8] * in.x + T[9] * in.y + T[10] * in.z + T[11];
+            cluster[i].intensity = in.intensity;
+        }
+        std::unordered_map<int, std::vector<int>> remap_name;
+        for (size_t k = 0; k < cluster.size(); k++) {
+            P3 pt = cluster[k];
+            float dis = pointDistance2d(pt);
+            float angle = getPolarAngle(pt);
+            float azimuth = getAzimuth(pt);
+            int range_idx = std::ceil((dis - P.min_dis) / P.range_res) - 1;
+            int sector_idx = std::ceil((angle - P.min_angle) / P.sector_res) - 1;
+            int azimuth_idx = std::ceil((azimuth - P.min_azimuth) / P.azimuth_res) - 1;
+            int voxel_idx = azimuth_idx * R * S + range_idx * S + sector_idx;
+            auto it_find = frame_next_.hash_cloud.find(voxel_idx);
+            if (it_find != frame_next_.hash_cloud.end() && it_find->second.label != -1) {
+                auto l_find = remap_name.find(it_find->second.label);
+                if (l_find == remap_name.end()) {
+                    std::vector<int> vec;
+                    vec.emplace_back(it_find->first);
+                    remap_name.insert(std::make_pair(it_find->second.label, vec));
+                } else {
+                    l_find->second.emplace_back(it_find->first);
+                }
+            }
+        }
+        for (auto& re : remap_name) sampleVec(re.second);
+        if (remap_name.size() == 0) {
+            c.second.state = 1;
+            dynamic_num++;
+        } else if (remap_name.size() == 1) {
+            auto it = remap_name.begin();
+            float ratio = (float)it->second.size() / (float)frame_next_.cluster_set[it->first].occupy_voxels.size();
+            if (ratio < P.occupancy) {
+                if (frame_next_.cluster_set[it->first].type == car) {
+                    c.second.state = 1;
+                    dynamic_num++;
+                } else {
+                    c.second.state = 0;
+                    c.second.type = frame_next_.cluster_set[it->first].type;
+                    ClusterT cluster_new;
+                    cluster_new.track_id = c.second.track_id;
+                    cluster_new.name = frame_next_.max_name++;
+                    cluster_new.type = frame_next_.cluster_set[it->first].type;
+                    cluster_new.occupy_voxels = it->second;
+                    reduceVec(frame_next_.cluster_set[it->first].occupy_voxels, cluster_new.occupy_voxels);
+                    for (auto& v : it->second) {
+                        frame_next_.hash_cloud[v].label = cluster_new.name;
+                        cluster_new.occupy_pts.insert(cluster_new.occupy_pts.end(), frame_next_.hash_cloud[v].ptIdx.begin(),
+                                                      frame_next_.hash_cloud[v].ptIdx.end());
+                    }
+                    for (int p : cluster_new.occupy_pts) cluster_new.cloud.push_back(frame_next_.cloud_use[p]);
+                    reduceVec(frame_next_.cluster_set[it->first].occupy_pts, cluster_new.occupy_pts);
+                    frame_next_.cluster_set.insert(std::make_pair(cluster_new.name, cluster_new));
+                }
+            } else {
+                if (frame_next_.cluster_set[it->first].type == car) {
+                    c.second.state = 0;
+                    frame_next_.cluster_set[it->first].track_id = c.second.track_id;
+                    auto& dst = frame_next_.cluster_set[it->first].cloud;
+                    dst.insert(dst.end(), cluster.begin(), cluster.end());
+                }
+            }
+        } else {
+            c.second.state = 0;
+            ClusterT cluster_new;
+            cluster_new.track_id = c.second.track_id;
+            cluster_new.name = frame_next_.max_name++;
+            cluster_new.type = car;
+            for (auto& re : remap_name) {
+                if (frame_next_.cluster_set[re.first].type == car &&
+                    ((float)re.second.size() / (float)frame_next_.cluster_set[re.first].occupy_voxels.size()) >= P.occupancy) {
+                    auto& src = frame_next_.cluster_set[re.first];
+                    cluster_new.occupy_pts.insert(cluster_new.occupy_pts.end(), src.occupy_pts.begin(), src.occupy_pts.end());
+                    cluster_new.occupy_voxels.insert(cluster_new.occupy_voxels.end(), src.occupy_voxels.begin(), src.occupy_voxels.end());
+                    frame_next_.cluster_set.erase(re.first);
+                }
+            }
+            for (int p : cluster_new.occupy_pts) cluster_new.cloud.push_back(frame_next_.cloud_use[p]);
+            for (auto& v : cluster_new.occupy_voxels) frame_next_.hash_cloud[v].label = cluster_new.name;
+            frame_next_.cluster_set.insert(std::make_pair(cluster_new.name, cluster_new));
+        }
+    }
+    return dynamic_num;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Builds frames a and b from their apri vectors (toy segmentation), runs tracking(a, b) and reports:
+//   states: for every cluster of frame a with state != -1, sorted by name: {name, state, |occupy_voxels|}
+//   next_labels: label of every voxel of frame b in ascending key order, after the call
+int oracle_toy_tracking(const scvod_params* params, const scvod_apri* apri_a, int32_t n_a, const scvod_apri* apri_b, int32_t n_b,
+                        const float pose_a[6], const float pose_b[6], int32_t car, int32_t tree, int32_t* states, int32_t* n_states,
+                        int32_t* next_labels, int32_t* n_next_vox, int32_t* dynamic_num, int32_t* n_next_clusters) {
+    FrameT fa, fb;
+    build_frame(*params, apri_a, n_a, fa);
+    build_frame(*params, apri_b, n_b, fb);
+    toy_segment(fa, car, tree);
+    toy_segment(fb, car, tree);
+    int name = 0;
+    int dyn = tracking(*params, fa, fb, pose_a, pose_b, car, name);
+    std::vector<int> names;
+    for (auto& kv : fa.cluster_set) names.push_back(kv.first);
+    std::sort(names.begin(), names.end());
+    int k = 0;
+    for (int nm : names) {
+        ClusterT& c = fa.cluster_set[nm];
+        if (c.state != -1) {
+            states[3 * k] = nm;
+            states[3 * k + 1] = c.state;
+            states[3 * k + 2] = (int)c.occupy_voxels.size();
+            ++k;
+        }
+    }
+    *n_states = k;
+    std::vector<int> keys;
+    for (auto& kv : fb.hash_cloud) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    for (size_t v = 0; v < keys.size(); ++v) next_labels[v] = fb.hash_cloud[keys[v]].label;
+    *n_next_vox = (int)keys.size();
+    *dynamic_num = dyn;
+    *n_next_clusters = (int)fb.cluster_set.size();
+    return 0;
+}
+
+}  // extern "C"

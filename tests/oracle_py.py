@@ -18,7 +18,7 @@ def load():
     if _lib is not None:
         return Oracle(_lib)
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("patchwork_oracle.cpp", "ssc_oracle.cpp", "oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("patchwork_oracle.cpp", "ssc_oracle.cpp", "tracking_oracle.cpp", "oracle.h")]
     if (not os.path.exists(so)) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     _lib = C.CDLL(so)
@@ -107,6 +107,18 @@ class Oracle:
         self.lib.oracle_track_probe(C.byref(params), _p(a), _p(o), o.shape[0] - 1, _p(t), _p(k), _p(l), k.shape[0],
                                     _p(hit), _p(uq), _p(ub))
         return hit[:n_pts], uq[:ub[-1]], ub
+
+    def toy_tracking(self, params, apri_a, apri_b, pose_a, pose_b, car=2, tree=1):
+        a = np.ascontiguousarray(apri_a)
+        b = np.ascontiguousarray(apri_b)
+        pa = np.ascontiguousarray(pose_a, np.float32)
+        pb = np.ascontiguousarray(pose_b, np.float32)
+        states = np.zeros((max(len(a), 1), 3), np.int32)
+        labels = np.zeros(max(len(b), 1), np.int32)
+        ns, nv, dyn, nc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.oracle_toy_tracking(C.byref(params), _p(a), len(a), _p(b), len(b), _p(pa), _p(pb), car, tree, _p(states),
+                                     C.byref(ns), _p(labels), C.byref(nv), C.byref(dyn), C.byref(nc))
+        return states[:ns.value], labels[:nv.value], dyn.value, nc.value
 
     def cluster(self, params, apri):
         a = np.ascontiguousarray(apri)

@@ -99,6 +99,15 @@ def test_facade_members_match_oracle(scvod, oracle, tmp_path):
     assert int(t[1]) > 0 and int(t[1]) == int(t[3]) and int(t[5]) == 0
     t = out["pair_tracking"].split()
     assert int(t[1]) > 0 and int(t[3]) == int(t[5])
+    # ... and the full SSC::tracking bookkeeping (states, split / fuse relabelling of the next frame) equals
+    # the oracle's sequential restatement of ssc.cpp:1250-1426 on the same two frames
+    apri = [np.fromfile(f"{pre}_{tag}_apri.bin", scvod.APRI_DTYPE) for tag in ("a", "b")]
+    st, labels, dyn, ncl = oracle.toy_tracking(P, apri[0], apri[1], [0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0])
+    got = np.loadtxt(f"{pre}_states.txt", dtype=np.int32).reshape(-1, 3)
+    assert np.array_equal(got, st)
+    assert int(t[5]) == dyn and int(t[7]) == ncl
+    assert np.array_equal(np.loadtxt(f"{pre}_next_labels.txt", dtype=np.int32), labels)
+    assert (st[:, 1] == 1).any() and (st[:, 1] == 0).any()      # both outcomes occur
 
 
 def test_voxelize_entry_point(scvod, oracle):
