@@ -177,25 +177,35 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
 // closed under t consecutive levels, sorts/merges them in registers and writes them back.  Runs of 16
 // are sorted entirely in registers first.  For np2 = 2048 this is 19 LDS passes instead of the 66 of a
 // level-per-pass network; no bounds predicates anywhere.
-template <typename T>
-__device__ __forceinline__ void cswap_dir(T& x, T& y, bool asc) {
-    const bool sw = asc ? (y < x) : (x < y);
-    const T nx = sw ? y : x;
-    const T ny = sw ? x : y;
-    x = nx;
-    y = ny;
+// ascending compare-exchange of unique unsigned keys; the borrow of x - y is the x < y flag (two full-rate
+// 32-bit VALU ops instead of a 64-bit compare)
+__device__ __forceinline__ void cswap_asc(unsigned long long& x, unsigned long long& y) {
+    unsigned long long d;
+    const bool lt = __builtin_usubll_overflow(x, y, &d);
+    const unsigned long long lo = lt ? x : y;
+    const unsigned long long hi = lt ? y : x;
+    x = lo;
+    y = hi;
+}
+__device__ __forceinline__ void cswap_asc(uint32_t& x, uint32_t& y) {
+    const uint32_t lo = x < y ? x : y;
+    const uint32_t hi = x < y ? y : x;
+    x = lo;
+    y = hi;
 }
 
-template <int LT, typename T>  // butterfly levels with local distances 2^(LT-1) .. 1 on 2^LT registers
-__device__ __forceinline__ void reg_merge(T (&e)[1 << LT], bool asc) {
+template <int LT, typename T>  // ascending butterfly levels with local distances 2^(LT-1) .. 1 on 2^LT registers
+__device__ __forceinline__ void reg_merge(T (&e)[1 << LT]) {
 #pragma unroll
     for (int d = (1 << LT) >> 1; d >= 1; d >>= 1) {
 #pragma unroll
         for (int m = 0; m < (1 << LT); ++m)
-            if ((m & d) == 0) cswap_dir(e[m], e[m + d], asc);
+            if ((m & d) == 0) cswap_asc(e[m], e[m + d]);
     }
 }
 
+// A descending merge of a group is the ascending merge of the group read in reverse order, so the direction
+// of a group only changes WHERE its registers come from / go to (m ^ rev), never the compare-exchange code.
 template <int THREADS, bool PAD, int LT, typename T>
 __device__ __forceinline__ void bitonic_pass(T* a, int np2, int k, int r) {
     // levels with distances 2^(r-1) .. 2^(r-LT) of stage k
@@ -203,13 +213,13 @@ __device__ __forceinline__ void bitonic_pass(T* a, int np2, int k, int r) {
     const int jl = 1 << (r - LT);
     for (int t = threadIdx.x; t < (np2 >> LT); t += THREADS) {
         const int b = ((t >> (r - LT)) << r) | (t & (jl - 1));
-        const bool asc = (b & k) == 0;
+        const int rev = ((b & k) == 0) ? 0 : (E - 1);
         T e[E];
 #pragma unroll
-        for (int m = 0; m < E; ++m) e[m] = a[sort_slot<PAD>(b + m * jl)];
-        reg_merge<LT>(e, asc);
+        for (int m = 0; m < E; ++m) e[m] = a[sort_slot<PAD>(b + (m ^ rev) * jl)];
+        reg_merge<LT>(e);
 #pragma unroll
-        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + m * jl)] = e[m];
+        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + (m ^ rev) * jl)] = e[m];
     }
     __syncthreads();
 }
@@ -217,7 +227,8 @@ __device__ __forceinline__ void bitonic_pass(T* a, int np2, int k, int r) {
 template <int THREADS, bool PAD, int LGE, typename T>
 __device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2 >= 2^LGE, power of two
     constexpr int E = 1 << LGE;
-    // stages k = 2 .. E inside registers: runs of E, run g ascending iff bit E of its base is clear
+    // stages k = 2 .. E inside registers: runs of E; directions inside the run are compile-time, the direction
+    // of the whole run (bit E of its base) is applied by storing it reversed
     for (int g = threadIdx.x; g < (np2 >> LGE); g += THREADS) {
         const int b = g << LGE;
         T e[E];
@@ -230,13 +241,16 @@ __device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2
 #pragma unroll
                 for (int m = 0; m < E; ++m)
                     if ((m & d) == 0) {
-                        const bool asc = (kk == E) ? ((b & E) == 0) : ((m & kk) == 0);
-                        cswap_dir(e[m], e[m + d], asc);
+                        if (kk == E || (m & kk) == 0)
+                            cswap_asc(e[m], e[m + d]);
+                        else
+                            cswap_asc(e[m + d], e[m]);
                     }
             }
         }
+        const int rev = ((b & E) == 0) ? 0 : (E - 1);
 #pragma unroll
-        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + m)] = e[m];
+        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + (m ^ rev))] = e[m];
     }
     __syncthreads();
     int lgk = LGE + 1;
@@ -380,9 +394,9 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
         const int4 item = A.order[w];
         const int n = item.y, base = item.z, off = item.w;
         const bool in_lds = (n <= CAP);
-        uint64_t* keys;
+        unsigned long long* keys;
         if (in_lds) {
-            keys = (uint64_t*)smem;
+            keys = (unsigned long long*)smem;
             int np2 = 1 << LGE;
             while (np2 < n) np2 <<= 1;
             for (int j = threadIdx.x; j < np2; j += THREADS)
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
             __syncthreads();
             block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
         } else {
-            keys = A.keys + (size_t)base + off;  // oversize patch: sort in place in global memory
+            keys = (unsigned long long*)(A.keys + (size_t)base + off);  // oversize patch: sort in place in global memory
             block_bitonic_sort<THREADS, false>(keys, n);
         }
         Xyz* dst = A.sorted_xyz + (size_t)base + off;
@@ -1063,7 +1077,7 @@ template <int CAP, int THREADS, int C_LO, int C_HI, int LGE>
 __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOTS = CAP + CAP / 8;
-    uint64_t* l_keys = (uint64_t*)smem;                       // padded layout
+    unsigned long long* l_keys = (unsigned long long*)smem;   // padded layout
     int* l_vbeg = (int*)(smem + (size_t)SLOTS * 8);           // [CAP]
     float* l_int = (float*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 4);  // [CAP] intensity in sorted order
     int* wsum = (int*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 8);
@@ -1076,7 +1090,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     const int m = item.y;
     const int base = item.z, off = item.w;
     const bool in_lds = (m <= CAP);
-    uint64_t* keys;
+    unsigned long long* keys;
     int* vbeg;
     float* ints;
     if (in_lds) {
@@ -1090,7 +1104,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         ints = l_int;
         block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
     } else {
-        keys = A.vkeys + (size_t)base + off;
+        keys = (unsigned long long*)(A.vkeys + (size_t)base + off);
         vbeg = A.tmp_vox_begin + (size_t)base + off;  // rewritten below with final values
         ints = A.tmp_vox_av + (size_t)base + off;     // m >= nv entries: used as staging, rewritten below
         block_bitonic_sort<THREADS, false>(keys, m);
