@@ -62,7 +62,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), pytho
                "raw values are KB per dispatch, bytes = KB*1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide "
                "coalesced read; uncalibrated for gathers, so read-side numbers of gather-heavy kernels are upper bounds)",
        "scans_per_launch": scans, "kernels": {}}
-by, total = collections.defaultdict(float), 0.0
+by, total, extra = collections.defaultdict(float), 0.0, 0.0
 for k in F:
     f = sum(F[k]) / len(F[k])
     w = sum(W.get(k, [0])) / max(1, len(W.get(k, [0])))
@@ -70,8 +70,11 @@ for k in F:
     out["kernels"][k] = {"launches": len(F[k]), "fetch_KB_raw": f, "write_KB_raw": w, "hbm_bytes_per_launch_corrected": b,
                          "hbm_bytes_per_scan": b / scans}
     by[label(k)] += b / scans
-    total += b / scans
-out["by_bench_label"], out["total_hbm_bytes_per_scan"] = dict(by), total
+    if k.startswith("k_cc_"):
+        extra += b / scans  # clustering = "next" row, measured by bench.py only as an extra
+    else:
+        total += b / scans
+out["by_bench_label"], out["total_hbm_bytes_per_scan"], out["extras_hbm_bytes_per_scan"] = dict(by), total, extra
 json.dump(out, open(os.path.join(here, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 d = json.load(open(os.path.join(src, "bench_full.json")))
 print("scans/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "roofline", {k: d["roofline"][k] for k in ("kernel", "frac", "path_GBps")})
