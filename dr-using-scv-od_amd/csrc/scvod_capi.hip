@@ -53,6 +53,7 @@ struct scvod_ctx {
     std::vector<int32_t> h_counts;
     bool counts_valid = false;
     bool clusters_valid = false;
+    bool types_valid = false;
     hipStream_t last_stream = nullptr;
     int32_t last_track_clusters = 0;
     // host staging for scvod_scan_result
@@ -158,6 +159,9 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cc_touched = k.take<uint8_t>(N);
     A.pt_voxel = k.take<int32_t>(N);
     A.pt_cluster = k.take<int32_t>(N);
+    A.cl_bbox = k.take<uint32_t>(6 * N);
+    A.cl_count = k.take<int32_t>(N);
+    A.pt_type = k.take<uint8_t>(N);
     c->t_hit = k.take<int32_t>(N);
     c->t_work = k.take<uint64_t>(N);
     c->t_uniq = k.take<int32_t>(N);
@@ -221,6 +225,10 @@ void build_dev_params(scvod_ctx* c) {
     z.num_min_pts = w.num_min_pts;
     z.num_rings_of_interest = w.num_rings_of_interest;
     D.n_patches = base;
+    D.max_z = p.max_z;
+    D.min_z = p.min_z;
+    D.car_square = p.car_square;
+    D.to_be_class = p.toBeClass;
     // voxel buckets: keys of filtered points lie in [-(R*S+S+1), bin_num)
     D.key_off = (int64_t)b.range_num * b.sector_num + b.sector_num + 1;
     int64_t range = (int64_t)b.bin_num + D.key_off + 1;
@@ -288,6 +296,7 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->batch_valid = false;
     c->counts_valid = false;
     c->clusters_valid = false;
+    c->types_valid = false;
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     if (mx == 0) {
@@ -411,6 +420,10 @@ void scvod_params_default(scvod_params* p) {
     p->sector_res = 1.2f;
     p->azimuth_res = 2.0f;
     p->occupancy = 0.6f;
+    p->max_z = 1.0f;       // utility.h:294
+    p->min_z = -1.0f;      // utility.h:295
+    p->car_square = 2.0f;  // utility.h:298
+    p->toBeClass = 1;      // utility.h:306
 }
 
 void scvod_pw_params_default(scvod_pw_params* p) {
@@ -675,6 +688,36 @@ int scvod_batch_fetch_clusters(scvod_ctx* c, int32_t s, int32_t* h_pt_cluster, i
     if (n > cap) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d)", cap, n);
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     if (n) HIPCHK(c, hipMemcpy(h_pt_cluster, c->A.pt_cluster + c->h_scan_off[s], sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int scvod_batch_cluster_types(scvod_ctx* c, void* stream, int32_t sync) {
+    if (!c) return SCVOD_ERR_INVALID;
+    if (!c->clusters_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_cluster_types needs scvod_batch_cluster first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->last_stream = st;
+    c->tim_used = 0;
+    launch_cluster_types(c->dev, c->A, st, timer_hook, c);
+    HIPCHK(c, hipGetLastError());
+    c->types_valid = true;
+    if (sync) HIPCHK(c, hipStreamSynchronize(st));
+    return SCVOD_OK;
+}
+
+int scvod_batch_fetch_cluster_types(scvod_ctx* c, int32_t s, int32_t car_label, int32_t other_label, int32_t* h_type,
+                                    int32_t cap) {
+    if (!c || !h_type) return SCVOD_ERR_INVALID;
+    if (!c->types_valid) return fail(c, SCVOD_ERR_STATE, "no cluster types computed for the last batch");
+    int rc = ensure_counts(c);
+    if (rc) return rc;
+    if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
+    const int32_t n = c->h_counts[(size_t)s * 8 + 4];
+    if (n > cap) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d)", cap, n);
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    std::vector<uint8_t> t(n ? n : 1);
+    if (n) HIPCHK(c, hipMemcpy(t.data(), c->A.pt_type + c->h_scan_off[s], (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) h_type[i] = t[i] == 0 ? -1 : (t[i] == 2 ? car_label : other_label);
     return n;
 }
 

@@ -25,6 +25,8 @@ struct DevParams {
     int32_t vb_shift;    // bucket = clamp((voxel_idx + key_off) >> vb_shift, 0, n_buckets-1)
     int32_t n_buckets;
     int32_t n_patches;
+    float max_z, min_z, car_square;  // recognise thresholds (utility.h:294-298)
+    int32_t to_be_class;             // utility.h:306
 };
 
 // per-patch record produced by the patch kernel, consumed by the emission kernels
@@ -98,6 +100,9 @@ struct Arena {
     uint8_t* cc_touched;      // [N] per voxel slot: appeared in a neighbourhood
     int32_t* pt_voxel;        // [N] voxel slot of every apri point
     int32_t* pt_cluster;      // [N] canonical cluster name = smallest apri index of the component
+    uint32_t* cl_bbox;        // [6N] per cluster root: min xyz / max xyz in order-preserving uint encoding
+    int32_t* cl_count;        // [N] per cluster root: number of points
+    uint8_t* pt_type;         // [N] per apri point: 0 erased, 1 other, 2 car
 };
 
 struct TrackJob {          // scan-vs-next-scan probe
@@ -128,6 +133,7 @@ typedef void (*TimerHook)(void* user, const char* name, int begin);
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu);
 void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
+void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,

@@ -1322,6 +1322,68 @@ __global__ __launch_bounds__(256) void k_cc_flatten(Arena A) {
     }
 }
 
+// ---- bounding boxes + type of every cluster (refineClusterByBoundingBox ssc.cpp:437-467, recognize ssc.cpp:849-872)
+__device__ __forceinline__ uint32_t f2ord(float f) { return float_sort_key(f); }
+__device__ __forceinline__ float ord2f(uint32_t u) { return u2f((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+__global__ __launch_bounds__(256) void k_cc_bbox_init(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + i);
+        bb[0] = bb[1] = bb[2] = 0xffffffffu;  // running minima (order-preserving encoding)
+        bb[3] = bb[4] = bb[5] = 0u;           // running maxima
+        A.cl_count[(size_t)base + i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_bbox(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const scvod_apri& a = A.apri[(size_t)base + i];
+        const int r = A.pt_cluster[(size_t)base + i];
+        uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + r);
+        atomicMin(&bb[0], f2ord(a.x));
+        atomicMin(&bb[1], f2ord(a.y));
+        atomicMin(&bb[2], f2ord(a.z));
+        atomicMax(&bb[3], f2ord(a.x));
+        atomicMax(&bb[4], f2ord(a.y));
+        atomicMax(&bb[5], f2ord(a.z));
+        atomicAdd(&A.cl_count[(size_t)base + r], 1);
+    }
+}
+
+// per point: 0 erased, 1 other, 2 car (labels are mapped by the fetch call)
+__global__ __launch_bounds__(256) void k_cc_type(DevParams P, Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = A.pt_cluster[(size_t)base + i];
+        const uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + r);
+        const float mnx = ord2f(bb[0]), mny = ord2f(bb[1]), mnz = ord2f(bb[2]);
+        const float mxx = ord2f(bb[3]), mxy = ord2f(bb[4]), mxz = ord2f(bb[5]);
+        const int cnt = A.cl_count[(size_t)base + r];
+        const float diff_zf = mxz - mnz;
+        uint8_t t;
+        if (mnz > 0.f || cnt < P.to_be_class || diff_zf < 0.2f) {
+            t = 0;
+        } else {
+            const double square = (double)(mxx - mnx) * (double)(mxy - mny);
+            if (square > (double)P.car_square)
+                t = 1;
+            else if ((double)mnz < (double)P.min_z && square < (double)P.car_square && (double)mxz < (double)P.max_z)
+                t = 2;
+            else
+                t = 1;
+        }
+        A.pt_type[(size_t)base + i] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Scan-vs-next-scan differencing, bulk part of SSC::tracking (ssc.cpp:1274-1321)
 // ------------------------------------------------------------------------------------------
@@ -1617,6 +1679,19 @@ void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHoo
     TH_BEGIN("cc_flatten");
     hipLaunchKernelGGL(k_cc_flatten, g, dim3(256), 0, st, A);
     TH_END("cc_flatten");
+}
+
+void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
+    const int B = A.n_scans;
+    if (B <= 0 || A.max_scan_pts <= 0) return;
+    dim3 g((A.max_scan_pts + 2047) / 2048, B);
+    TH_BEGIN("cc_bbox");
+    hipLaunchKernelGGL(k_cc_bbox_init, g, dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_cc_bbox, g, dim3(256), 0, st, A);
+    TH_END("cc_bbox");
+    TH_BEGIN("cc_type");
+    hipLaunchKernelGGL(k_cc_type, g, dim3(256), 0, st, P, A);
+    TH_END("cc_type");
 }
 
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,

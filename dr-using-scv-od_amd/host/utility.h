@@ -124,6 +124,10 @@ class Utility {
         p.sector_res = sector_res;
         p.azimuth_res = azimuth_res;
         p.occupancy = occupancy;
+        p.max_z = max_z;
+        p.min_z = min_z;
+        p.car_square = car_square;
+        p.toBeClass = toBeClass;
         return p;
     }
 };

@@ -19,7 +19,8 @@ MAX_PATCHES = 1024
 class Params(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "sensor_height", "min_dis", "max_dis", "min_angle", "max_angle", "min_azimuth", "max_azimuth",
-        "range_res", "sector_res", "azimuth_res", "occupancy")] + [("reserved", C.c_int32 * 5)]
+        "range_res", "sector_res", "azimuth_res", "occupancy", "max_z", "min_z", "car_square")] + \
+               [("toBeClass", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PwParams(C.Structure):
@@ -50,20 +51,21 @@ class ScanResult(C.Structure):
 YAML_KEYS = {"sensor_height_": "sensor_height", "min_dis_": "min_dis", "max_dis_": "max_dis", "min_angle_": "min_angle",
              "max_angle_": "max_angle", "min_azimuth_": "min_azimuth", "max_azimuth_": "max_azimuth",
              "range_res_": "range_res", "sector_res_": "sector_res", "azimuth_res_": "azimuth_res",
-             "occupancy_": "occupancy"}
+             "occupancy_": "occupancy", "max_z_": "max_z", "min_z_": "min_z", "car_square_": "car_square",
+             "toBeClass_": "toBeClass"}
 
 # values of the two YAML files shipped by the reference (config/semantickitti.yaml:24-55, config/parkinglot.yaml:23-48)
 PRESETS = {
     "semantickitti": dict(sensor_height=1.73, min_dis=1.5, max_dis=30.0, min_angle=0.0, max_angle=360.0,
                           min_azimuth=-40.0, max_azimuth=80.0, range_res=0.4, sector_res=1.2, azimuth_res=2.0,
-                          occupancy=0.4),
+                          occupancy=0.4, max_z=0.8, min_z=-1.2, car_square=30.0, toBeClass=10),
     "parkinglot": dict(sensor_height=1.83, min_dis=0.8, max_dis=40.0, min_angle=0.0, max_angle=360.0,
                        min_azimuth=-30.0, max_azimuth=60.0, range_res=0.4, sector_res=1.2, azimuth_res=2.0,
-                       occupancy=0.8),
+                       occupancy=0.8, max_z=1.0, min_z=-1.0, car_square=2.0, toBeClass=6),
     # BASELINE.json configs[4]: OS1-128 stream with a 2x finer voxel grid
     "os128_fine": dict(sensor_height=1.73, min_dis=1.5, max_dis=30.0, min_angle=0.0, max_angle=360.0,
                        min_azimuth=-40.0, max_azimuth=80.0, range_res=0.2, sector_res=0.6, azimuth_res=1.0,
-                       occupancy=0.4),
+                       occupancy=0.4, max_z=0.8, min_z=-1.2, car_square=30.0, toBeClass=10),
 }
 
 _lib = None
@@ -110,6 +112,8 @@ def load_lib():
         "scvod_batch_cluster": (C.c_int, [vp, vp, i32]),
         "scvod_batch_fetch_clusters": (C.c_int, [vp, i32, vp, i32]),
         "scvod_cluster": (C.c_int, [vp, vp, i32, vp]),
+        "scvod_batch_cluster_types": (C.c_int, [vp, vp, i32]),
+        "scvod_batch_fetch_cluster_types": (C.c_int, [vp, i32, i32, i32, vp, i32]),
         "scvod_batch_track": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, i32]),
         "scvod_batch_track_counts": (C.c_int, [vp, vp, i32]),
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
@@ -128,6 +132,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_destroy", "scvod_last_error", "scvod_arena_bytes", "scvod_process_scan", "scvod_patchwork",
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
+                    "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
                     "scvod_batch_track", "scvod_batch_track_counts",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search"]
 
@@ -151,7 +156,7 @@ def params_from_yaml(path):
     p = make_params()
     for k, v in (doc.get("ssc") or {}).items():
         if k in YAML_KEYS:
-            setattr(p, YAML_KEYS[k], float(v))
+            setattr(p, YAML_KEYS[k], int(v) if YAML_KEYS[k] == "toBeClass" else float(v))
     return p
 
 
@@ -299,6 +304,16 @@ class Ctx:
     def batch_fetch_clusters(self, s, cap):
         out = np.zeros(max(cap, 1), np.int32)
         n = self.lib.scvod_batch_fetch_clusters(self.h, int(s), out.ctypes.data_as(C.c_void_p), int(cap))
+        if n < 0:
+            self._chk(n)
+        return out[:n]
+
+    def batch_cluster_types(self, stream=None, sync=True):
+        self._chk(self.lib.scvod_batch_cluster_types(self.h, C.c_void_p(stream or 0), int(sync)))
+
+    def batch_fetch_cluster_types(self, s, cap, car_label=2, other_label=1):
+        out = np.zeros(max(cap, 1), np.int32)
+        n = self.lib.scvod_batch_fetch_cluster_types(self.h, int(s), car_label, other_label, out.ctypes.data_as(C.c_void_p), int(cap))
         if n < 0:
             self._chk(n)
         return out[:n]

@@ -62,7 +62,13 @@ typedef struct scvod_params {
     float sector_res;    /* 1.2  */
     float azimuth_res;   /* 2.0  */
     float occupancy;     /* 0.6  */
-    int32_t reserved[5];
+    /* keys of the bounding-box refine / recognise step (ssc.cpp:437-467, 849-872), used only by
+     * scvod_batch_cluster_types */
+    float max_z;         /* 1.0  */
+    float min_z;         /* -1.0 */
+    float car_square;    /* 2.0  */
+    int32_t toBeClass;   /* 1    */
+    int32_t reserved;
 } scvod_params;
 
 /* Patchwork constants.  Hard-coded in the reference (patchwork.h:48-51, :115-129);
@@ -236,6 +242,15 @@ int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
 /* copies the cluster name of every apri point of scan s into h_pt_cluster[cap]; returns the count (>= 0)
  * or a negative status */
 int scvod_batch_fetch_clusters(scvod_ctx* ctx, int32_t s, int32_t* h_pt_cluster, int32_t cap);
+/* Bounding-box refine + the bounding-box part of recognize for the clusters of scvod_batch_cluster
+ * (SSC::refineClusterByBoundingBox ssc.cpp:437-467, SSC::recognize ssc.cpp:849-872):
+ * per apri point of scan s, h_type[i] = -1 when its cluster is erased (min z > 0, fewer than toBeClass
+ * points, z extent < 0.2 m), `car_label` when bbox area <= car_square && min z < min_z && max z < max_z,
+ * otherwise `other_label` (the reference separates building / tree with PCL region growing, which stays
+ * on the host).  No intensity merge (ssc.cpp:571-635) is applied.  Returns the count or a negative status. */
+int scvod_batch_cluster_types(scvod_ctx* ctx, void* stream, int32_t sync);
+int scvod_batch_fetch_cluster_types(scvod_ctx* ctx, int32_t s, int32_t car_label, int32_t other_label, int32_t* h_type,
+                                    int32_t cap);
 /* one-shot host version on an apri_vec the caller holds (voxelises it first) */
 int scvod_cluster(scvod_ctx* ctx, const scvod_apri* h_apri, int32_t n, int32_t* h_pt_cluster);
 

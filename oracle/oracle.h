@@ -46,6 +46,10 @@ int oracle_track_probe(const scvod_params* params, const float* xyzi, const int3
 int oracle_cluster(const scvod_params* params, const scvod_apri* apri, int32_t n, int32_t* pt_cluster,
                    int32_t* max_name);
 
+/* refineClusterByBoundingBox + bounding-box part of recognize (ssc.cpp:437-467, 723-751, 849-872) */
+int oracle_cluster_types(const scvod_params* params, const scvod_apri* apri, int32_t n, const int32_t* pt_cluster,
+                         int32_t car_label, int32_t other_label, int32_t* pt_type);
+
 /* SSC::tracking incl. the host bookkeeping (src/ssc.cpp:1250-1426) on two frames built from apri vectors with a toy
  * segmentation (oracle/tracking_oracle.cpp); states = {name, state, |occupy_voxels|} per tracked cluster of frame a. */
 int oracle_toy_tracking(const scvod_params* params, const scvod_apri* apri_a, int32_t n_a, const scvod_apri* apri_b, int32_t n_b,

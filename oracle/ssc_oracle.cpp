@@ -206,6 +206,10 @@ void oracle_params_default(scvod_params* p) {  // utility.h:283-310
     p->sector_res = 1.2f;
     p->azimuth_res = 2.0f;
     p->occupancy = 0.6f;
+    p->max_z = 1.0f;       // utility.h:294
+    p->min_z = -1.0f;      // utility.h:295
+    p->car_square = 2.0f;  // utility.h:298
+    p->toBeClass = 1;      // utility.h:306
 }
 
 void oracle_pw_params_default(scvod_pw_params* p) {  // patchwork.h:48-51, 115-129
@@ -394,6 +398,47 @@ int oracle_cluster(const scvod_params* params, const scvod_apri* apri_vec_, int3
     names.erase(std::unique(names.begin(), names.end()), names.end());
     std::memcpy(pt_cluster, clusterIdxs.data(), n * sizeof(int));
     return (int)names.size();
+}
+
+// refineClusterByBoundingBox (ssc.cpp:437-467) + the bounding-box branch of recognize (ssc.cpp:849-872, features of
+// getDescriptorByEigenValue ssc.cpp:723-751) for given per-point cluster names; building vs tree (PCL region growing)
+// is not separated: both map to other_label.
+int oracle_cluster_types(const scvod_params* params, const scvod_apri* apri, int32_t n, const int32_t* pt_cluster,
+                         int32_t car_label, int32_t other_label, int32_t* pt_type) {
+    struct Box {
+        float mn[3], mx[3];
+        int count = 0;
+    };
+    std::unordered_map<int, Box> boxes;  // pcl::getMinMax3D per cluster cloud
+    for (int i = 0; i < n; ++i) {
+        Box& b = boxes[pt_cluster[i]];
+        const float p[3] = {apri[i].x, apri[i].y, apri[i].z};
+        for (int k = 0; k < 3; ++k) {
+            if (b.count == 0 || p[k] < b.mn[k]) b.mn[k] = p[k];
+            if (b.count == 0 || p[k] > b.mx[k]) b.mx[k] = p[k];
+        }
+        b.count++;
+    }
+    std::unordered_map<int, int> type;
+    for (auto& kv : boxes) {
+        const Box& b = kv.second;
+        float diff_z = b.mx[2] - b.mn[2];
+        if (b.mn[2] > 0.f || (b.count < params->toBeClass) || diff_z < 0.2) {
+            type[kv.first] = -1;  // erased, voxels relabelled -1
+            continue;
+        }
+        double diff_x = b.mx[0] - b.mn[0], diff_y = b.mx[1] - b.mn[1];
+        double square = diff_x * diff_y;                 // f_11(0,7)
+        double f6 = b.mx[2], f9 = b.mn[2];               // f_11(0,6) = point_max.z, f_11(0,9) = point_min.z
+        if (square > params->car_square)
+            type[kv.first] = other_label;
+        else if (f9 < params->min_z && square < params->car_square && f6 < params->max_z)
+            type[kv.first] = car_label;
+        else
+            type[kv.first] = other_label;
+    }
+    for (int i = 0; i < n; ++i) pt_type[i] = type[pt_cluster[i]];
+    return 0;
 }
 
 int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz, int32_t n_query, float radius,

@@ -128,6 +128,13 @@ class Oracle:
         nc = self.lib.oracle_cluster(C.byref(params), _p(a), n, _p(out), C.byref(mx))
         return out[:n], nc, mx.value
 
+    def cluster_types(self, params, apri, pt_cluster, car_label=2, other_label=1):
+        a = np.ascontiguousarray(apri)
+        c = np.ascontiguousarray(pt_cluster, np.int32)
+        out = np.zeros(max(len(a), 1), np.int32)
+        self.lib.oracle_cluster_types(C.byref(params), _p(a), len(a), _p(c), car_label, other_label, _p(out))
+        return out[:len(a)]
+
     def nn_search(self, map_xyz, query_xyz, radius):
         m = np.ascontiguousarray(map_xyz, np.float32)
         q = np.ascontiguousarray(query_xyz, np.float32)

@@ -251,3 +251,26 @@ def test_cluster_edge_aliases(scvod, oracle):
     assert np.array_equal(got, _canonical(ref))
     assert len(ctx.cluster(np.zeros(0, scvod.APRI_DTYPE))) == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("kind,preset", [("K64", "semantickitti"), ("PARK", "parkinglot")])
+def test_cluster_types_match_reference_rules(scvod, oracle, kind, preset):
+    """per-cluster bounding boxes + the bbox rules of refineClusterByBoundingBox / recognize."""
+    import synth
+    P = _params(scvod, preset)
+    pts, _, _ = synth.make_scan(5, 60, kind)
+    x = pts.numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    names = ctx.batch_fetch_clusters(0, r["n_apri"])
+    got = ctx.batch_fetch_cluster_types(0, r["n_apri"], car_label=P_car(P), other_label=1)
+    ref = oracle.cluster_types(P, r["apri"], names, car_label=P_car(P), other_label=1)
+    assert np.array_equal(got, ref)
+    assert (got == 2).any() and (got == 1).any() and (got == -1).any()
+    ctx.close()
+
+
+def P_car(P):
+    return 2   # ssc/car_ in both YAML files
