@@ -130,6 +130,36 @@ void SSC::process(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloudIn_) {
     fillHashCloud(r, apri_vec.data());
 }
 
+void SSC::segmentGpu() {
+    const int n = (int)apri_vec.size();
+    std::vector<int> names(n ? n : 1), types(n ? n : 1);
+    chk(ctx_, scvod_cluster(ctx_, apri_vec.data(), n, names.data()), "scvod_cluster");
+    chk(ctx_, scvod_batch_cluster_types(ctx_, nullptr, 1), "scvod_batch_cluster_types");
+    int rc = scvod_batch_fetch_cluster_types(ctx_, 0, car, tree, types.data(), n);
+    if (rc < 0) chk(ctx_, rc, "scvod_batch_fetch_cluster_types");
+    frame_ssc.cluster_set.clear();
+    int max_name = 4;
+    for (int i = 0; i < n; ++i) {
+        if (types[i] == -1) continue;  // erased by the bounding-box refine: its voxels keep label -1
+        const int nm = names[i] + 5;   // the reference's names start at 5 (ssc.cpp:300,346)
+        Cluster& c = frame_ssc.cluster_set[nm];
+        c.name = nm;
+        c.type = types[i];
+        c.occupy_pts.push_back(i);
+        c.occupy_voxels.push_back(apri_vec[i].voxel_idx);
+        c.cloud->points.push_back(cloud_use->points[i]);
+        if (nm > max_name) max_name = nm;
+    }
+    for (auto& kv : frame_ssc.cluster_set) {
+        std::vector<int>& v = kv.second.occupy_voxels;
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        for (int key : v) hash_cloud[key].label = kv.first;
+    }
+    frame_ssc.max_name = max_name + 1;
+    frame_ssc.hash_cloud = hash_cloud;  // ssc.cpp:651
+}
+
 // SSC::tracking: the transform + re-bin + probe of every `car` cluster of frame_pre_ runs on the GPU in
 // one call (ssc.cpp:1274-1321); label grouping and the dynamic / split / fuse decisions mutate
 // frame_next_ cluster by cluster and therefore stay sequential on the host (ssc.cpp:1323-1421).

@@ -42,6 +42,10 @@ class SSC : public Utility {
     void makeApriVec(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_);
     void makeHashCloud(const std::vector<PointAPRI>& apriIn_);
     void tracking(Frame& frame_pre_, Frame& frame_next_, Pose pose_pre_, Pose pose_next_);
+    // GPU stand-in for segment() + recognize() when the reference's PCL host code is not linked: curved-voxel
+    // clustering (ssc.cpp:299-393) + bounding-box refine / recognise rules (ssc.cpp:437-467, 849-872);
+    // no intensity merge, no region growing (building and tree both become `tree`).
+    void segmentGpu();
 
     scvod_ctx* ctx() const { return ctx_; }
     int dynamic_num_last = 0;  // what the reference only logs (ssc.cpp:1424)

@@ -125,3 +125,16 @@ def test_voxelize_entry_point(scvod, oracle):
     r0 = ctx.voxelize(np.zeros(0, scvod.APRI_DTYPE))
     assert r0["n_voxels"] == 0
     ctx.close()
+
+
+def test_sequence_driver_end_to_end(scvod):
+    """segDF-shaped chain on the facade (process -> GPU clustering + bbox rules -> tracking) on a labelled
+    synthetic parking-lot sequence: static structure is preserved, some movers are rejected."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sequence_demo", os.path.join(ROOT, "tools", "sequence_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    r = demo.run(seq=3, first=0, count=6, kind="PARK", preset="parkinglot", verbose=False)
+    assert r["PR"] > 99.0
+    assert r["n_dynamic"] > 0 and r["RR"] > 10.0
+    assert "dynamic_total" in r["log"]
