@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pseudo-clusters", action="store_true", help="differencing stage on synthetic index runs instead of GPU car clusters")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0")
     args = ap.parse_args()
@@ -109,8 +110,9 @@ def main():
         c["stream"] = tstreams[i % n_ctx].cuda_stream
     ctx = ctxs[0]
 
-    # ---- pseudo "potentially mobile" clusters for the differencing stage: every 5th apri point of a
-    # scan, in runs of 256 (the reference tracks only `car` clusters: ~5-6 k points per scan) ----
+    # ---- clusters for the differencing stage (built once, outside the timed region): the `car` clusters the
+    # GPU clustering + bounding-box rules find in every scan -- what SSC::tracking walks.
+    # --pseudo-clusters falls back to every 5th apri point in runs of 256. ----
     tot_vox = 0
     tot_car = 0
     for c in chunks:
@@ -120,11 +122,25 @@ def main():
         tot_vox += int(cnt[:, 6].sum())
         n_sc = cnt.shape[0]
         members, cbegin, pbegin = [], [0], [0]
+        if not args.pseudo_clusters:
+            ctx.batch_cluster(stream=stream, sync=False)
+            ctx.batch_cluster_types(stream=stream, sync=True)
         for s in range(n_sc - 1):
-            m = np.arange(0, cnt[s, 4], 5, dtype=np.int32)
+            if args.pseudo_clusters:
+                m = np.arange(0, cnt[s, 4], 5, dtype=np.int32)
+                sizes = [min(256, len(m) - k) for k in range(0, len(m), 256)]
+            else:
+                names = ctx.batch_fetch_clusters(s, int(cnt[s, 4]))
+                types = ctx.batch_fetch_cluster_types(s, int(cnt[s, 4]))
+                idx = np.nonzero(types == 2)[0].astype(np.int32)
+                order = np.argsort(names[idx], kind="stable")
+                m = idx[order]
+                nm = names[m]
+                starts = np.nonzero(np.concatenate([[True], nm[1:] != nm[:-1]]))[0] if len(m) else np.zeros(0, np.int64)
+                sizes = np.diff(np.append(starts, len(m))).tolist()
             members.append(m)
-            for k in range(0, len(m), 256):
-                cbegin.append(cbegin[-1] + min(256, len(m) - k))
+            for sz in sizes:
+                cbegin.append(cbegin[-1] + int(sz))
             pbegin.append(len(cbegin) - 1)
         mem = np.concatenate(members) if members else np.zeros(0, np.int32)
         tot_car += len(mem)
@@ -258,7 +274,7 @@ def main():
                "config": {"workload": f"seq05-shaped {args.kind} sequence, {args.scans} scans/rank, {args.preset}.yaml grid, "
                                       f"chunks of {args.chunk} scans on {n_ctx} stream(s)", "scans_per_rank": args.scans,
                           "points_per_scan": total_pts / args.scans, "voxels_per_scan": tot_vox / args.scans,
-                          "car_points_per_scan": tot_car / args.scans, "sharding": f"1 sequence per GPU x{world}"},
+                          "car_points_per_scan": tot_car / args.scans, "car_clusters": "pseudo" if args.pseudo_clusters else "gpu clustering + bbox rules", "sharding": f"1 sequence per GPU x{world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
                "extras": {"cluster_ms_per_sequence": cc_ms}}

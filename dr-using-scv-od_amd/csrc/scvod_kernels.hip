@@ -1443,23 +1443,67 @@ __global__ __launch_bounds__(256) void k_track_probe(DevParams P, Arena A, Track
     J.hit_slot[k] = slot;
 }
 
+// sampleVec of the hit list of every cluster (ssc.cpp:1319-1321) without a sort: the hits are slots of the next
+// scan's voxel table, so a per-cluster bitset over the table (LDS) gives the sorted unique list directly.
+constexpr int kTrackBitWords = 8192;  // 262144 table slots; larger tables take the sort path below
+__global__ __launch_bounds__(128) void k_track_unique_bits(Arena A, TrackJob J, int batch_mode) {
+    __shared__ uint32_t bits[kTrackBitWords];
+    __shared__ int wsum[3];
+    const int c = blockIdx.x;
+    const int k0 = J.pt_cluster_begin[c], k1 = J.pt_cluster_begin[c + 1];
+    const int pair = J.cluster_pair ? J.cluster_pair[c] : 0;
+    const int nv = batch_mode ? A.counts[(pair + 1) * 8 + 6] : J.n_next_vox;
+    const int nw = (nv + 31) >> 5;
+    if (nw > kTrackBitWords) return;  // handled by k_track_unique
+    for (int w = threadIdx.x; w < nw; w += 128) bits[w] = 0u;
+    __syncthreads();
+    for (int j = k0 + threadIdx.x; j < k1; j += 128) {
+        const int slot = J.hit_slot[j];
+        if (slot >= 0) atomicOr(&bits[slot >> 5], 1u << (slot & 31));
+    }
+    __syncthreads();
+    int run = 0;
+    for (int w0 = 0; w0 < nw; w0 += 128) {
+        const int w = w0 + threadIdx.x;
+        const uint32_t word = (w < nw) ? bits[w] : 0u;
+        int total;
+        const int ex = block_excl_scan<128>(__popc(word), total, wsum);
+        uint32_t rest = word;
+        int o = k0 + run + ex;
+        while (rest) {
+            const int b = __ffs(rest) - 1;
+            rest &= rest - 1;
+            J.uniq_slots[o++] = (w << 5) + b;
+        }
+        run += total;
+    }
+    if (threadIdx.x == 0) J.uniq_count[c] = run;
+}
+
 template <int CAP, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_track_unique(TrackJob J) {
+__global__ __launch_bounds__(THREADS) void k_track_unique(TrackJob J, int table_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* l_keys = (uint32_t*)smem;
     int* wsum = (int*)(smem + (size_t)CAP * 4);
     const int c = blockIdx.x;
     const int k0 = J.pt_cluster_begin[c], k1 = J.pt_cluster_begin[c + 1];
     const int m = k1 - k0;
+    if (table_words <= kTrackBitWords) return;  // done by k_track_unique_bits
     uint32_t* keys;
-    if (m <= CAP)
-        keys = l_keys;
-    else
-        keys = (uint32_t*)(J.work + k0);
     // misses sort to the end as 0xffffffff
-    for (int j = threadIdx.x; j < m; j += THREADS) keys[j] = (uint32_t)J.hit_slot[k0 + j];
-    __syncthreads();
-    block_bitonic_sort<THREADS, false>(keys, m);
+    if (m <= CAP) {
+        keys = l_keys;
+        int np2 = 8;
+        while (np2 < m) np2 <<= 1;
+        for (int j = threadIdx.x; j < np2; j += THREADS) keys[j] = (j < m) ? (uint32_t)J.hit_slot[k0 + j] : 0xffffffffu;
+        __syncthreads();
+        block_bitonic_sort_pow2<THREADS, false, 3>(keys, np2);  // 32-bit keys: compare-exchange = v_min + v_max
+    } else {
+        keys = (uint32_t*)(J.work + k0);
+        for (int j = threadIdx.x; j < m; j += THREADS) keys[j] = (uint32_t)J.hit_slot[k0 + j];
+        __syncthreads();
+        block_bitonic_sort<THREADS, false>(keys, m);
+    }
     int run = 0;
     for (int c0 = 0; c0 < m; c0 += THREADS) {
         int j = c0 + threadIdx.x;
@@ -1703,7 +1747,11 @@ void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int bat
     }
     if (J.n_clusters > 0) {
         TH_BEGIN("track_unique");
-        hipLaunchKernelGGL((k_track_unique<8192, 256>), dim3(J.n_clusters), dim3(256), 8192 * 4 + 64, st, J);
+        hipLaunchKernelGGL(k_track_unique_bits, dim3(J.n_clusters), dim3(128), 0, st, A, J, batch_mode);
+        // tables with more than 262144 voxels (never the case for the reference's grids) take the sort path
+        const int table_words = batch_mode ? (A.max_scan_pts + 31) / 32 : (J.n_next_vox + 31) / 32;
+        if (table_words > kTrackBitWords)
+            hipLaunchKernelGGL((k_track_unique<8192, 256>), dim3(J.n_clusters), dim3(256), 8192 * 4 + 64, st, J, table_words);
         TH_END("track_unique");
     }
 }
