@@ -805,16 +805,27 @@ int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const f
     float *d_map = nullptr, *d_q = nullptr, *d_sq = nullptr;
     int32_t* d_idx = nullptr;
     uint8_t* d_w = nullptr;
+    int* d_work = nullptr;
     const size_t nm = n_map ? n_map : 1, nq = n_query ? n_query : 1;
+    // grid: cell edge >= radius (so `within` is decided by the 27-cell probe), origin = min corner of the map
+    float origin[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < n_map; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (i == 0 || h_map_xyz[3 * (size_t)i + k] < origin[k]) origin[k] = h_map_xyz[3 * (size_t)i + k];
+    const float cell = radius > 0.2f ? radius : 0.2f;
+    int32_t buckets = 1024;
+    while (buckets < 2 * n_map && buckets < (1 << 26)) buckets <<= 1;
+    const size_t work_ints = 3 * (size_t)buckets + nm + nq + 8 + (size_t)buckets / 1024 + 1;
     HIPCHK(c, hipMalloc(&d_map, nm * 12));
     HIPCHK(c, hipMalloc(&d_q, nq * 12));
     HIPCHK(c, hipMalloc(&d_sq, nq * 4));
     HIPCHK(c, hipMalloc(&d_idx, nq * 4));
     HIPCHK(c, hipMalloc(&d_w, nq));
+    HIPCHK(c, hipMalloc(&d_work, work_ints * sizeof(int)));
     hipStream_t st = c->stream;
     if (n_map) HIPCHK(c, hipMemcpyAsync(d_map, h_map_xyz, (size_t)n_map * 12, hipMemcpyHostToDevice, st));
     if (n_query) HIPCHK(c, hipMemcpyAsync(d_q, h_query_xyz, (size_t)n_query * 12, hipMemcpyHostToDevice, st));
-    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, st);
+    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, origin, cell, buckets, d_work, st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     if (n_query) {
@@ -827,6 +838,7 @@ int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const f
     hipFree(d_sq);
     hipFree(d_idx);
     hipFree(d_w);
+    hipFree(d_work);
     return SCVOD_OK;
 }
 

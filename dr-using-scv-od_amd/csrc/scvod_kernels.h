@@ -137,7 +137,8 @@ void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, Ti
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
-               float* nn_sq, uint8_t* within, hipStream_t st);
+               float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work,
+               hipStream_t st);
 
 }  // namespace scvod
 #endif

@@ -1756,11 +1756,189 @@ void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int bat
     }
 }
 
+// ---- uniform-grid correspondence search ------------------------------------------------------------
+// Map points are hashed by cell (edge h >= radius) into a CSR table; a query probes the 27 cells around it.
+// If the best candidate is within h it is the true nearest neighbour (anything outside the 27 cells is farther
+// than h); otherwise the query goes to the exact brute-force kernel.  Distances and tie-breaking (lowest map
+// index) are those of the brute-force kernel, so both paths return identical results.
+struct NnGrid {
+    float ox, oy, oz, inv_h, h2;
+    uint32_t mask;  // buckets - 1 (power of two)
+};
+__device__ __forceinline__ uint32_t nn_bucket(const NnGrid& g, int cx, int cy, int cz) {
+    return ((uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^ (uint32_t)cz * 83492791u) & g.mask;
+}
+__device__ __forceinline__ void nn_cell(const NnGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+    cx = (int)floorf((x - g.ox) * g.inv_h);
+    cy = (int)floorf((y - g.oy) * g.inv_h);
+    cz = (int)floorf((z - g.oz) * g.inv_h);
+}
+
+__global__ __launch_bounds__(256) void k_nn_count(NnGrid g, const float* __restrict__ map_xyz, int n_map, int* count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_map) return;
+    int cx, cy, cz;
+    nn_cell(g, map_xyz[3 * (size_t)i], map_xyz[3 * (size_t)i + 1], map_xyz[3 * (size_t)i + 2], cx, cy, cz);
+    atomicAdd(&count[nn_bucket(g, cx, cy, cz)], 1);
+}
+
+// exclusive scan of `n` ints, three launches: per-block (1024) scans + block totals, scan of totals, add-back
+__global__ __launch_bounds__(1024) void k_scan_blocks(const int* in, int* out, int* block_tot, int n) {
+    __shared__ int wsum[17];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = (i < n) ? in[i] : 0;
+    int total;
+    const int ex = block_excl_scan<1024>(v, total, wsum);
+    if (i < n) out[i] = ex;
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_scan_totals(int* block_tot, int nb, int* grand_total) {
+    __shared__ int wsum[17];
+    int run = 0;
+    for (int c0 = 0; c0 < nb; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        const int v = (i < nb) ? block_tot[i] : 0;
+        int total;
+        const int ex = block_excl_scan<1024>(v, total, wsum);
+        if (i < nb) block_tot[i] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) *grand_total = run;
+}
+__global__ __launch_bounds__(1024) void k_scan_add(int* out, const int* block_tot, int n) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += block_tot[blockIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_nn_fill(NnGrid g, const float* __restrict__ map_xyz, int n_map, const int* start,
+                                                 int* cursor, int* entries) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_map) return;
+    int cx, cy, cz;
+    nn_cell(g, map_xyz[3 * (size_t)i], map_xyz[3 * (size_t)i + 1], map_xyz[3 * (size_t)i + 2], cx, cy, cz);
+    const uint32_t b = nn_bucket(g, cx, cy, cz);
+    entries[start[b] + atomicAdd(&cursor[b], 1)] = i;
+}
+
+__global__ __launch_bounds__(256) void k_nn_query(NnGrid g, const float* __restrict__ map_xyz, const float* __restrict__ q_xyz,
+                                                  int n_q, float r2, const int* start, const int* count, const int* entries,
+                                                  int32_t* nn_idx, float* nn_sq, uint8_t* within, int* todo, int* n_todo) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_q) return;
+    const float qx = q_xyz[3 * (size_t)q], qy = q_xyz[3 * (size_t)q + 1], qz = q_xyz[3 * (size_t)q + 2];
+    int cx, cy, cz;
+    nn_cell(g, qx, qy, qz, cx, cy, cz);
+    float best = 0.f;
+    int bi = -1;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const uint32_t b = nn_bucket(g, cx + dx, cy + dy, cz + dz);
+                const int s0 = start[b], c = count[b];
+                for (int k = 0; k < c; ++k) {
+                    const int m = entries[s0 + k];
+                    const float ex = map_xyz[3 * (size_t)m] - qx, ey = map_xyz[3 * (size_t)m + 1] - qy,
+                                ez = map_xyz[3 * (size_t)m + 2] - qz;
+                    const float d = (ex * ex + ey * ey) + ez * ez;
+                    if (bi < 0 || d < best || (d == best && m < bi)) {
+                        best = d;
+                        bi = m;
+                    }
+                }
+            }
+    // several of the 27 probes may hash to the same bucket: harmless (same candidates again)
+    if (bi >= 0 && best <= g.h2) {
+        nn_idx[q] = bi;
+        nn_sq[q] = best;
+        within[q] = best <= r2 ? 1 : 0;
+    } else {
+        todo[atomicAdd(n_todo, 1)] = q;  // exact answer needs the whole map
+    }
+}
+
+__global__ __launch_bounds__(kNnThreads) void k_nn_brute_list(const float* __restrict__ map_xyz, int n_map,
+                                                               const float* __restrict__ q_xyz, const int* todo,
+                                                               const int* n_todo, float r2, int32_t* nn_idx, float* nn_sq,
+                                                               uint8_t* within) {
+    __shared__ float tx[kNnTile], ty[kNnTile], tz[kNnTile];
+    const int nt = *n_todo;
+    for (int t0q = blockIdx.x * kNnThreads; t0q < nt; t0q += gridDim.x * kNnThreads) {
+        const int t = t0q + threadIdx.x;
+        const int q = (t < nt) ? todo[t] : -1;
+        float qx = 0, qy = 0, qz = 0;
+        if (q >= 0) {
+            qx = q_xyz[3 * (size_t)q];
+            qy = q_xyz[3 * (size_t)q + 1];
+            qz = q_xyz[3 * (size_t)q + 2];
+        }
+        float best = 0.f;
+        int bi = -1;
+        for (int m0 = 0; m0 < n_map; m0 += kNnTile) {
+            const int tn = min(kNnTile, n_map - m0);
+            __syncthreads();
+            for (int j = threadIdx.x; j < tn; j += kNnThreads) {
+                tx[j] = map_xyz[3 * (size_t)(m0 + j)];
+                ty[j] = map_xyz[3 * (size_t)(m0 + j) + 1];
+                tz[j] = map_xyz[3 * (size_t)(m0 + j) + 2];
+            }
+            __syncthreads();
+            if (q >= 0) {
+                for (int j = 0; j < tn; ++j) {
+                    const float dx = tx[j] - qx, dy = ty[j] - qy, dz = tz[j] - qz;
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    if (bi < 0 || d < best) {
+                        best = d;
+                        bi = m0 + j;
+                    }
+                }
+            }
+        }
+        if (q >= 0) {
+            nn_idx[q] = bi;
+            nn_sq[q] = best;
+            within[q] = (bi >= 0 && best <= r2) ? 1 : 0;
+        }
+    }
+}
+
+// work: ints, size >= 3 * buckets + n_map + n_q + 4 + (buckets / 1024 + 1)
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
-               float* nn_sq, uint8_t* within, hipStream_t st) {
+               float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work,
+               hipStream_t st) {
     if (n_q <= 0) return;
-    hipLaunchKernelGGL(k_nn_brute, dim3((n_q + kNnThreads - 1) / kNnThreads), dim3(kNnThreads), 0, st, map_xyz, n_map,
-                       q_xyz, n_q, radius * radius, nn_idx, nn_sq, within);
+    if (n_map <= 0 || buckets <= 0) {  // empty map: brute-force kernel writes idx -1
+        hipLaunchKernelGGL(k_nn_brute, dim3((n_q + kNnThreads - 1) / kNnThreads), dim3(kNnThreads), 0, st, map_xyz, n_map,
+                           q_xyz, n_q, radius * radius, nn_idx, nn_sq, within);
+        return;
+    }
+    NnGrid g;
+    g.ox = origin[0];
+    g.oy = origin[1];
+    g.oz = origin[2];
+    g.inv_h = 1.0f / cell;
+    g.h2 = (0.99f * cell) * (0.99f * cell);  // acceptance radius, a hair inside the cell edge (cell rounding)
+    g.mask = (uint32_t)buckets - 1u;
+    int* count = work;
+    int* start = count + buckets;
+    int* cursor = start + buckets;
+    int* entries = cursor + buckets;
+    int* todo = entries + n_map;
+    int* n_todo = todo + n_q;
+    int* grand = n_todo + 1;
+    int* block_tot = grand + 1;
+    const int nb = (buckets + 1023) / 1024;
+    hipMemsetAsync(count, 0, sizeof(int) * (size_t)buckets, st);
+    hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)buckets, st);
+    hipMemsetAsync(n_todo, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_nn_count, dim3((n_map + 255) / 256), dim3(256), 0, st, g, map_xyz, n_map, count);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(1024), 0, st, count, start, block_tot, buckets);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, block_tot, nb, grand);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, start, block_tot, buckets);
+    hipLaunchKernelGGL(k_nn_fill, dim3((n_map + 255) / 256), dim3(256), 0, st, g, map_xyz, n_map, start, cursor, entries);
+    hipLaunchKernelGGL(k_nn_query, dim3((n_q + 255) / 256), dim3(256), 0, st, g, map_xyz, q_xyz, n_q, radius * radius, start,
+                       count, entries, nn_idx, nn_sq, within, todo, n_todo);
+    hipLaunchKernelGGL(k_nn_brute_list, dim3(kPersistCUs * 2), dim3(kNnThreads), 0, st, map_xyz, n_map, q_xyz, todo, n_todo,
+                       radius * radius, nn_idx, nn_sq, within);
 }
 
 }  // namespace scvod

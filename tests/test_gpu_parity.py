@@ -274,3 +274,54 @@ def test_cluster_types_match_reference_rules(scvod, oracle, kind, preset):
 
 def P_car(P):
     return 2   # ssc/car_ in both YAML files
+
+
+def test_nn_search_large_grid_path(scvod, oracle):
+    """Grid-hash correspondence search at map scale, against scipy's kd-tree (the reference uses PCL's kd-tree)."""
+    from scipy.spatial import cKDTree
+    import time
+    rng = np.random.default_rng(5)
+    n = 400_000
+    # a long corridor of points (dense near the walls), queries = jittered map points + far outliers
+    m = np.stack([rng.uniform(0, 600, n), rng.choice([-8.0, 8.0], n) + rng.normal(0, 0.3, n), rng.uniform(-2, 3, n)], 1).astype(np.float32)
+    q = np.concatenate([m[::2] + rng.normal(0, 0.03, (n // 2, 3)).astype(np.float32),
+                        rng.uniform(-50, 650, (5000, 3)).astype(np.float32)])
+    P = _params(scvod, "semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=1024, max_scans=1)
+    t0 = time.time()
+    idx, sq, w = ctx.nn_search(m, q, 0.15)
+    dt = time.time() - t0
+    d_ref, i_ref = cKDTree(m.astype(np.float64)).query(q.astype(np.float64), k=1)
+    # squared distances recomputed with the kernel's fp32 formula for the kd-tree's answer
+    dd = m[i_ref] - q
+    sq_ref = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+    assert np.all(sq <= sq_ref * (1 + 1e-6) + 1e-12)          # never worse than the kd-tree's neighbour
+    same = idx == i_ref
+    assert same.mean() > 0.999                                  # differences only on fp32 ties / near-ties
+    assert np.allclose(np.sqrt(sq[~same]), d_ref[~same], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(w, (sq <= np.float32(0.15) * np.float32(0.15)).astype(np.uint8))
+    # exactness of the grid path on a sample: brute-force oracle
+    sel = rng.choice(len(q), 300, replace=False)
+    oi, od, ow = oracle.nn_search(m, q[sel], 0.15)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(sq[sel].view(np.uint32), od.view(np.uint32)) and np.array_equal(w[sel], ow)
+    assert dt < 20.0
+    ctx.close()
+
+
+def test_metric_on_gpu_matches_reference_golden(scvod):
+    """PR / RR (tool/analysis.py definition) with the GPU correspondence search == the reference's own numbers."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from metric_cases import make_case
+    import metric
+    ctx = scvod.Ctx(_params(scvod, "semantickitti"), max_points_total=1024, max_scans=1)
+    for g in json.load(open(os.path.join(here, "golden", "metric_golden.json"))):
+        xyz, lab, exyz, elab = make_case(**g["case"])
+        m = metric.preservation_rejection(xyz, lab, exyz, elab, ctx.nn_search, voxelsize=0.2)
+        for k in ("num_preserved", "num_static_preserved", "num_dynamic_preserved"):
+            assert m[k] == g[k]
+        assert abs(m["PR"] - g["PR"]) < 1e-9 and abs(m["RR"] - g["RR"]) < 1e-9
+    ctx.close()
