@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-all", action="store_true", help="skip the multi-threaded CPU context number")
     ap.add_argument("--pseudo-clusters", action="store_true", help="differencing stage on synthetic index runs instead of GPU car clusters")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0")
@@ -267,6 +268,26 @@ def main():
                              f"oracle/liboracle.so, g++ -O3 no -march, 1 thread; {os.cpu_count()} host cores present)",
                    "stage_ms_per_scan": {"patchwork": 1e3 * stages[0] / ns, "bin": 1e3 * stages[1] / ns,
                                          "voxelize": 1e3 * stages[2] / ns}}
+        # context only: the same oracle with one scan per host thread (ctypes releases the GIL), bounded to ~10 s
+        cpu_all = None
+        if cpu is not None and not args.no_cpu_all:
+            try:
+                from concurrent.futures import ThreadPoolExecutor
+                nthr = min(os.cpu_count() or 1, 64)
+                per = max(2, min(8, int(chunks[0]["n_sc"]) // nthr))
+                offs_all = chunks[0]["offs"]
+                xs = chunks[0]["pts"][: int(offs_all[nthr * per])].cpu().numpy()
+
+                def work(t):
+                    o = offs_all[t * per:(t + 1) * per + 1]
+                    orc.time_process(P, xs[int(o[0]):int(o[-1])], (o - o[0]).astype(np.int32))
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(nthr) as ex:
+                    list(ex.map(work, range(nthr)))
+                cpu_all = {"value": nthr * per / (time.perf_counter() - t1), "unit": "scans/s", "threads": nthr,
+                           "note": "one scan per thread, same oracle; context, not the baseline"}
+            except Exception:
+                cpu_all = None
         out = {"metric": "scans/sec on SemanticKITTI-seq-05-shaped input (SCV-OD hot path)", "value": scans_per_s,
                "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -277,7 +298,7 @@ def main():
                           "car_points_per_scan": tot_car / args.scans, "car_clusters": "pseudo" if args.pseudo_clusters else "gpu clustering + bbox rules", "sharding": f"1 sequence per GPU x{world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
-               "extras": {"cluster_ms_per_sequence": cc_ms}}
+               "extras": {"cluster_ms_per_sequence": cc_ms, "cpu_all_threads": cpu_all}}
         print(json.dumps(out))
     for x in ctxs:
         x.close()
