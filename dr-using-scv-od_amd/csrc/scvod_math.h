@@ -393,7 +393,6 @@ SCVOD_HD int32_t czm_patch_of(const CzmParams& c, float xf, float yf, float zf) 
     double x = (double)xf, y = (double)yf;
     double r = sqrt_d(x * x + y * y);  // pow(x,2) == x*x exactly for float-valued doubles
     if (!((r <= c.max_range) && (r > c.min_range))) return -1;
-    double theta = (y >= 0.0) ? atan2_f64(y, x) : 2.0 * SCVOD_M_PI + atan2_f64(y, x);
     int k;
     if (r < c.zone_min[1])
         k = 0;
@@ -405,8 +404,27 @@ SCVOD_HD int32_t czm_patch_of(const CzmParams& c, float xf, float yf, float zf) 
         k = 3;
     int32_t ring = (int32_t)((r - c.zone_min[k]) / c.ring_size[k]);
     if (ring > c.num_rings[k] - 1) ring = c.num_rings[k] - 1;
-    int32_t sector = (int32_t)(theta / c.sector_size[k]);
+    // sector = int(theta / sector_size) with theta = atan2(y, x) in double (+2 pi for y < 0).  The fp32 fdlibm
+    // atan2 of the same (float-valued) arguments is within 3e-7 rad of it, so whenever theta_f / sector_size is
+    // farther than that from an integer the cheap value decides the SAME index; only the rare points next to a
+    // sector boundary (and the exact axis directions) take the fp64 evaluation.
+    int32_t sector;
+    {
+        double tf = (double)atan2_f32(yf, xf);
+        if (y < 0.0) tf += 2.0 * SCVOD_M_PI;
+        const double u = tf / c.sector_size[k];
+        const int32_t su = (int32_t)u;
+        const double fr = u - (double)su;
+        const double margin = 1.0e-6 / c.sector_size[k];
+        if (fr > margin && fr < 1.0 - margin) {
+            sector = su;
+        } else {
+            const double theta = (y >= 0.0) ? atan2_f64(y, x) : 2.0 * SCVOD_M_PI + atan2_f64(y, x);
+            sector = (int32_t)(theta / c.sector_size[k]);
+        }
+    }
     if (sector > c.num_sectors[k] - 1) sector = c.num_sectors[k] - 1;
+    if (sector < 0) sector = 0;  // y == -0.0f with x < 0 gives theta = -pi: out-of-bounds indexing in the reference
     return c.patch_base[k] + ring * c.num_sectors[k] + sector;
 }
 

@@ -20,6 +20,7 @@ void oracle_grid_dims(const scvod_params* p, int32_t* range_num, int32_t* sector
 int oracle_patchwork(const scvod_params* params, const scvod_pw_params* pw, const float* xyzi, int32_t n,
                      int32_t sort_mode, uint8_t* cls, int32_t* ground_idx, int32_t* n_ground, int32_t* nonground_idx,
                      int32_t* n_nonground, scvod_patch_plane* planes, int32_t* n_patches);
+void oracle_patch_ids(const scvod_params* params, const float* xyzi, int32_t n, int32_t* pid);
 void oracle_svd3(const float cov_rowmajor[9], float sv[3], float U_rowmajor[9]);
 
 /* SSC::makeApriVec, src/ssc.cpp:155-195.  apply_filter == 0: SSC::tracking's unfiltered

@@ -188,6 +188,19 @@ class PatchworkOracle {
 
     int num_patches() const { return num_patches_; }
 
+    // patch id of one point as pc2czm + the z cut assign it (-1: not binned); for the spec-vs-libm test
+    int patch_of(float xf, float yf, float zf) {
+        if (zf < -1.8 * sensor_height_) return -1;
+        double r = xy2radius(xf, yf);
+        if (!((r <= pw_.max_range) && (r > pw_.min_range))) return -1;
+        double theta = xy2theta(xf, yf);
+        int k = (r < min_range_z2_) ? 0 : (r < min_range_z3_) ? 1 : (r < min_range_z4_) ? 2 : 3;
+        int ring_idx = std::min(static_cast<int>(((r - min_ranges_[k]) / ring_sizes_[k])), pw_.num_rings_each_zone[k] - 1);
+        int sector_idx = std::min(static_cast<int>((theta / sector_sizes_[k])), pw_.num_sectors_each_zone[k] - 1);
+        if (sector_idx < 0) sector_idx = 0;
+        return patch_base_[k] + ring_idx * pw_.num_sectors_each_zone[k] + sector_idx;
+    }
+
     // sort_mode 0: std::sort with `a.z < b.z` exactly as patchwork.h:295 (tie order is whatever
     //              libstdc++'s introsort yields);
     // sort_mode 1: ties broken by input index (the canonical order the GPU path implements).
@@ -235,6 +248,7 @@ class PatchworkOracle {
                     k = 3;
                 ring_idx = std::min(static_cast<int>(((r - min_ranges_[k]) / ring_sizes_[k])), pw_.num_rings_each_zone[k] - 1);
                 sector_idx = std::min(static_cast<int>((theta / sector_sizes_[k])), pw_.num_sectors_each_zone[k] - 1);
+                if (sector_idx < 0) sector_idx = 0;  // y == -0.0f, x < 0: theta = -pi; the reference indexes out of bounds here
                 patches[patch_base_[k] + ring_idx * pw_.num_sectors_each_zone[k] + sector_idx].emplace_back(pt);
             }
         }
@@ -438,6 +452,13 @@ int oracle_patchwork(const scvod_params* params, const scvod_pw_params* pw_in, c
     if (planes) std::memcpy(planes, pl.data(), pl.size() * sizeof(scvod_patch_plane));
     if (n_patches) *n_patches = po.num_patches();
     return 0;
+}
+
+void oracle_patch_ids(const scvod_params* params, const float* xyzi, int32_t n, int32_t* pid) {
+    scvod_pw_params pw;
+    oracle_pw_params_default(&pw);
+    PatchworkOracle po(pw, (double)params->sensor_height);
+    for (int i = 0; i < n; ++i) pid[i] = po.patch_of(xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2]);
 }
 
 // exposed for the SVD known-answer tests; cov row-major 3x3 (symmetric in practice)

@@ -35,6 +35,21 @@ void spec_svd3(const float cov[9], float sv[3], float U[9]) {
     for (int i = 0; i < 3; ++i) sv[i] = s.sv[i];
     for (int i = 0; i < 9; ++i) U[i] = s.U[i];
 }
+// patch ids with the reference's hard-coded Patchwork constants (patchwork.h:48-51,115-129)
+void spec_patch_ids(float sensor_height, const float* xyzi, long n, int* pid) {
+    scvod::CzmParams c;
+    const double mn = 2.7, mx = 80.0;
+    const int rings[4] = {2, 4, 4, 4}, secs[4] = {16, 32, 54, 32};
+    c.min_range = mn; c.max_range = mx;
+    c.zone_min[0] = mn; c.zone_min[1] = (7 * mn + mx) / 8.0; c.zone_min[2] = (3 * mn + mx) / 4.0; c.zone_min[3] = (mn + mx) / 2.0;
+    c.ring_size[0] = (c.zone_min[1] - mn) / rings[0]; c.ring_size[1] = (c.zone_min[2] - c.zone_min[1]) / rings[1];
+    c.ring_size[2] = (c.zone_min[3] - c.zone_min[2]) / rings[2]; c.ring_size[3] = (mx - c.zone_min[3]) / rings[3];
+    int base = 0;
+    for (int k = 0; k < 4; ++k) { c.sector_size[k] = 2 * M_PI / secs[k]; c.num_rings[k] = rings[k]; c.num_sectors[k] = secs[k]; c.patch_base[k] = base; base += rings[k] * secs[k]; }
+    c.num_patches = base;
+    c.z_cut = -1.8 * (double)sensor_height;
+    for (long i = 0; i < n; ++i) pid[i] = scvod::czm_patch_of(c, xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2]);
+}
 int spec_apri(const float g[9], const int dims[4], const float p[4], float out_f[7], int out_i[4]) {
     scvod::BinParams b;
     b.min_dis = g[0]; b.max_dis = g[1]; b.min_angle = g[2]; b.max_angle = g[3]; b.min_azimuth = g[4];

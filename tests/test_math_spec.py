@@ -94,3 +94,29 @@ def test_apri_spec_equals_oracle_binning(spec, oracle, scvod):
             assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (preset, i)
             assert list(oi) == [a["range_idx"], a["sector_idx"], a["azimuth_idx"], a["voxel_idx"]]
             assert bool(keep) == (i in keep_set)
+
+
+def test_patch_ids_spec_equals_libm_oracle(spec, oracle, scvod):
+    """pc2czm zone / ring / sector of the spec (fp32 atan2 fast path + fp64 fdlibm fall-back) == the oracle's
+    glibc-double evaluation, including points a few 1e-7 rad away from sector boundaries and on the axes."""
+    rng = np.random.default_rng(6)
+    P = scvod.make_params("semantickitti")
+    n = 400_000
+    r = rng.uniform(2.0, 85.0, n)
+    t = rng.uniform(0, 2 * np.pi, n)
+    for S in (16, 32, 54):                       # cluster a share of the angles around the sector boundaries
+        k = rng.integers(0, S, n // 8)
+        sl = slice((S // 16 - 1) * (n // 8), (S // 16 - 1) * (n // 8) + n // 8) if S != 54 else slice(3 * (n // 8), 4 * (n // 8))
+        t[sl] = k * (2 * np.pi / S) + rng.normal(0, 3e-7, n // 8)
+    x = np.stack([r * np.cos(t), r * np.sin(t), rng.uniform(-4, 3, n), np.zeros(n)], 1).astype(np.float32)
+    x[:200, 1] = 0.0                             # exact axis directions
+    x[200:400, 0] = 0.0
+    x[400:600, 1] = x[400:600, 0]
+    x[600:700, 1] = -0.0
+    x[600:700, 0] = np.abs(x[600:700, 0])
+    got = np.zeros(n, np.int32)
+    spec.spec_patch_ids(C.c_float(P.sensor_height), x.ctypes.data_as(C.c_void_p), C.c_long(n), got.ctypes.data_as(C.c_void_p))
+    ref = np.zeros(n, np.int32)
+    oracle.lib.oracle_patch_ids(C.byref(P), x.ctypes.data_as(C.c_void_p), n, ref.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(got, ref)
+    assert (ref >= 0).sum() > n // 2 and ref.max() == 503
