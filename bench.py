@@ -32,7 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # Algorithmic (compulsory) bytes per scan, SURVEY.md 8(d), split by stage so that a kernel is priced
 # against the bytes of ITS stage (DESIGN.md "Roofline accounting"):
-#   patchwork : 16 N (read xyzi) + 1 N (class)                         -> pw_* and emit kernels
+#   patchwork : 16 N (read xyzi)   [the per-point class byte of 8(d) is not materialised per batch any more:
+#               the two index lists carry it; scvod_batch_fetch builds the class array of a scan on request]
 #   binning   : 4 N (voxel_idx) + 1 N (dynamic/static label)           -> emit (fused)
 #   voxels    : 20 V                                                   -> vx_* kernels
 #   tracking  : 16 N_car + 4 N_car + 64                                -> track_* kernels
@@ -45,7 +46,7 @@ STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter":
 
 
 def stage_bytes(n_pts, n_vox, n_car, n_scans):
-    return {"patchwork": 17.0 * n_pts, "binning": 5.0 * n_pts, "voxels": 20.0 * n_vox,
+    return {"patchwork": 16.0 * n_pts, "binning": 5.0 * n_pts, "voxels": 20.0 * n_vox,
             "tracking": 20.0 * n_car + 64.0 * n_scans}
 
 

@@ -52,6 +52,7 @@ struct scvod_ctx {
     std::vector<int32_t> h_scan_off;
     std::vector<int32_t> h_counts;
     bool counts_valid = false;
+    bool have_patchwork = false;
     bool clusters_valid = false;
     bool types_valid = false;
     hipStream_t last_stream = nullptr;
@@ -303,6 +304,7 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
         HIPCHK(c, hipMemsetAsync(c->A.counts, 0, sizeof(int32_t) * 8 * n_scans, st));
     }
     c->batch_valid = true;
+    c->have_patchwork = (do_patchwork == 1);
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
@@ -341,7 +343,12 @@ int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
     out->n_voxels = k[6];
     out->n_patches = k[7];
     const Arena& A = c->A;
-    if ((rc = dl(c, c->r_cls, A.cls + base, (size_t)k[0]))) return rc;
+    if (c->have_patchwork) {
+        launch_cls(A, s, base, k[0], c->last_stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    }
+    if ((rc = dl(c, c->r_cls, A.cls + base, (size_t)(c->have_patchwork ? k[0] : 0)))) return rc;
     if ((rc = dl(c, c->r_ground, A.ground_idx + base, (size_t)k[1]))) return rc;
     if ((rc = dl(c, c->r_nonground, A.nonground_idx + base, (size_t)k[2]))) return rc;
     if ((rc = dl(c, c->r_planes, A.planes + (size_t)s * kMaxPatches, (size_t)k[7]))) return rc;

@@ -66,7 +66,7 @@ struct Arena {
     scvod_patch_plane* planes;  // [B][kMaxPatches]
     int32_t* emit_off;        // [B][kMaxPatches][4]  ground / nonground / apri / rejected
     // outputs of the Patchwork + binning stage
-    uint8_t* cls;             // [N]
+    uint8_t* cls;             // [N] filled per scan on request (scvod_batch_fetch / per-scan API), see k_cls_from_lists
     int32_t* ground_idx;      // [N]
     int32_t* nonground_idx;   // [N]
     scvod_apri* apri;         // [N]
@@ -132,6 +132,7 @@ typedef void (*TimerHook)(void* user, const char* name, int begin);
 // 2 = neither (apri / counts already in the arena: voxel stage only).
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu);
+void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,

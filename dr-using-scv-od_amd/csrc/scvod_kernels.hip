@@ -304,7 +304,6 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_classify(DevParams P, Arena 
             int pid = czm_patch_of(P.czm, p.x, p.y, p.z);
             A.pid[base + i] = (int16_t)pid;
             A.zkey[base + i] = float_sort_key(p.z);
-            A.cls[base + i] = SCVOD_CLS_DROPPED;
             if (pid >= 0) atomicAdd(&hist[pid], 1);
         }
     }
@@ -861,7 +860,6 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
             for (int e = lane; e < r.n_g; e += 64) {
                 const uint32_t id = seg[e] & 0x7fffffffu;
                 A.ground_idx[(size_t)base + xg + e] = (int32_t)id;
-                A.cls[base + id] = SCVOD_CLS_GROUND;
             }
         }
         // non-ground stream of this patch: for a rejected patch the ground part (front, ascending) followed
@@ -885,7 +883,6 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                 const uint32_t id = v & 0x7fffffffu;
                 const int spos = e - e0;  // position in the non-ground stream of this patch
                 A.nonground_idx[(size_t)base + xng + spos] = (int32_t)id;
-                A.cls[base + id] = SCVOD_CLS_NONGROUND;
                 if (keep) {
                     const float4 q = A.pts[base + id];
                     Apri a;
@@ -921,6 +918,19 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
             __builtin_amdgcn_wave_barrier();
             run_keep += nk;
         }
+    }
+}
+
+// Per-point class array of ONE scan, built on request from the two index lists (the reference holds the two clouds,
+// never a class array; materialising it for every scan of a batch cost 0.9 ms per sequence in byte scatters).
+__global__ __launch_bounds__(256) void k_cls_from_lists(Arena A, int s) {
+    const int base = A.scan_off[s];
+    const int n_g = A.counts[s * 8 + 1], n_ng = A.counts[s * 8 + 2];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_g + n_ng; i += gridDim.x * 256) {
+        if (i < n_g)
+            A.cls[base + A.ground_idx[(size_t)base + i]] = SCVOD_CLS_GROUND;
+        else
+            A.cls[base + A.nonground_idx[(size_t)base + (i - n_g)]] = SCVOD_CLS_NONGROUND;
     }
 }
 
@@ -1705,6 +1715,12 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_final, gb, dim3(256), 0, st, P, A);
         TH_END("vx_final");
     }
+}
+
+void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st) {
+    if (n_points <= 0) return;
+    hipMemsetAsync(A.cls + scan_base, SCVOD_CLS_DROPPED, (size_t)n_points, st);
+    hipLaunchKernelGGL(k_cls_from_lists, dim3((n_points + 2047) / 2048), dim3(256), 0, st, A, s);
 }
 
 void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
