@@ -53,6 +53,8 @@ struct scvod_ctx {
     std::vector<int32_t> h_counts;
     bool counts_valid = false;
     bool have_patchwork = false;
+    int batch_mode = 0;          // do_patchwork of the last batch: 1 Patchwork+binning, 0 binning only, 2 caller's apri_vec
+    bool apri_compact = false;   // PointAPRI records not materialised yet (k_apri_expand on request)
     bool clusters_valid = false;
     bool types_valid = false;
     hipStream_t last_stream = nullptr;
@@ -305,6 +307,8 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     }
     c->batch_valid = true;
     c->have_patchwork = (do_patchwork == 1);
+    c->batch_mode = do_patchwork;
+    c->apri_compact = (do_patchwork == 1);
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
@@ -352,6 +356,11 @@ int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
     if ((rc = dl(c, c->r_ground, A.ground_idx + base, (size_t)k[1]))) return rc;
     if ((rc = dl(c, c->r_nonground, A.nonground_idx + base, (size_t)k[2]))) return rc;
     if ((rc = dl(c, c->r_planes, A.planes + (size_t)s * kMaxPatches, (size_t)k[7]))) return rc;
+    if (c->apri_compact && k[4] > 0) {  // PointAPRI records of this scan only
+        launch_apri_expand(c->dev, A, s, 1, k[4], c->last_stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    }
     if ((rc = dl(c, c->r_apri, A.apri + base, (size_t)k[4]))) return rc;
     if ((rc = dl(c, c->r_apri_src, A.apri_src + base, (size_t)k[4]))) return rc;
     if ((rc = dl(c, c->r_rejected, A.rejected_src + base, (size_t)k[5]))) return rc;
@@ -678,6 +687,10 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
     c->tim_used = 0;
+    if (c->apri_compact) {  // the clustering kernels read the index triples of the PointAPRI records
+        launch_apri_expand(c->dev, c->A, 0, c->A.n_scans, c->A.max_scan_pts, st);
+        c->apri_compact = false;
+    }
     launch_cluster(c->dev, c->A, st, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     c->clusters_valid = true;
@@ -770,7 +783,7 @@ int scvod_batch_track(scvod_ctx* c, const int32_t* d_members, const int32_t* h_c
     J.work = c->t_work;
     J.uniq_slots = c->t_uniq;
     J.uniq_count = c->t_count;
-    launch_track(c->dev, c->A, J, 1, st, timer_hook, c);
+    launch_track(c->dev, c->A, J, c->batch_mode == 2 ? 2 : 1, st, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     c->last_track_clusters = n_clusters;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));

@@ -132,6 +132,7 @@ typedef void (*TimerHook)(void* user, const char* name, int begin);
 // 2 = neither (apri / counts already in the arena: voxel stage only).
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu);
+void launch_apri_expand(const DevParams& P, const Arena& A, int s0, int n_scans, int max_pts, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);

@@ -841,7 +841,6 @@ __global__ __launch_bounds__(1024) void k_emit_offsets(DevParams P, Arena A) {
 
 constexpr int kEmitThreads = 256;
 __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
-    __shared__ uint32_t stage[4 * 64 * 11];  // per wave: up to 64 PointAPRI records (44 B each)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int total = A.order_off[64];
@@ -887,20 +886,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     const float4 q = A.pts[base + id];
                     Apri a;
                     apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-                    // stage the 11-dword record in LDS so the wave can store the nk records of this step
-                    // as one contiguous, coalesced run
-                    uint32_t* rec = stage + wave * (64 * 11) + ek * 11;
-                    rec[0] = f2u(a.x);
-                    rec[1] = f2u(a.y);
-                    rec[2] = f2u(a.z);
-                    rec[3] = f2u(a.range);
-                    rec[4] = f2u(a.angle);
-                    rec[5] = f2u(a.azimuth);
-                    rec[6] = f2u(a.intensity);
-                    rec[7] = (uint32_t)a.range_idx;
-                    rec[8] = (uint32_t)a.sector_idx;
-                    rec[9] = (uint32_t)a.azimuth_idx;
-                    rec[10] = (uint32_t)a.voxel_idx;
+                    // apri_vec is kept in its compact form (source index, voxel key, intensity); the 44-byte
+                    // PointAPRI records are expanded from it on request (k_apri_expand)
                     A.apri_src[dst0 + ek] = (int32_t)id;
                     A.apri_key[dst0 + ek] = a.voxel_idx;
                     A.apri_int[dst0 + ek] = a.intensity;
@@ -908,16 +895,34 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
                 }
             }
-            // wave-synchronous: all lanes of this wave have written their records (same instruction stream)
-            __builtin_amdgcn_wave_barrier();
-            {
-                uint32_t* out = (uint32_t*)(A.apri + dst0);
-                const uint32_t* src = stage + wave * (64 * 11);
-                for (int k = lane; k < nk * 11; k += 64) out[k] = src[k];
-            }
-            __builtin_amdgcn_wave_barrier();
             run_keep += nk;
         }
+    }
+}
+
+// PointAPRI records (ssc.cpp:176-193) of scans [s0, s0 + gridDim.y), rebuilt from the compact apri_vec: the same spec
+// function on the same point gives the same bits k_emit saw when it derived key and intensity.
+__global__ __launch_bounds__(256) void k_apri_expand(DevParams P, Arena A, int s0) {
+    const int s = s0 + blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 q = A.pts[base + A.apri_src[(size_t)base + i]];
+        Apri a;
+        apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
+        scvod_apri out;
+        out.x = a.x;
+        out.y = a.y;
+        out.z = a.z;
+        out.range = a.range;
+        out.angle = a.angle;
+        out.azimuth = a.azimuth;
+        out.intensity = a.intensity;
+        out.range_idx = a.range_idx;
+        out.sector_idx = a.sector_idx;
+        out.azimuth_idx = a.azimuth_idx;
+        out.voxel_idx = a.voxel_idx;
+        A.apri[(size_t)base + i] = out;
     }
 }
 
@@ -1420,8 +1425,12 @@ __global__ __launch_bounds__(256) void k_track_probe(DevParams P, Arena A, Track
     int nv;
     if (batch_mode) {
         const int sb = A.scan_off[pair];
-        const scvod_apri& a = A.apri[(size_t)sb + J.members[k]];
-        q = make_float4(a.x, a.y, a.z, a.intensity);
+        if (batch_mode == 1) {  // members are apri_vec indices; the point itself is read through apri_src
+            q = A.pts[sb + A.apri_src[(size_t)sb + J.members[k]]];
+        } else {  // apri_vec supplied by the caller (no input cloud on the device)
+            const scvod_apri& a = A.apri[(size_t)sb + J.members[k]];
+            q = make_float4(a.x, a.y, a.z, a.intensity);
+        }
         const int nb = A.scan_off[pair + 1];
         keys = A.vox_key + nb;
         nv = A.counts[(pair + 1) * 8 + 6];
@@ -1715,6 +1724,11 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_final, gb, dim3(256), 0, st, P, A);
         TH_END("vx_final");
     }
+}
+
+void launch_apri_expand(const DevParams& P, const Arena& A, int s0, int n_scans, int max_pts, hipStream_t st) {
+    if (n_scans <= 0 || max_pts <= 0) return;
+    hipLaunchKernelGGL(k_apri_expand, dim3((max_pts + 1023) / 1024, n_scans), dim3(256), 0, st, P, A, s0);
 }
 
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st) {

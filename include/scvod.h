@@ -210,7 +210,9 @@ int scvod_track_probe(scvod_ctx* ctx, const float* h_xyzi, const int32_t* h_offs
 /* Run Patchwork -> binning -> voxel descriptors over n_scans scans already resident in
  * HBM.  d_xyzi: all scans concatenated; h_scan_offsets[n_scans+1] point offsets.
  * stream: hipStream_t (NULL = the ctx's own stream).  Asynchronous w.r.t. the host
- * unless sync != 0. */
+ * unless sync != 0.  d_xyzi must stay valid and unchanged until the next batch call: apri_vec is kept
+ * on the device in compact form (source index, voxel key, intensity) and the PointAPRI records,
+ * the per-point class array and the tracking probe read the points through it on request. */
 int scvod_batch_process(scvod_ctx* ctx, const void* d_xyzi, const int32_t* h_scan_offsets,
                         int32_t n_scans, void* stream, int32_t sync);
 
