@@ -377,6 +377,8 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 // ------------------------------------------------------------------------------------------
 // size classes (pw_size_class) that bound the sort tiers: class 40 <=> n >= 1024, class 48 <=> n >= 4096
 constexpr int kClassXS = 32, kClassM = 40, kClassM2 = 44, kClassL = 48;  // n >= 256 / 1024 / 2048 / 4096
+constexpr int kClassFitCoop = 36;   // n >= 512: plane fit by 16 lanes per patch (k_pw_fit_coop)
+constexpr int kFitCoopMin = 512;
 
 // order[] lists live items by descending size class; positions of classes [C_LO, C_HI]
 __device__ __forceinline__ void order_range(const int32_t* off, int c_lo, int c_hi, int& lo, int& hi) {
@@ -576,119 +578,66 @@ __device__ __forceinline__ float plane_res(const Xyz& q, float n0, float n1, flo
     return r;
 }
 
-__global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= A.order_off[64]) return;
-    const int4 item = A.order[t];
-    const int code = item.x;
-    const int s = code / kMaxPatches, p = code - s * kMaxPatches;
-    const int n = item.y, base = item.z, off = item.w;
-    const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
+struct FitState {
+    float cov[9];
+    float mean0, mean1, mean2;
+    float n0, n1, n2, thd;
+    float sv0, sv1, sv2;
+};
+__device__ __forceinline__ void fit_state_init(FitState& F) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F.cov[k] = 0.f;
+    F.mean0 = F.mean1 = F.mean2 = 0.f;
+    F.n0 = F.n1 = F.n2 = F.thd = 0.f;
+    F.sv0 = F.sv1 = F.sv2 = 0.f;
+}
 
-    int zone = 0;
-    while (zone < 3 && p >= P.czm.patch_base[zone + 1]) ++zone;
-    const int ring = (p - P.czm.patch_base[zone]) / P.czm.num_sectors[zone];
-    int concentric_idx = ring;
-    for (int k = 0; k < zone; ++k) concentric_idx += P.czm.num_rings[k];
-
-    // ---- extract_initial_seeds_ (patchwork.h:235-268) ----
-    int init_idx = 0;
-    if (zone == 0) {
-        while (init_idx < n && (double)sp[init_idx].z < P.czm.seed_margin_z) ++init_idx;
+// estimate_plane_ (patchwork.h:206-232) from the nine sums of pcl::computeMeanAndCovarianceMatrix
+__device__ __forceinline__ void fit_update(FitState& F, const CzmParams& cz, float a0, float a1, float a2, float a3, float a4,
+                                           float a5, float a6, float a7, float a8, int m) {
+    if (m != 0) {  // an empty set leaves cov_/pc_mean_ untouched (PCL)
+        const float fn = (float)m;
+        a0 = a0 / fn;
+        a1 = a1 / fn;
+        a2 = a2 / fn;
+        a3 = a3 / fn;
+        a4 = a4 / fn;
+        a5 = a5 / fn;
+        a6 = a6 / fn;
+        a7 = a7 / fn;
+        a8 = a8 / fn;
+        F.mean0 = a6;
+        F.mean1 = a7;
+        F.mean2 = a8;
+        F.cov[0] = a0 - a6 * a6;
+        F.cov[1] = a1 - a6 * a7;
+        F.cov[2] = a2 - a6 * a8;
+        F.cov[4] = a3 - a7 * a7;
+        F.cov[5] = a4 - a7 * a8;
+        F.cov[8] = a5 - a8 * a8;
+        F.cov[3] = F.cov[1];
+        F.cov[6] = F.cov[2];
+        F.cov[7] = F.cov[5];
     }
-    double sum = 0;
-    int cnt = 0;
-    for (int i = init_idx; i < n && cnt < P.czm.num_lpr; ++i) {
-        sum += (double)sp[i].z;
-        ++cnt;
-    }
-    const double lpr = cnt != 0 ? sum / cnt : 0.0;
-    const double seed_thr = lpr + P.czm.th_seeds;
+    Svd3 sv;
+    svd3_jacobi(F.cov, sv);
+    F.n0 = sv.U[2];
+    F.n1 = sv.U[5];
+    F.n2 = sv.U[8];
+    F.sv0 = sv.sv[0];
+    F.sv1 = sv.sv[1];
+    F.sv2 = sv.sv[2];
+    float dot = F.n0 * F.mean0;
+    dot = dot + F.n1 * F.mean1;
+    dot = dot + F.n2 * F.mean2;
+    const float d = -dot;
+    F.thd = (float)(cz.th_dist - (double)d);
+}
 
-    float cov[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float mean0 = 0.f, mean1 = 0.f, mean2 = 0.f;
-    float n0 = 0.f, n1 = 0.f, n2 = 0.f, thd = 0.f;
-    float sv0 = 0.f, sv1 = 0.f, sv2 = 0.f;
-
-    for (int iter = 0; iter < P.czm.num_iter; ++iter) {
-        // pcl::computeMeanAndCovarianceMatrix over the current ground set, strictly in z order
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f;
-        int m = 0;
-        // The lane streams its patch in blocks of PF points, next block in flight while the current
-        // one is accumulated (the only loop-carried dependence is the 9 fp32 adds).  Indices are
-        // clamped so every load is valid; membership is a select, adding +0.0f is exact here
-        // because the accumulators can never be -0.0f.
-        constexpr int PF = 8;
-        Xyz cur[PF], nxt[PF];
-#pragma unroll
-        for (int k = 0; k < PF; ++k) cur[k] = sp[min(k, n - 1)];
-        for (int j0 = 0; j0 < n; j0 += PF) {
-#pragma unroll
-            for (int k = 0; k < PF; ++k) nxt[k] = sp[min(j0 + PF + k, n - 1)];
-            if (iter == 0 && !((double)cur[0].z < seed_thr)) break;  // seeds are a prefix (z-sorted)
-#pragma unroll
-            for (int k = 0; k < PF; ++k) {
-                const Xyz q = cur[k];
-                bool in = (j0 + k < n);
-                if (iter == 0)
-                    in = in && ((double)q.z < seed_thr);
-                else
-                    in = in && (plane_res(q, n0, n1, n2) < thd);
-                const float t0 = q.x * q.x, t1 = q.x * q.y, t2 = q.x * q.z, t3 = q.y * q.y, t4 = q.y * q.z,
-                            t5 = q.z * q.z;
-                a0 += in ? t0 : 0.f;
-                a1 += in ? t1 : 0.f;
-                a2 += in ? t2 : 0.f;
-                a3 += in ? t3 : 0.f;
-                a4 += in ? t4 : 0.f;
-                a5 += in ? t5 : 0.f;
-                a6 += in ? q.x : 0.f;
-                a7 += in ? q.y : 0.f;
-                a8 += in ? q.z : 0.f;
-                m += in ? 1 : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < PF; ++k) cur[k] = nxt[k];
-        }
-        if (m != 0) {  // an empty set leaves cov_/pc_mean_ untouched (PCL)
-            const float fn = (float)m;
-            a0 = a0 / fn;
-            a1 = a1 / fn;
-            a2 = a2 / fn;
-            a3 = a3 / fn;
-            a4 = a4 / fn;
-            a5 = a5 / fn;
-            a6 = a6 / fn;
-            a7 = a7 / fn;
-            a8 = a8 / fn;
-            mean0 = a6;
-            mean1 = a7;
-            mean2 = a8;
-            cov[0] = a0 - a6 * a6;
-            cov[1] = a1 - a6 * a7;
-            cov[2] = a2 - a6 * a8;
-            cov[4] = a3 - a7 * a7;
-            cov[5] = a4 - a7 * a8;
-            cov[8] = a5 - a8 * a8;
-            cov[3] = cov[1];
-            cov[6] = cov[2];
-            cov[7] = cov[5];
-        }
-        Svd3 sv;
-        svd3_jacobi(cov, sv);
-        n0 = sv.U[2];
-        n1 = sv.U[5];
-        n2 = sv.U[8];
-        sv0 = sv.sv[0];
-        sv1 = sv.sv[1];
-        sv2 = sv.sv[2];
-        float dot = n0 * mean0;
-        dot = dot + n1 * mean1;
-        dot = dot + n2 * mean2;
-        const float d = -dot;
-        thd = (float)(P.czm.th_dist - (double)d);
-    }
-
+__device__ __forceinline__ void fit_finish(const DevParams& P, const Arena& A, int s, int p, int n, int zone, int ring,
+                                           int concentric_idx, const FitState& F) {
+    const float n0 = F.n0, n1 = F.n1, n2 = F.n2, thd = F.thd, mean0 = F.mean0, mean1 = F.mean1, mean2 = F.mean2;
+    const float sv0 = F.sv0, sv1 = F.sv1, sv2 = F.sv2;
     // ---- gating (patchwork.h:339-384) ----
     int status;
     {
@@ -726,6 +675,329 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
     A.planes[s * kMaxPatches + p] = pl;
     A.fit_thd[s * kMaxPatches + p] = thd;
 }
+
+// Every lane owns one patch (the fp32 sums of the fit are strictly sequential, so a patch cannot be
+// split across lanes), but the wave READS cooperatively: per step it copies the next kFitCh points of
+// each of its 64 patches into LDS with contiguous 192-byte runs per patch, and every lane then consumes
+// its own row.  A lane-per-patch walk straight from global memory touches 64 different cache lines per
+// load instruction and was bound by the L1/TA, not by HBM.
+constexpr int kFitCh = 16;               // points per patch per step
+constexpr int kFitRow = kFitCh * 3;      // dwords per patch per step
+constexpr int kFitQuads = kFitRow / 4;   // 16-byte quads per row (12)
+constexpr int kFitStride = kFitRow + 4;  // row stride 52 dwords: 16-byte aligned rows, b128 row accesses of 8
+                                         // consecutive lanes cover all 32 banks once
+constexpr int kFitLoads = kFitQuads;     // 64 lanes x 12 quad loads cover 64 rows x 12 quads
+
+typedef float fitq_mem __attribute__((ext_vector_type(4), aligned(4)));  // rows start on any point boundary
+typedef float fitq __attribute__((ext_vector_type(4)));
+
+struct FitTile {
+    fitq row[64 * kFitStride / 4];
+    uint32_t start[64];  // first point of the lane's patch in sorted_xyz (units of points)
+    int n[64];
+};
+
+// fetch step `c` of all 64 patches into registers (12 quads per lane): load j covers quad f = j * 64 + lane
+// = row f / 12, quad f % 12.  A quad is fetched when its first dword belongs to the patch; its tail may run up to
+// 12 bytes into whatever follows (never consumed: the consumers test the point index).
+__device__ __forceinline__ void fit_fetch(const FitTile& T, const float* __restrict__ src, int c, int lane, fitq (&r)[kFitLoads]) {
+#pragma unroll
+    for (int j = 0; j < kFitLoads; ++j) {
+        const int f = j * 64 + lane;
+        const int pp = f / kFitQuads;
+        const int w = (f - pp * kFitQuads) * 4;
+        const int pt = c * kFitCh + w / 3;
+        fitq v = {0.f, 0.f, 0.f, 0.f};
+        if (pt < T.n[pp]) v = *(const fitq_mem*)(src + ((size_t)T.start[pp] * 3 + (size_t)(c * kFitRow + w)));
+        r[j] = v;
+    }
+}
+__device__ __forceinline__ void fit_store(FitTile& T, int lane, const fitq (&r)[kFitLoads]) {
+#pragma unroll
+    for (int j = 0; j < kFitLoads; ++j) {
+        const int f = j * 64 + lane;
+        const int pp = f / kFitQuads;
+        const int w4 = f - pp * kFitQuads;
+        T.row[pp * (kFitStride / 4) + w4] = r[j];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
+    __shared__ FitTile T;
+    const int lane = threadIdx.x;
+    int lo, hi;
+    order_range(A.order_off, 0, kClassFitCoop - 1, lo, hi);  // the larger patches go to k_pw_fit_coop
+    const int t = lo + blockIdx.x * 64 + lane;
+    if (lo + blockIdx.x * 64 >= hi) return;
+    const bool live = t < hi;
+    const int4 item = live ? A.order[t] : make_int4(0, 0, 0, 0);
+    const int code = item.x;
+    const int s = code / kMaxPatches, p = code - s * kMaxPatches;
+    const int n = live ? item.y : 0;
+    T.start[lane] = (uint32_t)(item.z + item.w);
+    T.n[lane] = n;
+    int n_max = n;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_max = max(n_max, __shfl_xor(n_max, d));
+    const int n_steps = (n_max + kFitCh - 1) / kFitCh;
+    const float* __restrict__ src = (const float*)A.sorted_xyz;
+    const fitq* myq = T.row + lane * (kFitStride / 4);
+    __syncthreads();
+
+    int zone = 0;
+    while (zone < 3 && p >= P.czm.patch_base[zone + 1]) ++zone;
+    const int ring = (p - P.czm.patch_base[zone]) / P.czm.num_sectors[zone];
+    int concentric_idx = ring;
+    for (int k = 0; k < zone; ++k) concentric_idx += P.czm.num_rings[k];
+
+    fitq regs[kFitLoads];
+    float my[kFitRow];
+
+    // ---- extract_initial_seeds_ (patchwork.h:235-268): skip the too-low prefix (zone 0), mean z of the
+    // next num_lpr points ----
+    double sum = 0;
+    int cnt = 0;
+    {
+        bool skipping = (zone == 0);
+        bool busy = n > 0;
+        fit_fetch(T, src, 0, lane, regs);
+        for (int c = 0; c < n_steps; ++c) {
+            fit_store(T, lane, regs);
+            __syncthreads();
+            if (c + 1 < n_steps) fit_fetch(T, src, c + 1, lane, regs);
+            if (busy) {
+#pragma unroll
+                for (int g = 0; g < kFitQuads; ++g) {
+                    const fitq v = myq[g];
+                    my[4 * g] = v.x;
+                    my[4 * g + 1] = v.y;
+                    my[4 * g + 2] = v.z;
+                    my[4 * g + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < kFitCh; ++k) {
+                    const float z = my[3 * k + 2];
+                    const bool valid = (c * kFitCh + k < n);
+                    if (skipping && !(valid && (double)z < P.czm.seed_margin_z)) skipping = false;
+                    if (valid && !skipping && cnt < P.czm.num_lpr) {
+                        sum += (double)z;
+                        ++cnt;
+                    }
+                }
+                if ((!skipping && cnt >= P.czm.num_lpr) || (c + 1) * kFitCh >= n) busy = false;
+            }
+            __syncthreads();
+            if (!__any(busy)) break;
+        }
+    }
+    const double lpr = cnt != 0 ? sum / cnt : 0.0;
+    const double seed_thr = lpr + P.czm.th_seeds;
+
+    FitState F;
+    fit_state_init(F);
+
+    for (int iter = 0; iter < P.czm.num_iter; ++iter) {
+        const float n0 = F.n0, n1 = F.n1, n2 = F.n2, thd = F.thd;
+        // pcl::computeMeanAndCovarianceMatrix over the current ground set, strictly in z order.  Membership
+        // is a select; adding +0.0f is exact here because the accumulators can never be -0.0f.
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f, a8 = 0.f;
+        int m = 0;
+        bool busy = n > 0;
+        fit_fetch(T, src, 0, lane, regs);
+        for (int c = 0; c < n_steps; ++c) {
+            fit_store(T, lane, regs);
+            __syncthreads();
+            if (c + 1 < n_steps) fit_fetch(T, src, c + 1, lane, regs);  // in flight while this step is summed
+            if (busy) {
+#pragma unroll
+                for (int g = 0; g < kFitQuads; ++g) {
+                    const fitq v = myq[g];
+                    my[4 * g] = v.x;
+                    my[4 * g + 1] = v.y;
+                    my[4 * g + 2] = v.z;
+                    my[4 * g + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < kFitCh; ++k) {
+                    Xyz q;
+                    q.x = my[3 * k];
+                    q.y = my[3 * k + 1];
+                    q.z = my[3 * k + 2];
+                    bool in = (c * kFitCh + k < n);
+                    if (iter == 0)
+                        in = in && ((double)q.z < seed_thr);
+                    else
+                        in = in && (plane_res(q, n0, n1, n2) < thd);
+                    const float t0 = q.x * q.x, t1 = q.x * q.y, t2 = q.x * q.z, t3 = q.y * q.y, t4 = q.y * q.z,
+                                t5 = q.z * q.z;
+                    a0 += in ? t0 : 0.f;
+                    a1 += in ? t1 : 0.f;
+                    a2 += in ? t2 : 0.f;
+                    a3 += in ? t3 : 0.f;
+                    a4 += in ? t4 : 0.f;
+                    a5 += in ? t5 : 0.f;
+                    a6 += in ? q.x : 0.f;
+                    a7 += in ? q.y : 0.f;
+                    a8 += in ? q.z : 0.f;
+                    m += in ? 1 : 0;
+                }
+                if ((c + 1) * kFitCh >= n) busy = false;
+                // seeds are a prefix of the z-sorted patch: once the last point of a step fails, the rest fail
+                if (iter == 0 && busy && !((double)my[3 * (kFitCh - 1) + 2] < seed_thr)) busy = false;
+            }
+            __syncthreads();
+            if (!__any(busy)) break;
+        }
+        fit_update(F, P.czm, a0, a1, a2, a3, a4, a5, a6, a7, a8, m);
+    }
+    if (!live) return;
+
+    fit_finish(P, A, s, p, n, zone, ring, concentric_idx, F);
+}
+
+// Patches of kFitCoopMin points or more: a lane per patch leaves the chip almost empty (a K64 scan has ~40 such
+// patches holding 80 % of its points) and runs each of them as one dependent chain thousands of points long.  Here
+// 16 lanes share a patch: each step they test 16 points and form the 9 products in parallel, pass them through LDS
+// transposed, and lanes 0..8 of the group add "their" accumulator over the 16 points IN ORDER -- the sums are the
+// same sequential fp32 sums, only the nine independent chains run on nine lanes instead of one.
+constexpr int kFitCoopPF = 8;  // steps of 16 points in flight per group
+__global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
+    __shared__ fitq tile[4 * 9 * 4];  // [group][accumulator][16 points]
+    const int lane = threadIdx.x, g = lane >> 4, r = lane & 15, gbase = g << 4;
+    int lo, hi;
+    order_range(A.order_off, kClassFitCoop, 63, lo, hi);
+    if (lo + blockIdx.x * 4 >= hi) return;
+    const int w = lo + blockIdx.x * 4 + g;
+    const bool live = w < hi;
+    const int4 item = live ? A.order[w] : make_int4(0, 0, 0, 0);
+    const int code = item.x;
+    const int s = code / kMaxPatches, p = code - s * kMaxPatches;
+    const int n = live ? item.y : 0;
+    const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)item.z + item.w;
+    int n_max = n;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_max = max(n_max, __shfl_xor(n_max, d));
+    const int n_blocks = (n_max + 16 * kFitCoopPF - 1) / (16 * kFitCoopPF);
+
+    int zone = 0;
+    while (zone < 3 && p >= P.czm.patch_base[zone + 1]) ++zone;
+    const int ring = (p - P.czm.patch_base[zone]) / P.czm.num_sectors[zone];
+    int concentric_idx = ring;
+    for (int k = 0; k < zone; ++k) concentric_idx += P.czm.num_rings[k];
+
+    // ---- extract_initial_seeds_ (patchwork.h:235-268) ----
+    int init_idx = 0;
+    {
+        bool searching = live && (zone == 0);
+        for (int c = 0; __any(searching); ++c) {
+            if (searching) {
+                const int j = c * 16 + r;
+                const bool low = (j < n) && ((double)sp[j].z < P.czm.seed_margin_z);
+                const uint32_t m16 = (uint32_t)(__ballot(low) >> gbase) & 0xffffu;
+                if (m16 != 0xffffu) {
+                    init_idx = c * 16 + __builtin_ctz(~m16);
+                    searching = false;
+                }
+            }
+        }
+    }
+    double sum = 0;
+    int cnt = 0;
+    for (int i0 = 0; i0 < P.czm.num_lpr; i0 += 16) {
+        const int j = init_idx + i0 + r;
+        const float zc = (j < n) ? sp[j].z : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float z = __shfl(zc, gbase + k);
+            if (i0 + k < P.czm.num_lpr && init_idx + i0 + k < n) {
+                sum += (double)z;
+                ++cnt;
+            }
+        }
+    }
+    const double lpr = cnt != 0 ? sum / cnt : 0.0;
+    const double seed_thr = lpr + P.czm.th_seeds;
+
+    FitState F;
+    fit_state_init(F);
+    float* tf = (float*)tile;
+    const int acc_row = (g * 9 + (r < 9 ? r : 8)) * 4;  // lanes 9..15 shadow accumulator 8
+
+    for (int iter = 0; iter < P.czm.num_iter; ++iter) {
+        const float n0 = F.n0, n1 = F.n1, n2 = F.n2, thd = F.thd;
+        float acc = 0.f;
+        int m = 0;
+        bool busy = n > 0;
+        Xyz cur[kFitCoopPF], nxt[kFitCoopPF];
+#pragma unroll
+        for (int k = 0; k < kFitCoopPF; ++k) cur[k] = sp[min(k * 16 + r, max(n - 1, 0))];
+        for (int b = 0; b < n_blocks; ++b) {
+            const int j0 = b * 16 * kFitCoopPF;
+            if (busy) {
+#pragma unroll
+                for (int k = 0; k < kFitCoopPF; ++k) nxt[k] = sp[min(j0 + (kFitCoopPF + k) * 16 + r, n - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < kFitCoopPF; ++k) {
+                const Xyz q = cur[k];
+                const int j = j0 + k * 16 + r;
+                bool in = busy && (j < n);
+                bool fails = false;
+                if (iter == 0) {
+                    fails = in && !((double)q.z < seed_thr);
+                    in = in && !fails;
+                } else {
+                    in = in && (plane_res(q, n0, n1, n2) < thd);
+                }
+                const float t0 = q.x * q.x, t1 = q.x * q.y, t2 = q.x * q.z, t3 = q.y * q.y, t4 = q.y * q.z, t5 = q.z * q.z;
+                float* col = tf + g * 9 * 16 + r;
+                col[0 * 16] = in ? t0 : 0.f;
+                col[1 * 16] = in ? t1 : 0.f;
+                col[2 * 16] = in ? t2 : 0.f;
+                col[3 * 16] = in ? t3 : 0.f;
+                col[4 * 16] = in ? t4 : 0.f;
+                col[5 * 16] = in ? t5 : 0.f;
+                col[6 * 16] = in ? q.x : 0.f;
+                col[7 * 16] = in ? q.y : 0.f;
+                col[8 * 16] = in ? q.z : 0.f;
+                const unsigned long long bin = __ballot(in);
+                m += __popc((uint32_t)(bin >> gbase) & 0xffffu);
+                // seeds are a prefix of the z-sorted patch: the group stops after the step in which one fails
+                const bool stop = (iter == 0) && (((uint32_t)(__ballot(fails) >> gbase) & 0xffffu) != 0u);
+                __syncthreads();
+                const fitq v0 = tile[acc_row], v1 = tile[acc_row + 1], v2 = tile[acc_row + 2], v3 = tile[acc_row + 3];
+                // adding +0.0f for non-members is exact: the accumulators can never be -0.0f
+                acc += v0.x;
+                acc += v0.y;
+                acc += v0.z;
+                acc += v0.w;
+                acc += v1.x;
+                acc += v1.y;
+                acc += v1.z;
+                acc += v1.w;
+                acc += v2.x;
+                acc += v2.y;
+                acc += v2.z;
+                acc += v2.w;
+                acc += v3.x;
+                acc += v3.y;
+                acc += v3.z;
+                acc += v3.w;
+                __syncthreads();
+                if (stop || j0 + (k + 1) * 16 >= n) busy = false;
+            }
+#pragma unroll
+            for (int k = 0; k < kFitCoopPF; ++k) cur[k] = nxt[k];
+            if (!__any(busy)) break;
+        }
+        const float a0 = __shfl(acc, gbase + 0), a1 = __shfl(acc, gbase + 1), a2 = __shfl(acc, gbase + 2),
+                    a3 = __shfl(acc, gbase + 3), a4 = __shfl(acc, gbase + 4), a5 = __shfl(acc, gbase + 5),
+                    a6 = __shfl(acc, gbase + 6), a7 = __shfl(acc, gbase + 7), a8 = __shfl(acc, gbase + 8);
+        fit_update(F, P.czm, a0, a1, a2, a3, a4, a5, a6, a7, a8, m);
+    }
+    if (live && r == 0) fit_finish(P, A, s, p, n, zone, ring, concentric_idx, F);
+}
+
 
 // one wave per (scan, patch): final plane test of every point (patchwork.h:488-501), keeps the
 // z order inside the ground part and the non-ground part, counts what k_emit_offsets needs.
@@ -1656,6 +1928,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_sort_wave, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
         TH_END("pw_sort_small");
         TH_BEGIN("pw_fit");
+        hipLaunchKernelGGL(k_pw_fit_coop, dim3((int)(A.total_pts / kFitCoopMin / 4) + 1), dim3(64), 0, st, P, A);
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");
