@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 #   voxels    : 20 V                                                   -> vx_* kernels
 #   tracking  : 16 N_car + 4 N_car + 64                                -> track_* kernels
 STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter": "patchwork",
-            "pw_sort_small": "patchwork", "pw_sort_mid": "patchwork", "pw_sort_large": "patchwork", "pw_order": "patchwork", "pw_fit": "patchwork",
+            "pw_sort_small": "patchwork", "pw_sort_mid": "patchwork", "pw_sort_large": "patchwork", "pw_order": "patchwork", "pw_fit": "patchwork", "pw_fit_large": "patchwork",
             "pw_arrange": "patchwork", "emit_offsets": "patchwork",
             "emit": "binning", "vx_count": "voxels", "vx_offsets": "voxels", "vx_order": "voxels", "vx_scatter": "voxels",
             "vx_bucket_small": "voxels", "vx_bucket_mid": "voxels", "vx_bucket_large": "voxels", "vx_final_offsets": "voxels",

@@ -377,8 +377,11 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 // ------------------------------------------------------------------------------------------
 // size classes (pw_size_class) that bound the sort tiers: class 40 <=> n >= 1024, class 48 <=> n >= 4096
 constexpr int kClassXS = 32, kClassM = 40, kClassM2 = 44, kClassL = 48;  // n >= 256 / 1024 / 2048 / 4096
-constexpr int kClassFitCoop = 36;   // n >= 512: plane fit by 16 lanes per patch (k_pw_fit_coop)
-constexpr int kFitCoopMin = 512;
+#ifndef SCVOD_FIT_COOP_CLASS
+#define SCVOD_FIT_COOP_CLASS 36
+#endif
+constexpr int kClassFitCoop = SCVOD_FIT_COOP_CLASS;  // 36: n >= 512: plane fit by 16 lanes per patch (k_pw_fit_coop)
+constexpr int kFitCoopMin = 1 << (kClassFitCoop / 4);
 
 // order[] lists live items by descending size class; positions of classes [C_LO, C_HI]
 __device__ __forceinline__ void order_range(const int32_t* off, int c_lo, int c_hi, int& lo, int& hi) {
@@ -920,6 +923,7 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
 
     FitState F;
     fit_state_init(F);
+    const int n_last = max(n - 1, 0);
     float* tf = (float*)tile;
     const int acc_row = (g * 9 + (r < 9 ? r : 8)) * 4;  // lanes 9..15 shadow accumulator 8
 
@@ -930,13 +934,13 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
         bool busy = n > 0;
         Xyz cur[kFitCoopPF], nxt[kFitCoopPF];
 #pragma unroll
-        for (int k = 0; k < kFitCoopPF; ++k) cur[k] = sp[min(k * 16 + r, max(n - 1, 0))];
+        for (int k = 0; k < kFitCoopPF; ++k) cur[k] = sp[min(k * 16 + r, n_last)];
         for (int b = 0; b < n_blocks; ++b) {
             const int j0 = b * 16 * kFitCoopPF;
-            if (busy) {
+            // unconditional (clamped) loads: a load under a branch would have to land before the branch joins, which
+            // serialises the whole block behind one memory latency
 #pragma unroll
-                for (int k = 0; k < kFitCoopPF; ++k) nxt[k] = sp[min(j0 + (kFitCoopPF + k) * 16 + r, n - 1)];
-            }
+            for (int k = 0; k < kFitCoopPF; ++k) nxt[k] = sp[min(j0 + (kFitCoopPF + k) * 16 + r, n_last)];
 #pragma unroll
             for (int k = 0; k < kFitCoopPF; ++k) {
                 const Xyz q = cur[k];
@@ -964,7 +968,9 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
                 m += __popc((uint32_t)(bin >> gbase) & 0xffffu);
                 // seeds are a prefix of the z-sorted patch: the group stops after the step in which one fails
                 const bool stop = (iter == 0) && (((uint32_t)(__ballot(fails) >> gbase) & 0xffffu) != 0u);
-                __syncthreads();
+                // the LDS unit executes one wave's instructions in order, so the rows written above are what the reads
+                // below see; only the compiler has to be kept from reordering them
+                __builtin_amdgcn_wave_barrier();
                 const fitq v0 = tile[acc_row], v1 = tile[acc_row + 1], v2 = tile[acc_row + 2], v3 = tile[acc_row + 3];
                 // adding +0.0f for non-members is exact: the accumulators can never be -0.0f
                 acc += v0.x;
@@ -983,7 +989,7 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
                 acc += v3.y;
                 acc += v3.z;
                 acc += v3.w;
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
                 if (stop || j0 + (k + 1) * 16 >= n) busy = false;
             }
 #pragma unroll
@@ -1927,8 +1933,10 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
                            sort_lds_bytes(256), st, P, A);
         hipLaunchKernelGGL(k_pw_sort_wave, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
         TH_END("pw_sort_small");
-        TH_BEGIN("pw_fit");
+        TH_BEGIN("pw_fit_large");
         hipLaunchKernelGGL(k_pw_fit_coop, dim3((int)(A.total_pts / kFitCoopMin / 4) + 1), dim3(64), 0, st, P, A);
+        TH_END("pw_fit_large");
+        TH_BEGIN("pw_fit");
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");

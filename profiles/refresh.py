@@ -35,7 +35,7 @@ def load(path):
 
 
 def label(k):
-    m = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit",
+    m = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_pw_fit_coop": "pw_fit_large",
          "k_pw_arrange": "pw_arrange", "k_emit_offsets": "emit_offsets", "k_emit": "emit", "k_vx_count": "vx_count",
          "k_vx_offsets": "vx_offsets", "k_vx_scatter": "vx_scatter", "k_vx_final_offsets": "vx_final_offsets",
          "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_pw_sort_wave": "pw_sort_small"}
