@@ -45,6 +45,7 @@ struct scvod_ctx {
     int32_t* t_uniq = nullptr;
     int32_t* t_begin = nullptr;
     int32_t* t_pair = nullptr;
+    int32_t* t_pairpt = nullptr;
     int32_t* t_count = nullptr;
     float* t_T = nullptr;
     // last batch
@@ -170,6 +171,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     c->t_uniq = k.take<int32_t>(N);
     c->t_begin = k.take<int32_t>(N + 1);
     c->t_pair = k.take<int32_t>(N);
+    c->t_pairpt = k.take<int32_t>(B + 1);
     c->t_count = k.take<int32_t>(N);
     c->t_T = k.take<float>(12 * (B + 1));
     *total = align_up(k.off, 256);
@@ -764,9 +766,15 @@ int scvod_batch_track(scvod_ctx* c, const int32_t* d_members, const int32_t* h_c
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
     c->tim_used = 0;
-    std::vector<int32_t> pair(n_clusters > 0 ? n_clusters : 1);
-    for (int p = 0; p < n_pairs; ++p)
+    std::vector<int32_t> pair(n_clusters > 0 ? n_clusters : 1), pair_pt(n_pairs + 1);
+    int32_t max_pair_pts = 0;
+    for (int p = 0; p < n_pairs; ++p) {
         for (int k = h_pair_cluster_begin[p]; k < h_pair_cluster_begin[p + 1]; ++k) pair[k] = p;
+        pair_pt[p] = h_cluster_begin[h_pair_cluster_begin[p]];
+        pair_pt[p + 1] = h_cluster_begin[h_pair_cluster_begin[p + 1]];
+        if (pair_pt[p + 1] - pair_pt[p] > max_pair_pts) max_pair_pts = pair_pt[p + 1] - pair_pt[p];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->t_pairpt, pair_pt.data(), sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_begin, h_cluster_begin, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
     if (n_clusters) HIPCHK(c, hipMemcpyAsync(c->t_pair, pair.data(), sizeof(int32_t) * n_clusters, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_T, h_T, sizeof(float) * 12 * n_pairs, hipMemcpyHostToDevice, st));
@@ -778,6 +786,9 @@ int scvod_batch_track(scvod_ctx* c, const int32_t* d_members, const int32_t* h_c
     J.n_clusters = n_clusters;
     J.n_pts = n_pts;
     J.cluster_pair = c->t_pair;
+    J.pair_pt_begin = c->t_pairpt;
+    J.n_pairs = n_pairs;
+    J.max_pair_pts = max_pair_pts;
     J.T = c->t_T;
     J.hit_slot = c->t_hit;
     J.work = c->t_work;

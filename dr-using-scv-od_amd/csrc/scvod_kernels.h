@@ -114,6 +114,8 @@ struct TrackJob {          // scan-vs-next-scan probe
     // per cluster: which transform / which source scan / which next table
     const int32_t* cluster_pair;   // [n_clusters] pair index (0 for the single-pair API)
     const float* T;                // [n_pairs][12]
+    const int32_t* pair_pt_begin;  // batch mode: [n_pairs+1] first point (offset into members) of every pair
+    int32_t n_pairs, max_pair_pts;
     // next tables: explicit (single pair) or arena scans (batch)
     const int32_t* next_keys;      // explicit table or nullptr
     const int32_t* next_labels;    // explicit labels or nullptr (= all labelled)

@@ -1740,6 +1740,63 @@ __global__ __launch_bounds__(256) void k_track_probe(DevParams P, Arena A, Track
     J.hit_slot[k] = slot;
 }
 
+// Batch form of the probe: blockIdx.y = scan pair, so the block can stage the next scan's voxel keys in LDS once
+// and run every binary search there (eleven dependent L2 round trips per point otherwise).
+constexpr int kTrackLdsKeys = 8192;
+__global__ __launch_bounds__(256) void k_track_probe_pair(DevParams P, Arena A, TrackJob J, int batch_mode) {
+    __shared__ int32_t skeys[kTrackLdsKeys];
+    const int pair = blockIdx.y;
+    const int k0 = J.pair_pt_begin[pair], k1 = J.pair_pt_begin[pair + 1];
+    if (k0 + (int)blockIdx.x * 256 >= k1) return;
+    const int sb = A.scan_off[pair];
+    const int nb = A.scan_off[pair + 1];
+    const int nv = A.counts[(pair + 1) * 8 + 6];
+    const int32_t* gkeys = A.vox_key + nb;
+    const bool in_lds = nv <= kTrackLdsKeys;
+    if (in_lds)
+        for (int i = threadIdx.x; i < nv; i += 256) skeys[i] = gkeys[i];
+    __syncthreads();
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = J.T[12 * pair + i];
+    for (int k = k0 + blockIdx.x * 256 + threadIdx.x; k < k1; k += gridDim.x * 256) {
+        float4 q;
+        if (batch_mode == 1) {  // members are apri_vec indices; the point itself is read through apri_src
+            q = A.pts[sb + A.apri_src[(size_t)sb + J.members[k]]];
+        } else {  // apri_vec supplied by the caller (no input cloud on the device)
+            const scvod_apri& a = A.apri[(size_t)sb + J.members[k]];
+            q = make_float4(a.x, a.y, a.z, a.intensity);
+        }
+        // Utility::transformCloud (utility.h:401-404): explicit fp32 dot products, no FMA
+        float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
+        float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
+        float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
+        Apri a;
+        apri_of_point(P.bin, x, y, z, q.w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
+        const int key = a.voxel_idx;
+        int lo = 0, hi = nv;
+        if (in_lds) {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (skeys[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            J.hit_slot[k] = (lo < nv && skeys[lo] == key) ? lo : -1;
+        } else {
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (gkeys[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            J.hit_slot[k] = (lo < nv && gkeys[lo] == key) ? lo : -1;
+        }
+    }
+}
+
 // sampleVec of the hit list of every cluster (ssc.cpp:1319-1321) without a sort: the hits are slots of the next
 // scan's voxel table, so a per-cluster bitset over the table (LDS) gives the sorted unique list directly.
 constexpr int kTrackBitWords = 8192;  // 262144 table slots; larger tables take the sort path below
@@ -2053,7 +2110,12 @@ void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int bat
                   TimerHook th, void* tu) {
     if (J.n_pts > 0) {
         TH_BEGIN("track_probe");
-        hipLaunchKernelGGL(k_track_probe, dim3((J.n_pts + 255) / 256), dim3(256), 0, st, P, A, J, batch_mode);
+        if (batch_mode && J.pair_pt_begin && !J.next_labels) {
+            const int bx = (J.max_pair_pts + 1023) / 1024;  // four points per thread amortise the key staging
+            hipLaunchKernelGGL(k_track_probe_pair, dim3(bx > 0 ? bx : 1, J.n_pairs), dim3(256), 0, st, P, A, J, batch_mode);
+        } else {
+            hipLaunchKernelGGL(k_track_probe, dim3((J.n_pts + 255) / 256), dim3(256), 0, st, P, A, J, batch_mode);
+        }
         TH_END("track_probe");
     }
     if (J.n_clusters > 0) {
