@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
     for (int iter = 0; iter < P.czm.num_iter; ++iter) {
         const float n0 = F.n0, n1 = F.n1, n2 = F.n2, thd = F.thd;
         float acc = 0.f;
-        int m = 0;
+        int m_lane = 0;
         bool busy = n > 0;
         Xyz cur[kFitCoopPF], nxt[kFitCoopPF];
 #pragma unroll
@@ -953,19 +953,19 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
                 } else {
                     in = in && (plane_res(q, n0, n1, n2) < thd);
                 }
-                const float t0 = q.x * q.x, t1 = q.x * q.y, t2 = q.x * q.z, t3 = q.y * q.y, t4 = q.y * q.z, t5 = q.z * q.z;
+                // non-members contribute +0.0f to every sum: zero the point, the products follow (0 * 0 = +0)
+                const float zx = in ? q.x : 0.f, zy = in ? q.y : 0.f, zz = in ? q.z : 0.f;
                 float* col = tf + g * 9 * 16 + r;
-                col[0 * 16] = in ? t0 : 0.f;
-                col[1 * 16] = in ? t1 : 0.f;
-                col[2 * 16] = in ? t2 : 0.f;
-                col[3 * 16] = in ? t3 : 0.f;
-                col[4 * 16] = in ? t4 : 0.f;
-                col[5 * 16] = in ? t5 : 0.f;
-                col[6 * 16] = in ? q.x : 0.f;
-                col[7 * 16] = in ? q.y : 0.f;
-                col[8 * 16] = in ? q.z : 0.f;
-                const unsigned long long bin = __ballot(in);
-                m += __popc((uint32_t)(bin >> gbase) & 0xffffu);
+                col[0 * 16] = zx * zx;
+                col[1 * 16] = zx * zy;
+                col[2 * 16] = zx * zz;
+                col[3 * 16] = zy * zy;
+                col[4 * 16] = zy * zz;
+                col[5 * 16] = zz * zz;
+                col[6 * 16] = zx;
+                col[7 * 16] = zy;
+                col[8 * 16] = zz;
+                m_lane += in ? 1 : 0;
                 // seeds are a prefix of the z-sorted patch: the group stops after the step in which one fails
                 const bool stop = (iter == 0) && (((uint32_t)(__ballot(fails) >> gbase) & 0xffffu) != 0u);
                 // the LDS unit executes one wave's instructions in order, so the rows written above are what the reads
@@ -996,6 +996,9 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
             for (int k = 0; k < kFitCoopPF; ++k) cur[k] = nxt[k];
             if (!__any(busy)) break;
         }
+        int m = m_lane;  // members seen by this lane -> members of the group's patch
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) m += __shfl_xor(m, d);
         const float a0 = __shfl(acc, gbase + 0), a1 = __shfl(acc, gbase + 1), a2 = __shfl(acc, gbase + 2),
                     a3 = __shfl(acc, gbase + 3), a4 = __shfl(acc, gbase + 4), a5 = __shfl(acc, gbase + 5),
                     a6 = __shfl(acc, gbase + 6), a7 = __shfl(acc, gbase + 7), a8 = __shfl(acc, gbase + 8);
