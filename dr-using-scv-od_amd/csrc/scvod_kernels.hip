@@ -1029,13 +1029,17 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
         // (element r of the non-ground part lives at seg[n - 1 - r]; k_emit reads it that way)
         int n_g = 0, n_ng = 0, a_g = 0, a_ng = 0;
         uint32_t* seg = A.seg + (size_t)base + off;
+        // the next 64 points are in flight while this step is classified (clamped, unconditional loads)
+        Xyz q_next = sp[min(lane, n - 1)];
+        uint32_t w_next = si[min(lane, n - 1)];
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             int g = 0, keep = 0;
-            uint32_t w = 0;
+            const Xyz q = q_next;
+            uint32_t w = w_next;
+            q_next = sp[min(j + 64, n - 1)];
+            w_next = si[min(j + 64, n - 1)];
             if (j < n) {
-                const Xyz q = sp[j];
-                w = si[j];
                 g = plane_res(q, n0, n1, n2) < thd;
                 // range/FOV verdict of makeApriVec, only for points that reach the non-ground stream
                 if (!g || rejected) {
@@ -1146,14 +1150,26 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
         // by the non-ground part; the latter is stored back to front by k_pw_arrange
         const int e0 = kept ? r.n_g : 0;
         int run_keep = 0;
-        auto seg_at = [&](int e) -> uint32_t {
-            return (e < r.n) ? ((e < r.n_g) ? seg[e] : seg[r.n - 1 - (e - r.n_g)]) : 0u;
+        auto seg_at = [&](int e) -> uint32_t {  // clamped, unconditional load (callers test e < r.n)
+            const int k = (e < r.n_g) ? e : r.n - 1 - (e - r.n_g);
+            return seg[min(max(k, 0), r.n - 1)];
         };
-        uint32_t v_next = seg_at(e0 + lane);
+        // two steps of seg words and one step of point gathers are in flight while a step is emitted; lanes that keep
+        // nothing gather the scan's first point (one shared line) so the load needs no branch
+        auto gather = [&](uint32_t v, int e) -> float4 {
+            const bool k = (e < r.n) && (v >> 31);
+            return A.pts[base + (k ? (v & 0x7fffffffu) : 0u)];
+        };
+        uint32_t v0 = seg_at(e0 + lane), v1 = seg_at(e0 + 64 + lane);
+        float4 q0 = gather(v0, e0 + lane);
         for (int c0 = e0; c0 < r.n; c0 += 64) {
             const int e = c0 + lane;
-            const uint32_t v = v_next;
-            v_next = seg_at(e + 64);  // next step's word is in flight while this step computes
+            const uint32_t v = v0;
+            const float4 q = q0;
+            const uint32_t v2 = seg_at(e + 128);
+            q0 = gather(v1, e + 64);
+            v0 = v1;
+            v1 = v2;
             const int keep = (e < r.n) ? (int)(v >> 31) : 0;
             const unsigned long long bk = __ballot(keep);
             const int ek = __popcll(bk & ((1ull << lane) - 1ull));
@@ -1164,7 +1180,6 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                 const int spos = e - e0;  // position in the non-ground stream of this patch
                 A.nonground_idx[(size_t)base + xng + spos] = (int32_t)id;
                 if (keep) {
-                    const float4 q = A.pts[base + id];
                     Apri a;
                     apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
                     // apri_vec is kept in its compact form (source index, voxel key, intensity); the 44-byte
