@@ -205,7 +205,7 @@ def main():
         x.set_timing(False)
 
     # "next" row 8(f)-1, reported separately (not part of `value`): curved-voxel clustering on the resident batch
-    cc_ms = None
+    cc_ms = ct_ms = None
     try:
         barrier()
         t1 = time.perf_counter()
@@ -219,8 +219,15 @@ def main():
             c["ctx"].batch_cluster(stream=c["stream"], sync=False)
         barrier()
         cc_ms = 1e3 * ((time.perf_counter() - t1) - t_proc)
+        t1 = time.perf_counter()
+        for c in chunks:  # 8(f)-2: bounding boxes + type rules on top of the clusters
+            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
+            c["ctx"].batch_cluster(stream=c["stream"], sync=False)
+            c["ctx"].batch_cluster_types(stream=c["stream"], sync=False)
+        barrier()
+        ct_ms = 1e3 * ((time.perf_counter() - t1) - t_proc) - cc_ms
     except Exception as e:  # never let the optional stage break the bench line
-        cc_ms = None
+        cc_ms = ct_ms = None
     dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, args.scans, total_pts)
 
     if rank == 0:
@@ -299,7 +306,7 @@ def main():
                           "car_points_per_scan": tot_car / args.scans, "car_clusters": "pseudo" if args.pseudo_clusters else "gpu clustering + bbox rules", "sharding": f"1 sequence per GPU x{world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
-               "extras": {"cluster_ms_per_sequence": cc_ms, "cpu_all_threads": cpu_all}}
+               "extras": {"cluster_ms_per_sequence": cc_ms, "cluster_types_ms_per_sequence": ct_ms, "cpu_all_threads": cpu_all}}
         print(json.dumps(out))
     for x in ctxs:
         x.close()

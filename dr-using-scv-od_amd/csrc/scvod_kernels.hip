@@ -1649,21 +1649,59 @@ __global__ __launch_bounds__(256) void k_cc_bbox_init(Arena A) {
     }
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+
+// Neighbouring apri points mostly belong to the same cluster, so the wave first reduces box and member count per
+// distinct cluster it holds and only one lane per cluster touches the global record (a 20 000-point cluster would
+// otherwise serialise 140 000 atomics on seven words).
 __global__ __launch_bounds__(256) void k_cc_bbox(Arena A) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const scvod_apri& a = A.apri[(size_t)base + i];
-        const int r = A.pt_cluster[(size_t)base + i];
-        uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + r);
-        atomicMin(&bb[0], f2ord(a.x));
-        atomicMin(&bb[1], f2ord(a.y));
-        atomicMin(&bb[2], f2ord(a.z));
-        atomicMax(&bb[3], f2ord(a.x));
-        atomicMax(&bb[4], f2ord(a.y));
-        atomicMax(&bb[5], f2ord(a.z));
-        atomicAdd(&A.cl_count[(size_t)base + r], 1);
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        const bool valid = i < n;
+        int r = -1;
+        uint32_t ox = 0, oy = 0, oz = 0;
+        if (valid) {
+            const scvod_apri& a = A.apri[(size_t)base + i];
+            r = A.pt_cluster[(size_t)base + i];
+            ox = f2ord(a.x);
+            oy = f2ord(a.y);
+            oz = f2ord(a.z);
+        }
+        bool todo = valid;
+        while (__any(todo)) {
+            const int first = __ffsll((long long)__ballot(todo)) - 1;
+            const int r0 = __shfl(r, first);
+            const bool mine = todo && (r == r0);
+            const int cnt = __popcll(__ballot(mine));
+            const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mny = wave_min_u32(mine ? oy : 0xffffffffu),
+                           mnz = wave_min_u32(mine ? oz : 0xffffffffu);
+            const uint32_t mxx = wave_max_u32(mine ? ox : 0u), mxy = wave_max_u32(mine ? oy : 0u),
+                           mxz = wave_max_u32(mine ? oz : 0u);
+            if (lane == first) {
+                uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + r0);
+                if (mnx < bb[0]) atomicMin(&bb[0], mnx);  // a stale read only costs a redundant atomic
+                if (mny < bb[1]) atomicMin(&bb[1], mny);
+                if (mnz < bb[2]) atomicMin(&bb[2], mnz);
+                if (mxx > bb[3]) atomicMax(&bb[3], mxx);
+                if (mxy > bb[4]) atomicMax(&bb[4], mxy);
+                if (mxz > bb[5]) atomicMax(&bb[5], mxz);
+                atomicAdd(&A.cl_count[(size_t)base + r0], cnt);
+            }
+            if (mine) todo = false;
+        }
     }
 }
 

@@ -38,7 +38,7 @@ def label(k):
     m = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_pw_fit_coop": "pw_fit_large",
          "k_pw_arrange": "pw_arrange", "k_emit_offsets": "emit_offsets", "k_emit": "emit", "k_vx_count": "vx_count",
          "k_vx_offsets": "vx_offsets", "k_vx_scatter": "vx_scatter", "k_vx_final_offsets": "vx_final_offsets",
-         "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_pw_sort_wave": "pw_sort_small"}
+         "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_track_probe_pair": "track_probe", "k_pw_sort_wave": "pw_sort_small"}
     if k in m:
         return m[k]
     if k.startswith("k_track_unique"):
@@ -70,8 +70,8 @@ for k in F:
     out["kernels"][k] = {"launches": len(F[k]), "fetch_KB_raw": f, "write_KB_raw": w, "hbm_bytes_per_launch_corrected": b,
                          "hbm_bytes_per_scan": b / scans}
     by[label(k)] += b / scans
-    if k.startswith("k_cc_"):
-        extra += b / scans  # clustering = "next" row, measured by bench.py only as an extra
+    if k.startswith("k_cc_") or k in ("k_apri_expand", "k_cls_from_lists"):
+        extra += b / scans  # clustering = "next" row (bench.py: prep + extras only); expansion kernels run on fetch/clustering
     else:
         total += b / scans
 out["by_bench_label"], out["total_hbm_bytes_per_scan"], out["extras_hbm_bytes_per_scan"] = dict(by), total, extra
