@@ -155,6 +155,47 @@ def test_track_probe_parity(scvod, oracle):
     ctx.close()
 
 
+def test_batch_track_matches_oracle_per_pair(scvod, oracle):
+    """scvod_batch_track (device-resident sequence shard: points read through apri_src, next scan's keys staged in
+    LDS) must count, per cluster, exactly the unique next-scan voxels the oracle's per-pair probe finds."""
+    import torch
+    import synth
+    P = _params(scvod, "semantickitti")
+    count = 4
+    pts, offs, poses, _ = synth.make_batch(5, 420, count, "K64")
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    d = pts.cuda()
+    ctx.batch_process(d, offs)
+    res = [ctx.batch_fetch(s) for s in range(count)]
+    members, cbegin, pbegin, per_pair = [], [0], [0], []
+    for s in range(count - 1):
+        n_a = res[s]["n_apri"]
+        m = np.arange(s % 3, n_a, 3, dtype=np.int32)      # every third apri point, ragged cluster sizes
+        sizes = [37, 500, 1, 1200, 64]
+        k, i, mine = 0, 0, [0]
+        while k < len(m):
+            sz = min(sizes[i % len(sizes)], len(m) - k)
+            k += sz
+            i += 1
+            mine.append(k)
+            cbegin.append(cbegin[-1] + sz)
+        members.append(m)
+        pbegin.append(len(cbegin) - 1)
+        per_pair.append((m, np.asarray(mine, np.int32)))
+    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)])
+    ctx.batch_track(torch.from_numpy(np.concatenate(members)).cuda(), cbegin, pbegin, T)
+    uq = ctx.batch_track_counts()
+    for s in range(count - 1):
+        m, o = per_pair[s]
+        a = res[s]["apri"]
+        xyzi = np.stack([a["x"][m], a["y"][m], a["z"][m], a["intensity"][m]], 1).astype(np.float32)
+        keys = res[s + 1]["vox_key"]
+        _, _, oub = oracle.track_probe(P, xyzi, o, T[s], keys, np.zeros(len(keys), np.int32))
+        assert np.array_equal(uq[pbegin[s]:pbegin[s + 1]], np.diff(oub)), f"pair {s}"
+    assert uq.sum() > 0
+    ctx.close()
+
+
 def test_nn_search_parity(scvod, oracle):
     rng = np.random.default_rng(11)
     m = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
