@@ -287,6 +287,8 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
         if (n < 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets not monotone");
         if (n > mx) mx = n;
     }
+    if (mx > SCVOD_MAX_SCAN_POINTS)
+        return fail(c, SCVOD_ERR_CAPACITY, "scan of %d points > SCVOD_MAX_SCAN_POINTS (%d)", mx, SCVOD_MAX_SCAN_POINTS);
     HIPCHK(c, hipSetDevice(c->device));
     if (!st) st = c->stream;
     c->last_stream = st;

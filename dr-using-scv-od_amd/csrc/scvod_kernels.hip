@@ -179,13 +179,27 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
 // level-per-pass network; no bounds predicates anywhere.
 // ascending compare-exchange of unique unsigned keys; the borrow of x - y is the x < y flag (two full-rate
 // 32-bit VALU ops instead of a 64-bit compare)
+// Sort keys are (32-bit primary key, 19-bit index) packed under a fixed exponent: 0x3ff << 52 | key << 19 | idx.
+// Every key is then a normal double in [1, 2) whose numeric order IS the integer order of (key, idx), so a
+// compare-exchange is one v_min_f64 + one v_max_f64 instead of a 64-bit compare and four selects.  The pad value
+// 2.0 sorts after every key.  (Indices fit because a scan holds at most 2^19 points, include/scvod.h.)
+constexpr int kKeyIdxBits = 19;
+static_assert((1 << kKeyIdxBits) >= SCVOD_MAX_SCAN_POINTS, "index field of the sort keys");
+constexpr unsigned long long kKeyExp = 0x3ffull << 52;
+constexpr unsigned long long kKeyPad = 0x4000000000000000ull;
+__device__ __forceinline__ unsigned long long pack_key(uint32_t key, uint32_t idx) {
+    return kKeyExp | ((unsigned long long)key << kKeyIdxBits) | idx;
+}
+__device__ __forceinline__ uint32_t key_idx(unsigned long long k) { return (uint32_t)k & ((1u << kKeyIdxBits) - 1u); }
+__device__ __forceinline__ uint32_t key_major(unsigned long long k) { return (uint32_t)(k >> kKeyIdxBits); }
+
 __device__ __forceinline__ void cswap_asc(unsigned long long& x, unsigned long long& y) {
-    unsigned long long d;
-    const bool lt = __builtin_usubll_overflow(x, y, &d);
-    const unsigned long long lo = lt ? x : y;
-    const unsigned long long hi = lt ? y : x;
-    x = lo;
-    y = hi;
+    double lo, hi;
+    const double dx = __longlong_as_double((long long)x), dy = __longlong_as_double((long long)y);
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(dx), "v"(dy));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(dx), "v"(dy));
+    x = (unsigned long long)__double_as_longlong(lo);
+    y = (unsigned long long)__double_as_longlong(hi);
 }
 __device__ __forceinline__ void cswap_asc(uint32_t& x, uint32_t& y) {
     const uint32_t lo = x < y ? x : y;
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 #pragma unroll
     for (int it = 0; it < kClsItems; ++it) {
         int i = start + it * kClsThreads + threadIdx.x;
-        if (i < n && pid[it] >= 0) A.keys[(size_t)base + hist[pid[it]] + rank[it]] = ((uint64_t)zk[it] << 32) | (uint32_t)i;
+        if (i < n && pid[it] >= 0) A.keys[(size_t)base + hist[pid[it]] + rank[it]] = pack_key(zk[it], (uint32_t)i);
     }
 }
 
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
             int np2 = 1 << LGE;
             while (np2 < n) np2 <<= 1;
             for (int j = threadIdx.x; j < np2; j += THREADS)
-                keys[sort_slot<true>(j)] = (j < n) ? A.keys[(size_t)base + off + j] : ~0ull;
+                keys[sort_slot<true>(j)] = (j < n) ? A.keys[(size_t)base + off + j] : kKeyPad;
             __syncthreads();
             block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
         } else {
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
         Xyz* dst = A.sorted_xyz + (size_t)base + off;
         uint32_t* dsti = A.sorted_idx + (size_t)base + off;
         for (int j = threadIdx.x; j < n; j += THREADS) {
-            const uint32_t id = (uint32_t)keys[in_lds ? sort_slot<true>(j) : j];
+            const uint32_t id = key_idx(keys[in_lds ? sort_slot<true>(j) : j]);
             const float4 q = A.pts[base + id];
             Xyz o;
             o.x = q.x;
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256) void k_pw_sort_wave(DevParams P, Arena A) {
     for (int w = lo + blockIdx.x * 4 + wave; w < hi; w += gridDim.x * 4) {
         const int4 item = A.order[w];
         const int n = item.y, base = item.z, off = item.w;  // n < 64
-        unsigned long long key = (lane < n) ? A.keys[(size_t)base + off + lane] : ~0ull;
+        unsigned long long key = (lane < n) ? A.keys[(size_t)base + off + lane] : kKeyPad;
 #pragma unroll
         for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256) void k_pw_sort_wave(DevParams P, Arena A) {
             }
         }
         if (lane < n) {
-            const uint32_t id = (uint32_t)key;
+            const uint32_t id = key_idx(key);
             const float4 q = A.pts[base + id];
             Xyz o;
             o.x = q.x;
@@ -1380,7 +1394,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
 #pragma unroll
     for (int it = 0; it < kVxItems; ++it) {
         int i = start + it * kVxThreads + threadIdx.x;
-        if (bk[it] >= 0) A.vkeys[(size_t)base + hist[bk[it]] + rank[it]] = ((uint64_t)vx_bias(key[it]) << 32) | (uint32_t)i;
+        if (bk[it] >= 0) A.vkeys[(size_t)base + hist[bk[it]] + rank[it]] = pack_key(vx_bias(key[it]), (uint32_t)i);
     }
 }
 
@@ -1408,7 +1422,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         int np2 = 1 << LGE;
         while (np2 < m) np2 <<= 1;
         for (int j = threadIdx.x; j < np2; j += THREADS)
-            l_keys[sort_slot<true>(j)] = (j < m) ? A.vkeys[(size_t)base + off + j] : ~0ull;
+            l_keys[sort_slot<true>(j)] = (j < m) ? A.vkeys[(size_t)base + off + j] : kKeyPad;
         __syncthreads();
         keys = l_keys;
         vbeg = l_vbeg;
@@ -1430,8 +1444,8 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
             // never form keys[-1]: with flat addressing that leaves the LDS aperture
             const uint64_t cur = keys[KX(j)];
             const uint64_t prev = keys[KX(j > 0 ? j - 1 : 0)];
-            head = (j == 0) || ((uint32_t)(cur >> 32) != (uint32_t)(prev >> 32));
-            const uint32_t idx = (uint32_t)cur;
+            head = (j == 0) || (key_major(cur) != key_major(prev));
+            const uint32_t idx = key_idx(cur);
             A.vox_pts[(size_t)base + off + j] = (int32_t)idx;
         }
         int th;
@@ -1442,7 +1456,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     __syncthreads();
     const int nv = run;
     if (in_lds) {
-        for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + (uint32_t)keys[KX(j)]];
+        for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + key_idx(keys[KX(j)])];
         __syncthreads();
     }
     // per voxel: sequential fp32 mean, then population variance accumulated as float += double
@@ -1453,18 +1467,18 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         if (in_lds) {
             for (int j = j0; j < j1; ++j) av += ints[j];
         } else {
-            for (int j = j0; j < j1; ++j) av += A.apri_int[(size_t)base + (uint32_t)keys[j]];
+            for (int j = j0; j < j1; ++j) av += A.apri_int[(size_t)base + key_idx(keys[j])];
         }
         const float fn = (float)(j1 - j0);
         av = av / fn;
         float cov = 0.f;
         for (int j = j0; j < j1; ++j) {
-            const float in = in_lds ? ints[j] : A.apri_int[(size_t)base + (uint32_t)keys[j]];
+            const float in = in_lds ? ints[j] : A.apri_int[(size_t)base + key_idx(keys[j])];
             const double d = (double)(in - av);
             cov = (float)((double)cov + d * d);
         }
         cov = cov / fn;
-        A.tmp_vox_key[(size_t)base + off + v] = vx_unbias((uint32_t)(keys[KX(j0)] >> 32));
+        A.tmp_vox_key[(size_t)base + off + v] = vx_unbias(key_major(keys[KX(j0)]));
         A.tmp_vox_cov[(size_t)base + off + v] = cov;
         A.tmp_vox_av[(size_t)base + off + v] = av;
     }

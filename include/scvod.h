@@ -38,6 +38,10 @@ extern "C" {
 #define SCVOD_ERR_CAPACITY (-4)  /* batch larger than the ctx capacity              */
 #define SCVOD_ERR_STATE (-5)     /* call order violated (e.g. fetch before run)     */
 
+/* One scan holds at most 2^19 points (a 128-beam x 2048-column sweep is 262144): sort keys carry the point index in
+ * 19 bits.  Larger scans are refused with SCVOD_ERR_CAPACITY. */
+#define SCVOD_MAX_SCAN_POINTS 524288
+
 #define SCVOD_NUM_ZONES 4
 #define SCVOD_MAX_PATCHES 1024 /* reference model has 504 (patchwork.h:48-49) */
 
