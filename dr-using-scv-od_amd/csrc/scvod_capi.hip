@@ -229,6 +229,7 @@ void build_dev_params(scvod_ctx* c) {
     z.num_lpr = w.num_lpr;
     z.num_min_pts = w.num_min_pts;
     z.num_rings_of_interest = w.num_rings_of_interest;
+    czm_finalize(z);
     D.n_patches = base;
     D.max_z = p.max_z;
     D.min_z = p.min_z;

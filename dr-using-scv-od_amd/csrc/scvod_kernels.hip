@@ -459,8 +459,8 @@ __global__ __launch_bounds__(256) void k_pw_sort_wave(DevParams P, Arena A) {
             for (int j = k >> 1; j >= 1; j >>= 1) {
                 const unsigned long long other = __shfl_xor(key, j, 64);
                 const bool take_min = (((lane & k) == 0) == ((lane & j) == 0));
-                const unsigned long long mn = key < other ? key : other;
-                const unsigned long long mx = key < other ? other : key;
+                unsigned long long mn = key, mx = other;
+                cswap_asc(mn, mx);
                 key = take_min ? mn : mx;
             }
         }

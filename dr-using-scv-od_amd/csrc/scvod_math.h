@@ -385,24 +385,67 @@ struct CzmParams {
     double th_seeds, th_dist, uprightness_thr;
     double elevation_thr[4], flatness_thr[4];
     int32_t num_iter, num_lpr, num_min_pts, num_rings_of_interest;
+    // derived constants of the cheap (fp32 / reciprocal) evaluation, czm_finalize(); they only decide WHEN the cheap
+    // value is trusted, never what the result is
+    int32_t fast_ok;           // ranges small enough for the fp32 error bound below
+    float r_margin;            // |r_fp32 - r_fp64| stays far below this (1.2e-7 * r for r <= 1000 m)
+    float min_range_f, max_range_f, zone_min_f[4], inv_ring_f[4], ring_margin_f[4];
+    double inv_sector[4], sector_margin[4];
 };
+
+inline void czm_finalize(CzmParams& c) {
+    c.fast_ok = (c.max_range <= 1000.0 && c.min_range >= 0.0) ? 1 : 0;
+    c.r_margin = 1.0e-3f;
+    c.min_range_f = (float)c.min_range;
+    c.max_range_f = (float)c.max_range;
+    for (int k = 0; k < 4; ++k) {
+        c.zone_min_f[k] = (float)c.zone_min[k];
+        c.inv_ring_f[k] = (float)(1.0 / c.ring_size[k]);
+        c.ring_margin_f[k] = (float)(2.0e-3 / c.ring_size[k] + 1.0e-4);
+        if (!(c.ring_size[k] > 1.0e-2) || c.num_rings[k] > 256) c.fast_ok = 0;  // keeps (r - zone_min) / ring_size <= 256
+        c.inv_sector[k] = 1.0 / c.sector_size[k];
+        c.sector_margin[k] = 1.0e-6 / c.sector_size[k] + 1.0e-9;
+    }
+}
 
 // patch id in (zone, ring, sector) emission order, or -1 when the point is not binned
 SCVOD_HD int32_t czm_patch_of(const CzmParams& c, float xf, float yf, float zf) {
     if ((double)zf < c.z_cut) return -1;  // erased prefix of the z-sorted cloud (patchwork.h:302-310)
     double x = (double)xf, y = (double)yf;
-    double r = sqrt_d(x * x + y * y);  // pow(x,2) == x*x exactly for float-valued doubles
-    if (!((r <= c.max_range) && (r > c.min_range))) return -1;
-    int k;
-    if (r < c.zone_min[1])
-        k = 0;
-    else if (r < c.zone_min[2])
-        k = 1;
-    else if (r < c.zone_min[3])
-        k = 2;
-    else
-        k = 3;
-    int32_t ring = (int32_t)((r - c.zone_min[k]) / c.ring_size[k]);
+    // Zone and ring from the fp32 radius when it is farther than r_margin from every boundary that matters (its error
+    // against the reference's double sqrt is below 1.3e-7 * r): same decisions, no fp64 sqrt / division.  Points next
+    // to a boundary, NaNs and exotic parameter sets take the reference arithmetic below.
+    int k = -1;
+    int32_t ring = 0;
+    if (c.fast_ok) {
+        const float rf = sqrt_f(xf * xf + yf * yf);
+        const float m = c.r_margin;
+        if (fabs_f(rf - c.max_range_f) > m && fabs_f(rf - c.min_range_f) > m && fabs_f(rf - c.zone_min_f[1]) > m &&
+            fabs_f(rf - c.zone_min_f[2]) > m && fabs_f(rf - c.zone_min_f[3]) > m) {
+            if (!((rf <= c.max_range_f) && (rf > c.min_range_f))) return -1;
+            const int kf = (rf < c.zone_min_f[1]) ? 0 : (rf < c.zone_min_f[2]) ? 1 : (rf < c.zone_min_f[3]) ? 2 : 3;
+            const float v = (rf - c.zone_min_f[kf]) * c.inv_ring_f[kf];
+            const int32_t rv = (int32_t)v;
+            const float fr = v - (float)rv;
+            if (fr > c.ring_margin_f[kf] && fr < 1.0f - c.ring_margin_f[kf]) {
+                k = kf;
+                ring = rv;
+            }
+        }
+    }
+    if (k < 0) {
+        double r = sqrt_d(x * x + y * y);  // pow(x,2) == x*x exactly for float-valued doubles
+        if (!((r <= c.max_range) && (r > c.min_range))) return -1;
+        if (r < c.zone_min[1])
+            k = 0;
+        else if (r < c.zone_min[2])
+            k = 1;
+        else if (r < c.zone_min[3])
+            k = 2;
+        else
+            k = 3;
+        ring = (int32_t)((r - c.zone_min[k]) / c.ring_size[k]);
+    }
     if (ring > c.num_rings[k] - 1) ring = c.num_rings[k] - 1;
     // sector = int(theta / sector_size) with theta = atan2(y, x) in double (+2 pi for y < 0).  The fp32 fdlibm
     // atan2 of the same (float-valued) arguments is within 3e-7 rad of it, so whenever theta_f / sector_size is
@@ -412,10 +455,10 @@ SCVOD_HD int32_t czm_patch_of(const CzmParams& c, float xf, float yf, float zf) 
     {
         double tf = (double)atan2_f32(yf, xf);
         if (y < 0.0) tf += 2.0 * SCVOD_M_PI;
-        const double u = tf / c.sector_size[k];
+        const double u = tf * c.inv_sector[k];  // within 1e-15 of tf / sector_size: far inside the margin
         const int32_t su = (int32_t)u;
         const double fr = u - (double)su;
-        const double margin = 1.0e-6 / c.sector_size[k];
+        const double margin = c.sector_margin[k];
         if (fr > margin && fr < 1.0 - margin) {
             sector = su;
         } else {

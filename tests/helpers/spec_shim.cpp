@@ -48,6 +48,7 @@ void spec_patch_ids(float sensor_height, const float* xyzi, long n, int* pid) {
     for (int k = 0; k < 4; ++k) { c.sector_size[k] = 2 * M_PI / secs[k]; c.num_rings[k] = rings[k]; c.num_sectors[k] = secs[k]; c.patch_base[k] = base; base += rings[k] * secs[k]; }
     c.num_patches = base;
     c.z_cut = -1.8 * (double)sensor_height;
+    scvod::czm_finalize(c);
     for (long i = 0; i < n; ++i) pid[i] = scvod::czm_patch_of(c, xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2]);
 }
 int spec_apri(const float g[9], const int dims[4], const float p[4], float out_f[7], int out_i[4]) {

@@ -108,6 +108,14 @@ def test_patch_ids_spec_equals_libm_oracle(spec, oracle, scvod):
         k = rng.integers(0, S, n // 8)
         sl = slice((S // 16 - 1) * (n // 8), (S // 16 - 1) * (n // 8) + n // 8) if S != 54 else slice(3 * (n // 8), 4 * (n // 8))
         t[sl] = k * (2 * np.pi / S) + rng.normal(0, 3e-7, n // 8)
+    # a share of the radii within a few fp32 ulps (and within the fast path's margin) of every zone / ring boundary
+    mn, mx = 2.7, 80.0
+    zb = [mn, (7 * mn + mx) / 8, (3 * mn + mx) / 4, (mn + mx) / 2, mx]
+    bounds = []
+    for k, nr in enumerate((2, 4, 4, 4)):
+        bounds += [zb[k] + j * (zb[k + 1] - zb[k]) / nr for j in range(nr + 1)]
+    bsel = rng.choice(np.asarray(bounds), n // 8)
+    r[4 * (n // 8):5 * (n // 8)] = bsel + rng.choice([0.0, 1e-7, 1e-6, 1e-5, 1e-4, 5e-4, 2e-3], n // 8) * rng.choice([-1, 1], n // 8) * bsel / 10
     x = np.stack([r * np.cos(t), r * np.sin(t), rng.uniform(-4, 3, n), np.zeros(n)], 1).astype(np.float32)
     x[:200, 1] = 0.0                             # exact axis directions
     x[200:400, 0] = 0.0
