@@ -240,6 +240,17 @@ def test_error_conventions(scvod):
     with pytest.raises(scvod.ScvodError):
         scvod.Ctx(bad, max_points_total=100)
     ctx.close()
+    # one scan above SCVOD_MAX_SCAN_POINTS (2^19: the index field of the sort keys) is refused, not truncated;
+    # exactly 2^19 points is accepted
+    big = scvod.Ctx(P, max_points_total=(1 << 19) + 8, max_scans=1)
+    d = torch.zeros(((1 << 19) + 1, 4), device="cuda")
+    off = np.array([0, (1 << 19) + 1], np.int32)
+    assert big.lib.scvod_batch_process(big.h, C.c_void_p(d.data_ptr()), off.ctypes.data_as(C.c_void_p), 1, None, 1) == -4
+    assert b"SCVOD_MAX_SCAN_POINTS" in big.lib.scvod_last_error(big.h)
+    off = np.array([0, 1 << 19], np.int32)
+    big.batch_process(d, off)
+    assert big.batch_counts()[0, 0] == (1 << 19)
+    big.close()
 
 
 def _canonical(labels):
