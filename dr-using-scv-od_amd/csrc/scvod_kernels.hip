@@ -1028,24 +1028,54 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int total = A.order_off[64];
-    for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
-        const int4 item = A.order[w];
+    const int stride = gridDim.x * 4;
+    int wi = blockIdx.x * 4 + wave;
+    if (wi >= total) return;
+    // Half of the live patches hold fewer than 64 points: a wave would spend its time in the dependent chain
+    // order[] -> plane -> points.  So the chain is software-pipelined ACROSS patches: the list item two patches ahead
+    // and the plane + first 64 points of the next patch are in flight while the current patch is arranged (all loads
+    // unconditional with clamped indices, so none has to land before a branch joins).
+    struct Head {
+        float n0, n1, n2, thd;
+        int status;
+        Xyz q;
+        uint32_t w;
+    };
+    auto load_item = [&](int k) -> int4 { return A.order[min(k, total - 1)]; };
+    auto load_head = [&](const int4& it) -> Head {
+        const int slot = it.x;  // scan * kMaxPatches + patch
+        const size_t first = (size_t)it.z + it.w + min(lane, it.y - 1);
+        Head h;
+        h.n0 = A.planes[slot].normal[0];
+        h.n1 = A.planes[slot].normal[1];
+        h.n2 = A.planes[slot].normal[2];
+        h.status = A.planes[slot].status;
+        h.thd = A.fit_thd[slot];
+        h.q = A.sorted_xyz[first];
+        h.w = A.sorted_idx[first];
+        return h;
+    };
+    int4 item = load_item(wi), item1 = load_item(wi + stride);
+    Head head = load_head(item);
+    for (; wi < total; wi += stride) {
+        const int4 item2 = load_item(wi + 2 * stride);
+        const Head head1 = load_head(item1);
         const int code = item.x;
         const int s = code / kMaxPatches, p = code - s * kMaxPatches;
         const int n = item.y, base = item.z, off = item.w;
         const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
         const uint32_t* __restrict__ si = A.sorted_idx + (size_t)base + off;
-        const scvod_patch_plane pl = A.planes[s * kMaxPatches + p];
-        const float n0 = pl.normal[0], n1 = pl.normal[1], n2 = pl.normal[2];
-        const float thd = A.fit_thd[s * kMaxPatches + p];
-        const bool rejected = (pl.status >= 2);
+        const float n0 = head.n0, n1 = head.n1, n2 = head.n2;
+        const float thd = head.thd;
+        const int status = head.status;
+        const bool rejected = (status >= 2);
         // ONE pass: ground part grows from the front in z order, the non-ground part from the back
         // (element r of the non-ground part lives at seg[n - 1 - r]; k_emit reads it that way)
         int n_g = 0, n_ng = 0, a_g = 0, a_ng = 0;
         uint32_t* seg = A.seg + (size_t)base + off;
         // the next 64 points are in flight while this step is classified (clamped, unconditional loads)
-        Xyz q_next = sp[min(lane, n - 1)];
-        uint32_t w_next = si[min(lane, n - 1)];
+        Xyz q_next = head.q;
+        uint32_t w_next = head.w;
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             int g = 0, keep = 0;
@@ -1080,12 +1110,15 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
             PatchRec r;
             r.n = n;
             r.n_g = n_g;
-            r.status = pl.status;
+            r.status = status;
             r.a_g = a_g;
             r.a_ng = a_ng;
             A.patch_rec[s * kMaxPatches + p] = r;
             A.planes[s * kMaxPatches + p].n_ground = n_g;
         }
+        item = item1;
+        item1 = item2;
+        head = head1;
     }
 }
 
