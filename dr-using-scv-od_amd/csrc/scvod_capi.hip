@@ -46,6 +46,7 @@ struct scvod_ctx {
     int32_t* t_begin = nullptr;
     int32_t* t_pair = nullptr;
     int32_t* t_pairpt = nullptr;
+    uint32_t* d_labels = nullptr;   // staging of the host API's label array (scvod_voxelgrid)
     int32_t* t_count = nullptr;
     float* t_T = nullptr;
     // last batch
@@ -166,6 +167,10 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cl_bbox = k.take<uint32_t>(6 * N);
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
+    A.vg_par = k.take<int32_t>(B * 16);
+    A.vg_range = k.take<int32_t>(1);
+    A.vg_outoff = k.take<int32_t>(B + 1);
+    c->d_labels = k.take<uint32_t>(N);
     c->t_hit = k.take<int32_t>(N);
     c->t_work = k.take<uint64_t>(N);
     c->t_uniq = k.take<int32_t>(N);
@@ -423,6 +428,76 @@ void get_transformation(const float p[6], float t[12]) {
     t[11] = z;
 }
 inline float red3(float a, float b, float c) { return a + (b + c); }  // Eigen fixed-size redux order
+
+// label filter + pcl::VoxelGrid over a batch of scans resident in HBM.  Two phases with one small host
+// round trip each: the largest cell-index range picks the bucket shift of the voxel stage; the per-scan output counts
+// become the output offsets.
+int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, const int32_t* h_off, int32_t n_scans,
+                  const float leaf[3], float max_intensity, void* d_out, int64_t out_cap, int32_t* h_out_off, hipStream_t st) {
+    if (!c) return SCVOD_ERR_INVALID;
+    if (n_scans <= 0 || !h_off || !d_xyzi || !leaf || !d_out || !h_out_off) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (!(leaf[0] > 0.f) || !(leaf[1] > 0.f) || !(leaf[2] > 0.f)) return fail(c, SCVOD_ERR_INVALID, "leaf size must be positive");
+    if (n_scans > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "n_scans %d > capacity %d", n_scans, c->cap_scans);
+    if (h_off[0] != 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets[0] must be 0");
+    const int64_t total = h_off[n_scans];
+    if (total > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%lld points > capacity %lld", (long long)total, (long long)c->cap_pts);
+    int32_t mx = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const int32_t n = h_off[s + 1] - h_off[s];
+        if (n < 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets not monotone");
+        if (n > mx) mx = n;
+    }
+    if (mx > SCVOD_MAX_SCAN_POINTS)
+        return fail(c, SCVOD_ERR_CAPACITY, "scan of %d points > SCVOD_MAX_SCAN_POINTS (%d)", mx, SCVOD_MAX_SCAN_POINTS);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!st) st = c->stream;
+    c->last_stream = st;
+    c->h_scan_off.assign(h_off, h_off + n_scans + 1);
+    HIPCHK(c, hipMemcpyAsync(c->d_scan_off, c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
+    c->A.pts = (const float4*)d_xyzi;
+    c->A.scan_off = c->d_scan_off;
+    c->A.n_scans = n_scans;
+    c->A.max_scan_pts = mx;
+    c->A.total_pts = total;
+    c->tim_used = 0;
+    c->batch_valid = c->counts_valid = c->clusters_valid = c->types_valid = false;  // the arena is reused
+    h_out_off[0] = 0;
+    if (mx == 0) {
+        for (int s = 0; s < n_scans; ++s) h_out_off[s + 1] = 0;
+        return SCVOD_OK;
+    }
+    VgJob J;
+    J.labels = d_labels;
+    J.max_intensity = max_intensity;
+    for (int a = 0; a < 3; ++a) J.inv_leaf[a] = 1.0f / leaf[a];
+    J.out = (float4*)d_out;
+    launch_voxelgrid_keys(c->A, J, st);
+    HIPCHK(c, hipGetLastError());
+    int32_t range = 0;
+    HIPCHK(c, hipMemcpyAsync(&range, c->A.vg_range, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    // voxel stage with cell indices as keys: <= 1022 buckets over [0, range], one more for the dropped points
+    DevParams D = c->dev;
+    D.key_off = 0;
+    int shift = 0;
+    while (((int64_t)range >> shift) + 2 > kMaxBuckets) ++shift;
+    D.vb_shift = shift;
+    D.n_buckets = (int)(((int64_t)range >> shift) + 2);
+    launch_process(D, c->A, st, 3, 0, 1, nullptr, nullptr);
+    launch_voxelgrid_centroids(c->A, J, st);
+    HIPCHK(c, hipGetLastError());
+    std::vector<int32_t> par((size_t)n_scans * 16);
+    HIPCHK(c, hipMemcpyAsync(par.data(), c->A.vg_par, sizeof(int32_t) * par.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int s = 0; s < n_scans; ++s) h_out_off[s + 1] = h_out_off[s] + par[(size_t)s * 16 + 8];
+    if (h_out_off[n_scans] > out_cap)
+        return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%lld < %d points)", (long long)out_cap, h_out_off[n_scans]);
+    HIPCHK(c, hipMemcpyAsync(c->A.vg_outoff, h_out_off, sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
+    launch_voxelgrid_gather(c->A, J, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));  // h_out_off is the caller's pageable memory
+    return SCVOD_OK;
+}
 
 }  // namespace
 
@@ -830,6 +905,32 @@ int scvod_batch_timings(scvod_ctx* c, const char** names, float* ms, int32_t cap
         if (ms) ms[n] = t;
     }
     return n;
+}
+
+int scvod_batch_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, const int32_t* h_scan_offsets,
+                          int32_t n_scans, const float leaf[3], float max_intensity, void* d_out_xyzi, int64_t out_capacity,
+                          int32_t* h_out_offsets, void* stream) {
+    return run_voxelgrid(c, d_xyzi, d_labels, h_scan_offsets, n_scans, leaf, max_intensity, d_out_xyzi, out_capacity,
+                         h_out_offsets, (hipStream_t)stream);
+}
+
+int scvod_voxelgrid(scvod_ctx* c, const float* h_xyzi, const uint32_t* h_labels, int32_t n, const float leaf[3],
+                    float max_intensity, float* h_out_xyzi, int32_t out_capacity, int32_t* n_out) {
+    if (!c || !n_out || n < 0 || (n > 0 && (!h_xyzi || !h_out_xyzi))) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    *n_out = 0;
+    if (n == 0) return SCVOD_OK;
+    if (n > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%d points > capacity %lld", n, (long long)c->cap_pts);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_in, h_xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (h_labels) HIPCHK(c, hipMemcpyAsync(c->d_labels, h_labels, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    float4* d_out = (float4*)c->A.cl_bbox;  // device-side output staging: 24 bytes per point, idle outside cluster typing
+    int32_t off[2] = {0, n}, out_off[2] = {0, 0};
+    int rc = run_voxelgrid(c, c->d_in, h_labels ? c->d_labels : nullptr, off, 1, leaf, max_intensity, d_out, n, out_off, c->stream);
+    if (rc) return rc;
+    *n_out = out_off[1];
+    if (out_off[1] > out_capacity) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d)", out_capacity, out_off[1]);
+    if (out_off[1]) HIPCHK(c, hipMemcpy(h_out_xyzi, d_out, sizeof(float) * 4 * (size_t)out_off[1], hipMemcpyDeviceToHost));
+    return SCVOD_OK;
 }
 
 int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,

@@ -103,6 +103,10 @@ struct Arena {
     uint32_t* cl_bbox;        // [6N] per cluster root: min xyz / max xyz in order-preserving uint encoding
     int32_t* cl_count;        // [N] per cluster root: number of points
     uint8_t* pt_type;         // [N] per apri point: 0 erased, 1 other, 2 car
+    // loader-side VoxelGrid
+    int32_t* vg_par;          // [B][16] per scan: min_b[3], mul[3], overflow flag, kept points, distinct cells
+    int32_t* vg_range;        // [1] largest cell index range of the batch
+    int32_t* vg_outoff;       // [B+1] output offsets (uploaded by the host between the two phases)
 };
 
 struct TrackJob {          // scan-vs-next-scan probe
@@ -135,6 +139,15 @@ typedef void (*TimerHook)(void* user, const char* name, int begin);
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu);
 void launch_apri_expand(const DevParams& P, const Arena& A, int s0, int n_scans, int max_pts, hipStream_t st);
+struct VgJob {                // SSC::getCloud label filter + pcl::VoxelGrid (ssc.cpp:1063-1076, 1103-1106)
+    const uint32_t* labels;   // per input point, or nullptr (no filter, no intensity scaling)
+    float max_intensity;
+    float inv_leaf[3];        // 1.f / leaf, fp32 like Eigen::Array4f::Ones() / leaf_size_
+    float4* out;              // caller's output buffer (phase 2)
+};
+void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st);
+void launch_voxelgrid_centroids(const Arena& A, const VgJob& J, hipStream_t st);
+void launch_voxelgrid_gather(const Arena& A, const VgJob& J, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);

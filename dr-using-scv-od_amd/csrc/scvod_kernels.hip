@@ -1243,6 +1243,159 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// the loader step in front of the hot path -- label filter + intensity scaling of SSC::getCloud
+// (ssc.cpp:1063-1076) and pcl::VoxelGrid<PointXYZI> (ssc.cpp:1103-1106; PCL 1.8.1 applyFilter).  The cell index of
+// every kept point becomes a key of the voxel stage above (same bucket + LDS sort machinery, keys ascending, point
+// indices ascending inside a cell = the canonical order), the centroid kernel then walks each cell's point list
+// sequentially (CentroidPoint's fp32 running sums).  Filtered points get the key INT_MAX and form one trailing cell
+// that is dropped.
+// ------------------------------------------------------------------------------------------
+constexpr int32_t kVgDropped = 0x7fffffff;
+__device__ __forceinline__ bool vg_kept(const VgJob& J, int gi) {
+    if (!J.labels) return true;
+    const uint32_t l = J.labels[gi] & 0xFFFFu;
+    return !(l == 0u || l == 1u);
+}
+
+// one workgroup per scan: getMinMax3D over the kept points, then PCL's bounding box / divisions / overflow test
+__global__ __launch_bounds__(1024) void k_vg_minmax(Arena A, VgJob J) {
+    __shared__ float red[6][16];
+    __shared__ int cnt[16];
+    const int s = blockIdx.x;
+    const int base = A.scan_off[s];
+    const int n = A.scan_off[s + 1] - base;
+    float mn[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    float mx[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+    int kept = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        if (!vg_kept(J, base + i)) continue;
+        const float4 p = A.pts[base + i];
+        mn[0] = p.x < mn[0] ? p.x : mn[0];
+        mn[1] = p.y < mn[1] ? p.y : mn[1];
+        mn[2] = p.z < mn[2] ? p.z : mn[2];
+        mx[0] = p.x > mx[0] ? p.x : mx[0];
+        mx[1] = p.y > mx[1] ? p.y : mx[1];
+        mx[2] = p.z > mx[2] ? p.z : mx[2];
+        ++kept;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float o = __shfl_xor(mn[a], d), q = __shfl_xor(mx[a], d);
+            mn[a] = o < mn[a] ? o : mn[a];
+            mx[a] = q > mx[a] ? q : mx[a];
+        }
+        kept += __shfl_xor(kept, d);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) {
+            red[a][wave] = mn[a];
+            red[3 + a][wave] = mx[a];
+        }
+        cnt[wave] = kept;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kept = 0;
+        for (int w = 0; w < 16; ++w) {
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = red[a][w] < mn[a] ? red[a][w] : mn[a];
+                mx[a] = red[3 + a][w] > mx[a] ? red[3 + a][w] : mx[a];
+            }
+            kept += cnt[w];
+        }
+        int32_t* par = A.vg_par + s * 16;
+        int overflow = 0;
+        int min_b[3] = {0, 0, 0}, div_b[3] = {1, 1, 1};
+        long long range = 1;
+        if (kept > 0) {
+            const long long dx = (long long)((mx[0] - mn[0]) * J.inv_leaf[0]) + 1;
+            const long long dy = (long long)((mx[1] - mn[1]) * J.inv_leaf[1]) + 1;
+            const long long dz = (long long)((mx[2] - mn[2]) * J.inv_leaf[2]) + 1;
+            overflow = (dx * dy * dz > 2147483647ll) ? 1 : 0;
+            for (int a = 0; a < 3; ++a) {
+                min_b[a] = (int)floor_f(mn[a] * J.inv_leaf[a]);
+                const int max_b = (int)floor_f(mx[a] * J.inv_leaf[a]);
+                div_b[a] = max_b - min_b[a] + 1;
+            }
+            range = overflow ? (long long)n : (long long)div_b[0] * div_b[1] * div_b[2];
+            if (range > 2147483646ll) range = 2147483646ll;
+        }
+        par[0] = min_b[0];
+        par[1] = min_b[1];
+        par[2] = min_b[2];
+        par[3] = 1;
+        par[4] = div_b[0];
+        par[5] = div_b[0] * div_b[1];
+        par[6] = overflow;
+        par[7] = kept;
+        atomicMax(A.vg_range, (int)range);
+        A.counts[s * 8 + 4] = n;  // the voxel stage sorts every input point (dropped ones under kVgDropped)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vg_keys(Arena A, VgJob J) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.scan_off[s + 1] - base;
+    const int32_t* par = A.vg_par + s * 16;
+    const int mb0 = par[0], mb1 = par[1], mb2 = par[2], m1 = par[4], m2 = par[5], overflow = par[6];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int32_t key = kVgDropped;
+        if (vg_kept(J, base + i)) {
+            if (overflow) {
+                key = i;  // PCL returns the input cloud: every point its own cell, input order
+            } else {
+                const float4 p = A.pts[base + i];
+                const int i0 = (int)(floor_f(p.x * J.inv_leaf[0]) - (float)mb0);
+                const int i1 = (int)(floor_f(p.y * J.inv_leaf[1]) - (float)mb1);
+                const int i2 = (int)(floor_f(p.z * J.inv_leaf[2]) - (float)mb2);
+                key = i0 + i1 * m1 + i2 * m2;
+            }
+        }
+        A.apri_key[(size_t)base + i] = key;
+    }
+}
+
+// one lane per cell: CentroidPoint over the cell's points in ascending input index (fp32 running sums, / float(count))
+__global__ __launch_bounds__(256) void k_vg_centroid(Arena A, VgJob J) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int nv = A.counts[s * 8 + 6];
+    const int32_t* vbeg = A.vox_pt_begin + base + s;
+    float4* tmp = (float4*)A.apri;  // the PointAPRI array is idle here: 16 of its 44 bytes per point hold the centroids
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+        if (A.vox_key[(size_t)base + v] == kVgDropped) continue;
+        const int b0 = vbeg[v], b1 = vbeg[v + 1];
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        for (int k = b0; k < b1; ++k) {
+            const float4 p = A.pts[base + A.vox_pts[(size_t)base + k]];
+            sx += p.x;
+            sy += p.y;
+            sz += p.z;
+            si += J.labels ? p.w * J.max_intensity : p.w;
+        }
+        const float fn = (float)(b1 - b0);
+        tmp[(size_t)base + v] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int dropped = (nv > 0 && A.vox_key[(size_t)base + nv - 1] == kVgDropped) ? 1 : 0;
+        A.vg_par[s * 16 + 8] = nv - dropped;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vg_gather(Arena A, VgJob J) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n_out = A.vg_par[s * 16 + 8];
+    const float4* tmp = (const float4*)A.apri;
+    float4* dst = J.out + A.vg_outoff[s];
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < n_out; v += gridDim.x * 256) dst[v] = tmp[(size_t)base + v];
+}
+
 // PointAPRI records (ssc.cpp:176-193) of scans [s0, s0 + gridDim.y), rebuilt from the compact apri_vec: the same spec
 // function on the same point gives the same bits k_emit saw when it derived key and intensity.
 __global__ __launch_bounds__(256) void k_apri_expand(DevParams P, Arena A, int s0) {
@@ -2170,6 +2323,23 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
 void launch_apri_expand(const DevParams& P, const Arena& A, int s0, int n_scans, int max_pts, hipStream_t st) {
     if (n_scans <= 0 || max_pts <= 0) return;
     hipLaunchKernelGGL(k_apri_expand, dim3((max_pts + 1023) / 1024, n_scans), dim3(256), 0, st, P, A, s0);
+}
+
+void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st) {
+    const int B = A.n_scans;
+    if (B <= 0) return;
+    hipMemsetAsync(A.vg_range, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_vg_minmax, dim3(B), dim3(1024), 0, st, A, J);
+    if (A.max_scan_pts > 0)
+        hipLaunchKernelGGL(k_vg_keys, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A, J);
+}
+void launch_voxelgrid_centroids(const Arena& A, const VgJob& J, hipStream_t st) {
+    if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
+    hipLaunchKernelGGL(k_vg_centroid, dim3((A.max_scan_pts + 1023) / 1024, A.n_scans), dim3(256), 0, st, A, J);
+}
+void launch_voxelgrid_gather(const Arena& A, const VgJob& J, hipStream_t st) {
+    if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
+    hipLaunchKernelGGL(k_vg_gather, dim3((A.max_scan_pts + 1023) / 1024, A.n_scans), dim3(256), 0, st, A, J);
 }
 
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st) {

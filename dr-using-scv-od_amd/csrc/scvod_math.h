@@ -87,6 +87,13 @@ SCVOD_HD double sqrt_d(double x) {
     return __builtin_sqrt(x);
 #endif
 }
+SCVOD_HD float floor_f(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ::floorf(x);
+#else
+    return __builtin_floorf(x);
+#endif
+}
 SCVOD_HD float ceil_f(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return ::ceilf(x);

@@ -119,6 +119,8 @@ def load_lib():
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
         "scvod_set_timing": (C.c_int, [vp, i32]),
         "scvod_nn_search": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp]),
+        "scvod_batch_voxelgrid": (C.c_int, [vp, vp, vp, vp, i32, vp, f32, vp, i64, vp, vp]),
+        "scvod_voxelgrid": (C.c_int, [vp, vp, vp, i32, vp, f32, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # raises AttributeError if a declared symbol is not exported
@@ -134,7 +136,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
                     "scvod_batch_track", "scvod_batch_track_counts",
-                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search"]
+                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
 
 
 def make_params(preset=None, **kw):
@@ -348,6 +350,31 @@ class Ctx:
 
     def arena_bytes(self):
         return int(self.lib.scvod_arena_bytes(self.h))
+
+    def voxelgrid(self, xyzi, leaf=(0.08, 0.08, 0.08), labels=None, max_intensity=1.0):
+        """SSC::getCloud label filter + pcl::VoxelGrid of one host scan (ssc.cpp:1063-1076, 1103-1106)."""
+        x, px = self._f32(xyzi)
+        n = x.shape[0]
+        lf = np.asarray(leaf, np.float32)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        n_out = C.c_int32(0)
+        self._chk(self.lib.scvod_voxelgrid(self.h, px, None if lab is None else lab.ctypes.data_as(C.c_void_p), n,
+                                           lf.ctypes.data_as(C.c_void_p), float(max_intensity), out.ctypes.data_as(C.c_void_p),
+                                           out.shape[0], C.byref(n_out)))
+        return out[:n_out.value]
+
+    def batch_voxelgrid(self, d_xyzi, offsets, d_out, leaf=(0.08, 0.08, 0.08), d_labels=None, max_intensity=1.0, stream=None):
+        """Device-resident form: d_xyzi / d_out / d_labels are torch CUDA tensors; returns the output offsets."""
+        offs = np.ascontiguousarray(offsets, np.int32)
+        lf = np.asarray(leaf, np.float32)
+        out_off = np.zeros(len(offs), np.int32)
+        self._chk(self.lib.scvod_batch_voxelgrid(self.h, C.c_void_p(d_xyzi.data_ptr()),
+                                                 None if d_labels is None else C.c_void_p(d_labels.data_ptr()),
+                                                 offs.ctypes.data_as(C.c_void_p), len(offs) - 1, lf.ctypes.data_as(C.c_void_p),
+                                                 float(max_intensity), C.c_void_p(d_out.data_ptr()), int(d_out.shape[0]),
+                                                 out_off.ctypes.data_as(C.c_void_p), C.c_void_p(stream) if stream else None))
+        return out_off
 
     def nn_search(self, map_xyz, query_xyz, radius):
         m, pm = self._f32(map_xyz)

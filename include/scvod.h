@@ -209,6 +209,25 @@ int scvod_track_probe(scvod_ctx* ctx, const float* h_xyzi, const int32_t* h_offs
                       const int32_t* h_next_labels, int32_t n_next_vox, int32_t* h_hit_slot,
                       int32_t* h_uniq_slots, int32_t* h_uniq_begin);
 
+/* ---- loader step in front of the path ------------------------------------ */
+
+/* SSC::getCloud's label filter + intensity scaling (src/ssc.cpp:1063-1076: points whose label & 0xFFFF is 0 or 1 are
+ * skipped, intensity *= max_intensity) followed by pcl::VoxelGrid<pcl::PointXYZI>::filter with leaf (lx, ly, lz)
+ * (src/ssc.cpp:1103-1106: 0.08 m; PCL 1.8.1 semantics incl. the "leaf size too small -> output = input" branch).
+ * labels == NULL: VoxelGrid only (no filter, no scaling).  Output: one xyzi centroid per occupied cell in ascending
+ * cell index, the cell's points summed in ascending input index (std::sort leaves that order unspecified in PCL).
+ * d_* pointers are device memory; h_out_offsets[n_scans+1] receives the output offsets (in points).  The ctx's arena
+ * is reused: results of an earlier scvod_batch_process are invalidated.  Synchronous. */
+int scvod_batch_voxelgrid(scvod_ctx* ctx, const void* d_xyzi, const uint32_t* d_labels,
+                          const int32_t* h_scan_offsets, int32_t n_scans, const float leaf[3],
+                          float max_intensity, void* d_out_xyzi, int64_t out_capacity,
+                          int32_t* h_out_offsets, void* stream);
+
+/* The same for one scan in host memory. */
+int scvod_voxelgrid(scvod_ctx* ctx, const float* h_xyzi, const uint32_t* h_labels, int32_t n,
+                    const float leaf[3], float max_intensity, float* h_out_xyzi,
+                    int32_t out_capacity, int32_t* n_out);
+
 /* ---- device-resident batch entry points (sequence shards; used by bench.py) ------------- */
 
 /* Run Patchwork -> binning -> voxel descriptors over n_scans scans already resident in

@@ -61,6 +61,12 @@ int oracle_toy_tracking(const scvod_params* params, const scvod_apri* apri_a, in
 int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz, int32_t n_query, float radius,
                      int32_t* nn_idx, float* nn_sqdist, uint8_t* within);
 
+/* label filter + intensity scaling of SSC::getCloud (src/ssc.cpp:1063-1076) and pcl::VoxelGrid 0.08 m
+ * (src/ssc.cpp:1103-1106, PCL 1.8.1 restated).  labels == NULL: VoxelGrid only.  Returns 1 when PCL's "leaf size too
+ * small" branch copied the input. */
+int oracle_voxelgrid(const float* xyzi, const uint32_t* labels, int32_t n, float max_intensity, const float leaf[3],
+                     int32_t sort_mode, float* out_xyzi, int32_t* n_out);
+
 /* libm probes for tests/test_math_spec.py */
 float oracle_libm_atan2f(float y, float x);
 double oracle_libm_atan2(double y, double x);

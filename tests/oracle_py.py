@@ -18,7 +18,7 @@ def load():
     if _lib is not None:
         return Oracle(_lib)
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("patchwork_oracle.cpp", "ssc_oracle.cpp", "tracking_oracle.cpp", "oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("patchwork_oracle.cpp", "ssc_oracle.cpp", "tracking_oracle.cpp", "loader_oracle.cpp", "oracle.h")]
     if (not os.path.exists(so)) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     _lib = C.CDLL(so)
@@ -144,6 +144,17 @@ class Oracle:
         w = np.zeros(max(nq, 1), np.uint8)
         self.lib.oracle_nn_search(_p(m), m.shape[0], _p(q), nq, C.c_float(radius), _p(idx), _p(sq), _p(w))
         return idx[:nq], sq[:nq], w[:nq]
+
+    def voxelgrid(self, xyzi, leaf=(0.08, 0.08, 0.08), labels=None, max_intensity=1.0, sort_mode=1):
+        a = np.ascontiguousarray(xyzi, np.float32)
+        n = a.shape[0]
+        lf = np.asarray(leaf, np.float32)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        n_out = C.c_int32(0)
+        rc = self.lib.oracle_voxelgrid(_p(a), None if lab is None else _p(lab), n, C.c_float(max_intensity), _p(lf), sort_mode,
+                                       _p(out), C.byref(n_out))
+        return out[:n_out.value], rc
 
     def svd3(self, cov):
         c = np.ascontiguousarray(cov, np.float32).reshape(9)
