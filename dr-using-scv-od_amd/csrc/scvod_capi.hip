@@ -46,6 +46,7 @@ struct scvod_ctx {
     int32_t* t_begin = nullptr;
     int32_t* t_pair = nullptr;
     int32_t* t_pairpt = nullptr;
+    uint16_t* d_vb_lut = nullptr;   // A.vb_lut is set only for the duration of a VoxelGrid run
     uint32_t* d_labels = nullptr;   // staging of the host API's label array (scvod_voxelgrid)
     int32_t* t_count = nullptr;
     float* t_T = nullptr;
@@ -170,6 +171,9 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vg_par = k.take<int32_t>(B * 16);
     A.vg_range = k.take<int32_t>(1);
     A.vg_outoff = k.take<int32_t>(B + 1);
+    c->d_vb_lut = k.take<uint16_t>(B * kVgLutBins);
+    A.vb_lut = nullptr;  // hot path: uniform key ranges (DevParams::vb_shift)
+    A.vb_lut_shift = 0;
     c->d_labels = k.take<uint32_t>(N);
     c->t_hit = k.take<int32_t>(N);
     c->t_work = k.take<uint64_t>(N);
@@ -476,14 +480,18 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     int32_t range = 0;
     HIPCHK(c, hipMemcpyAsync(&range, c->A.vg_range, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    // voxel stage with cell indices as keys: <= 1022 buckets over [0, range], one more for the dropped points
+    // voxel stage with cell indices as keys: 1022 population-balanced buckets (k_vg_lut) + one for the dropped points
     DevParams D = c->dev;
     D.key_off = 0;
-    int shift = 0;
-    while (((int64_t)range >> shift) + 2 > kMaxBuckets) ++shift;
-    D.vb_shift = shift;
-    D.n_buckets = (int)(((int64_t)range >> shift) + 2);
-    launch_process(D, c->A, st, 3, 0, 1, nullptr, nullptr);
+    D.vb_shift = 0;
+    D.n_buckets = kMaxBuckets;
+    int lshift = 0;
+    while (((int64_t)range >> lshift) > kVgLutBins - 1) ++lshift;
+    Arena Av = c->A;
+    Av.vb_lut = c->d_vb_lut;
+    Av.vb_lut_shift = lshift;
+    launch_voxelgrid_lut(Av, st);
+    launch_process(D, Av, st, 3, 0, 1, nullptr, nullptr);
     launch_voxelgrid_centroids(c->A, J, st);
     HIPCHK(c, hipGetLastError());
     std::vector<int32_t> par((size_t)n_scans * 16);

@@ -13,6 +13,7 @@ namespace scvod {
 
 constexpr int kMaxPatches = SCVOD_MAX_PATCHES;
 constexpr int kMaxBuckets = 1024;
+constexpr int kVgLutBins = 16384;
 
 struct Xyz {
     float x, y, z;
@@ -107,6 +108,8 @@ struct Arena {
     int32_t* vg_par;          // [B][16] per scan: min_b[3], mul[3], overflow flag, kept points, distinct cells
     int32_t* vg_range;        // [1] largest cell index range of the batch
     int32_t* vg_outoff;       // [B+1] output offsets (uploaded by the host between the two phases)
+    uint16_t* vb_lut;         // [B][kVgLutBins] monotone key-bin -> bucket table of the VoxelGrid run; nullptr in the hot path
+    int32_t vb_lut_shift;     // key >> vb_lut_shift = bin
 };
 
 struct TrackJob {          // scan-vs-next-scan probe
@@ -146,6 +149,7 @@ struct VgJob {                // SSC::getCloud label filter + pcl::VoxelGrid (ss
     float4* out;              // caller's output buffer (phase 2)
 };
 void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st);
+void launch_voxelgrid_lut(const Arena& A, hipStream_t st);
 void launch_voxelgrid_centroids(const Arena& A, const VgJob& J, hipStream_t st);
 void launch_voxelgrid_gather(const Arena& A, const VgJob& J, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);

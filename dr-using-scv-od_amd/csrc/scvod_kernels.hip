@@ -1360,6 +1360,37 @@ __global__ __launch_bounds__(256) void k_vg_keys(Arena A, VgJob J) {
     }
 }
 
+// Cell indices are anything but uniform (the ground layers near the sensor hold most of a scan), so equal index ranges
+// make buckets of tens of thousands of points.  One workgroup per scan histograms the keys into kVgLutBins equal
+// ranges (≈ a 1 m band of one z layer for a KITTI scan at 0.08 m) and cuts the running count into <= 1022 buckets of about equal population; the table is monotone, so bucket
+// order is still key order.
+__global__ __launch_bounds__(1024) void k_vg_lut(Arena A) {
+    extern __shared__ int hist[];  // kVgLutBins counters (64 KB)
+    __shared__ int wsum[17];
+    const int s = blockIdx.x;
+    const int base = A.scan_off[s];
+    const int n = A.scan_off[s + 1] - base;
+    for (int b = threadIdx.x; b < kVgLutBins; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int32_t key = A.apri_key[(size_t)base + i];
+        if (key != kVgDropped) atomicAdd(&hist[key >> A.vb_lut_shift], 1);
+    }
+    __syncthreads();
+    const int kept = A.vg_par[s * 16 + 7];
+    const int target = max(kept / (kMaxBuckets - 2) + 1, 1536);  // ~1.5 k points per bucket: the 2048-key LDS tier
+    int run = 0;
+    for (int b0 = 0; b0 < kVgLutBins; b0 += 1024) {
+        const int c = hist[b0 + threadIdx.x];
+        int total;
+        const int ex = block_excl_scan<1024>(c, total, wsum);
+        const int bucket = min((run + ex) / target, kMaxBuckets - 2);
+        A.vb_lut[(size_t)s * kVgLutBins + b0 + threadIdx.x] = (uint16_t)bucket;
+        run += total;
+        __syncthreads();
+    }
+}
+
 // one lane per cell: CentroidPoint over the cell's points in ascending input index (fp32 running sums, / float(count))
 __global__ __launch_bounds__(256) void k_vg_centroid(Arena A, VgJob J) {
     const int s = blockIdx.y;
@@ -1508,7 +1539,11 @@ __global__ __launch_bounds__(256) void k_apri_split(Arena A) {
 // Voxel stage (SSC::makeHashCloud): bucket by the high bits of the key, sort (key, apri idx)
 // inside each bucket, per-voxel sequential intensity mean / variance.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int vx_bucket_of(const DevParams& P, int32_t voxel_idx) {
+__device__ __forceinline__ int vx_bucket_of(const DevParams& P, const Arena& A, int s, int32_t voxel_idx) {
+    if (A.vb_lut) {  // VoxelGrid run: population-balanced monotone table (cell indices are far from uniform)
+        if (voxel_idx == 0x7fffffff) return kMaxBuckets - 1;
+        return A.vb_lut[(size_t)s * kVgLutBins + (voxel_idx >> A.vb_lut_shift)];
+    }
     int64_t b = ((int64_t)voxel_idx + P.key_off) >> P.vb_shift;
     if (b < 0) b = 0;
     if (b > P.n_buckets - 1) b = P.n_buckets - 1;
@@ -1532,7 +1567,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_count(DevParams P, Arena A) {
 #pragma unroll
     for (int it = 0; it < kVxItems; ++it) {
         int i = start + it * kVxThreads + threadIdx.x;
-        if (i < n) atomicAdd(&hist[vx_bucket_of(P, A.apri_key[(size_t)base + i])], 1);
+        if (i < n) atomicAdd(&hist[vx_bucket_of(P, A, s, A.apri_key[(size_t)base + i])], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < P.n_buckets; b += kVxThreads) {
@@ -1567,7 +1602,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
         bk[it] = -1;
         if (i < n) {
             key[it] = A.apri_key[(size_t)base + i];
-            bk[it] = vx_bucket_of(P, key[it]);
+            bk[it] = vx_bucket_of(P, A, s, key[it]);
             rank[it] = atomicAdd(&hist[bk[it]], 1);
         }
     }
@@ -2332,6 +2367,11 @@ void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st) {
     hipLaunchKernelGGL(k_vg_minmax, dim3(B), dim3(1024), 0, st, A, J);
     if (A.max_scan_pts > 0)
         hipLaunchKernelGGL(k_vg_keys, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A, J);
+}
+void launch_voxelgrid_lut(const Arena& A, hipStream_t st) {
+    if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
+    hipFuncSetAttribute((const void*)k_vg_lut, hipFuncAttributeMaxDynamicSharedMemorySize, kVgLutBins * (int)sizeof(int));
+    hipLaunchKernelGGL(k_vg_lut, dim3(A.n_scans), dim3(1024), kVgLutBins * sizeof(int), st, A);
 }
 void launch_voxelgrid_centroids(const Arena& A, const VgJob& J, hipStream_t st) {
     if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
