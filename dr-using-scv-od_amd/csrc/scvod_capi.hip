@@ -63,11 +63,8 @@ struct scvod_ctx {
     hipStream_t last_stream = nullptr;
     int32_t last_track_clusters = 0;
     // host staging for scvod_scan_result
-    std::vector<uint8_t> r_cls;
-    std::vector<int32_t> r_ground, r_nonground, r_apri_src, r_rejected, r_vox_key, r_vox_begin, r_vox_pts;
-    std::vector<scvod_patch_plane> r_planes;
-    std::vector<scvod_apri> r_apri;
-    std::vector<float> r_vox_av, r_vox_cov;
+    void* stage = nullptr;       // pinned host block holding the arrays of the last scvod_scan_result
+    size_t stage_bytes = 0;
     // timing
     bool timing = false;
     std::vector<TimingEntry> tim;
@@ -361,41 +358,59 @@ int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
     out->n_voxels = k[6];
     out->n_patches = k[7];
     const Arena& A = c->A;
-    if (c->have_patchwork) {
-        launch_cls(A, s, base, k[0], c->last_stream);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    hipStream_t st = c->last_stream;
+    if (c->have_patchwork) launch_cls(A, s, base, k[0], st);
+    if (c->apri_compact && k[4] > 0) launch_apri_expand(c->dev, A, s, 1, k[4], st);  // PointAPRI records of this scan only
+    HIPCHK(c, hipGetLastError());
+    // one pinned staging block, twelve asynchronous copies, one synchronisation (the pointers handed out live in it)
+    struct Part {
+        const void* src;
+        size_t bytes;
+        size_t at;
+    };
+    const size_t n_cls = c->have_patchwork ? (size_t)k[0] : 0;
+    Part parts[12] = {{A.cls + base, n_cls, 0},
+                      {A.ground_idx + base, 4 * (size_t)k[1], 0},
+                      {A.nonground_idx + base, 4 * (size_t)k[2], 0},
+                      {A.planes + (size_t)s * kMaxPatches, sizeof(scvod_patch_plane) * (size_t)k[7], 0},
+                      {A.apri + base, sizeof(scvod_apri) * (size_t)k[4], 0},
+                      {A.apri_src + base, 4 * (size_t)k[4], 0},
+                      {A.rejected_src + base, 4 * (size_t)k[5], 0},
+                      {A.vox_key + base, 4 * (size_t)k[6], 0},
+                      {A.vox_pt_begin + base + s, 4 * ((size_t)k[6] + 1), 0},
+                      {A.vox_pts + base, 4 * (size_t)k[4], 0},
+                      {A.vox_av + base, 4 * (size_t)k[6], 0},
+                      {A.vox_cov + base, 4 * (size_t)k[6], 0}};
+    size_t need = 0;
+    for (Part& p : parts) {
+        p.at = need;
+        need += (p.bytes + 63) & ~(size_t)63;
     }
-    if ((rc = dl(c, c->r_cls, A.cls + base, (size_t)(c->have_patchwork ? k[0] : 0)))) return rc;
-    if ((rc = dl(c, c->r_ground, A.ground_idx + base, (size_t)k[1]))) return rc;
-    if ((rc = dl(c, c->r_nonground, A.nonground_idx + base, (size_t)k[2]))) return rc;
-    if ((rc = dl(c, c->r_planes, A.planes + (size_t)s * kMaxPatches, (size_t)k[7]))) return rc;
-    if (c->apri_compact && k[4] > 0) {  // PointAPRI records of this scan only
-        launch_apri_expand(c->dev, A, s, 1, k[4], c->last_stream);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    need += 64;
+    if (need > c->stage_bytes) {
+        if (c->stage) hipHostFree(c->stage);
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        HIPCHK(c, hipHostMalloc(&c->stage, need + need / 4, hipHostMallocDefault));
+        c->stage_bytes = need + need / 4;
     }
-    if ((rc = dl(c, c->r_apri, A.apri + base, (size_t)k[4]))) return rc;
-    if ((rc = dl(c, c->r_apri_src, A.apri_src + base, (size_t)k[4]))) return rc;
-    if ((rc = dl(c, c->r_rejected, A.rejected_src + base, (size_t)k[5]))) return rc;
-    if ((rc = dl(c, c->r_vox_key, A.vox_key + base, (size_t)k[6]))) return rc;
-    if ((rc = dl(c, c->r_vox_begin, A.vox_pt_begin + base + s, (size_t)k[6] + 1))) return rc;
-    if ((rc = dl(c, c->r_vox_pts, A.vox_pts + base, (size_t)k[4]))) return rc;
-    if ((rc = dl(c, c->r_vox_av, A.vox_av + base, (size_t)k[6]))) return rc;
-    if ((rc = dl(c, c->r_vox_cov, A.vox_cov + base, (size_t)k[6]))) return rc;
-    if (k[6] == 0) c->r_vox_begin[0] = 0;
-    out->cls = c->r_cls.data();
-    out->ground_idx = c->r_ground.data();
-    out->nonground_idx = c->r_nonground.data();
-    out->planes = c->r_planes.data();
-    out->apri = c->r_apri.data();
-    out->apri_src = c->r_apri_src.data();
-    out->rejected_src = c->r_rejected.data();
-    out->vox_key = c->r_vox_key.data();
-    out->vox_pt_begin = c->r_vox_begin.data();
-    out->vox_pts = c->r_vox_pts.data();
-    out->vox_av = c->r_vox_av.data();
-    out->vox_cov = c->r_vox_cov.data();
+    char* h = (char*)c->stage;
+    for (const Part& p : parts)
+        if (p.bytes) HIPCHK(c, hipMemcpyAsync(h + p.at, p.src, p.bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (k[6] == 0) *(int32_t*)(h + parts[8].at) = 0;
+    out->cls = (const uint8_t*)(h + parts[0].at);
+    out->ground_idx = (const int32_t*)(h + parts[1].at);
+    out->nonground_idx = (const int32_t*)(h + parts[2].at);
+    out->planes = (const scvod_patch_plane*)(h + parts[3].at);
+    out->apri = (const scvod_apri*)(h + parts[4].at);
+    out->apri_src = (const int32_t*)(h + parts[5].at);
+    out->rejected_src = (const int32_t*)(h + parts[6].at);
+    out->vox_key = (const int32_t*)(h + parts[7].at);
+    out->vox_pt_begin = (const int32_t*)(h + parts[8].at);
+    out->vox_pts = (const int32_t*)(h + parts[9].at);
+    out->vox_av = (const float*)(h + parts[10].at);
+    out->vox_cov = (const float*)(h + parts[11].at);
     return SCVOD_OK;
 }
 
@@ -624,6 +639,7 @@ void scvod_destroy(scvod_ctx* c) {
     }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->arena_base) hipFree(c->arena_base);
+    if (c->stage) hipHostFree(c->stage);
     delete c;
 }
 
