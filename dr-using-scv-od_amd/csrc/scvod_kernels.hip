@@ -739,11 +739,11 @@ __device__ __forceinline__ void fit_store(FitTile& T, int lane, const fitq (&r)[
     }
 }
 
-__global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
+__global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A, int coop_class) {
     __shared__ FitTile T;
     const int lane = threadIdx.x;
     int lo, hi;
-    order_range(A.order_off, 0, kClassFitCoop - 1, lo, hi);  // the larger patches go to k_pw_fit_coop
+    order_range(A.order_off, 0, coop_class - 1, lo, hi);  // the larger patches go to k_pw_fit_coop
     const int t = lo + blockIdx.x * 64 + lane;
     if (lo + blockIdx.x * 64 >= hi) return;
     const bool live = t < hi;
@@ -878,11 +878,11 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A) {
 // transposed, and lanes 0..8 of the group add "their" accumulator over the 16 points IN ORDER -- the sums are the
 // same sequential fp32 sums, only the nine independent chains run on nine lanes instead of one.
 constexpr int kFitCoopPF = 8;  // steps of 16 points in flight per group
-__global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A) {
+__global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int coop_class) {
     __shared__ fitq tile[4 * 9 * 4];  // [group][accumulator][16 points]
     const int lane = threadIdx.x, g = lane >> 4, r = lane & 15, gbase = g << 4;
     int lo, hi;
-    order_range(A.order_off, kClassFitCoop, 63, lo, hi);
+    order_range(A.order_off, coop_class, 63, lo, hi);
     if (lo + blockIdx.x * 4 >= hi) return;
     const int w = lo + blockIdx.x * 4 + g;
     const bool live = w < hi;
@@ -2281,11 +2281,16 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
                            sort_lds_bytes(256), st, P, A);
         hipLaunchKernelGGL(k_pw_sort_wave, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
         TH_END("pw_sort_small");
+        // Throughput (a sequence shard) wants the 16-lane fit only where a lane per patch starves the chip (>= 512
+        // points); a handful of scans (the per-scan host API) has too few patches to fill it either way, and the lane-per-
+        // patch chain of a 500-point patch is then the latency: everything from 64 points up goes to the 16-lane kernel.
+        const int coop_class = (B <= 8) ? kClassWave : kClassFitCoop;
+        const int coop_min = 1 << (coop_class / 4);
         TH_BEGIN("pw_fit_large");
-        hipLaunchKernelGGL(k_pw_fit_coop, dim3((int)(A.total_pts / kFitCoopMin / 4) + 1), dim3(64), 0, st, P, A);
+        hipLaunchKernelGGL(k_pw_fit_coop, dim3((int)(A.total_pts / coop_min / 4) + 1), dim3(64), 0, st, P, A, coop_class);
         TH_END("pw_fit_large");
         TH_BEGIN("pw_fit");
-        hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A);
+        hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A, coop_class);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");
         hipLaunchKernelGGL(k_pw_arrange, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);

@@ -19,3 +19,12 @@ for kind, preset in (("K64", "semantickitti"), ("PARK", "parkinglot")):
     ts = np.sort(ts)
     print(f"{kind}: {x.shape[0]} points -> {r['n_apri']} apri, {r['n_voxels']} voxels; process_scan median {ts[len(ts)//2]:.3f} ms, min {ts[0]:.3f} ms")
     ctx.close()
+
+# where the time goes at B = 1: hipEvent time of every stage of one scan
+x = synth.make_scan(5, 40, "K64")[0].numpy()
+ctx = scvod.Ctx(scvod.make_params("semantickitti"), max_points_total=x.shape[0] + 64, max_scans=1)
+ctx.process_scan(x)
+ctx.set_timing(True)
+ctx.process_scan(x)
+tm = ctx.timings()
+print("device time per stage (us):", {k: round(1e3 * v, 1) for k, v in tm}, "sum", round(1e3 * sum(v for _, v in tm), 1))
