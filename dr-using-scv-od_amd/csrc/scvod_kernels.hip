@@ -1797,12 +1797,22 @@ __global__ __launch_bounds__(256) void k_cc_init(Arena A) {
     }
 }
 
+constexpr int kCcLdsKeys = 8192;
 // one thread per voxel: neighbourhood look-ups with the index triple(s) of its points
 __global__ __launch_bounds__(256) void k_cc_link(DevParams P, Arena A) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int nv = A.counts[s * 8 + 6];
-    const int32_t* keys = A.vox_key + base;
+    // the scan's sorted key table in LDS when it fits (27 binary searches per voxel: eleven dependent L2 round trips
+    // each otherwise)
+    __shared__ int32_t skeys[kCcLdsKeys];
+    if ((int)blockIdx.x * 256 >= nv) return;  // the grid is sized for the point count, voxels are far fewer
+    const int32_t* gkeys = A.vox_key + base;
+    const bool in_lds = nv <= kCcLdsKeys;
+    if (in_lds)
+        for (int i = threadIdx.x; i < nv; i += 256) skeys[i] = gkeys[i];
+    __syncthreads();
+    const int32_t* keys = in_lds ? skeys : gkeys;
     const int32_t* vbeg = A.vox_pt_begin + base + s;
     const int32_t* vpts = A.vox_pts + base;
     int* parent = A.cc_parent + base;
