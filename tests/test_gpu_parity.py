@@ -155,18 +155,21 @@ def test_track_probe_parity(scvod, oracle):
     ctx.close()
 
 
-def test_batch_track_matches_oracle_per_pair(scvod, oracle):
+@pytest.mark.parametrize("fine", [False, True])
+def test_batch_track_matches_oracle_per_pair(scvod, oracle, fine):
     """scvod_batch_track (device-resident sequence shard: points read through apri_src, next scan's keys staged in
-    LDS) must count, per cluster, exactly the unique next-scan voxels the oracle's per-pair probe finds."""
+    LDS) must count, per cluster, exactly the unique next-scan voxels the oracle's per-pair probe finds.  `fine`: a grid
+    so fine that a scan has more voxels than the LDS key table holds (global-memory search path)."""
     import torch
     import synth
-    P = _params(scvod, "semantickitti")
+    P = scvod.make_params("semantickitti", range_res=0.05, sector_res=0.2, azimuth_res=0.25) if fine else _params(scvod, "semantickitti")
     count = 4
     pts, offs, poses, _ = synth.make_batch(5, 420, count, "K64")
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
     d = pts.cuda()
     ctx.batch_process(d, offs)
     res = [ctx.batch_fetch(s) for s in range(count)]
+    assert (min(r["n_voxels"] for r in res) > 8192) == fine
     members, cbegin, pbegin, per_pair = [], [0], [0], []
     for s in range(count - 1):
         n_a = res[s]["n_apri"]
@@ -263,6 +266,20 @@ def _canonical(labels):
     out = np.empty(len(labels), np.int64)
     out[order] = np.repeat(mins, np.diff(np.append(np.nonzero(first)[0], len(labels))))
     return out
+
+
+def test_cluster_partition_on_a_fine_grid(scvod, oracle):
+    """more voxels than the clustering kernel's LDS key table holds: neighbourhood searches in global memory"""
+    import synth
+    P = scvod.make_params("semantickitti", range_res=0.05, sector_res=0.2, azimuth_res=0.25)
+    x = synth.make_scan(5, 33, "K64")[0].numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    assert r["n_voxels"] > 8192
+    got = ctx.cluster(r["apri"])
+    ref, _, _ = oracle.cluster(P, r["apri"])
+    assert np.array_equal(got, _canonical(ref))
+    ctx.close()
 
 
 @pytest.mark.parametrize("kind,preset,seq,idx,stride", [("K64", "semantickitti", 5, 10, 3), ("PARK", "parkinglot", 3, 4, 1)])
