@@ -3,7 +3,10 @@
 The hot path partitions by scan: Patchwork / binning / voxel descriptors are independent per scan
 (SSC::reset clears all per-scan state, src/ssc.cpp:79-86), so a rank owns a contiguous block of scans
 and no data-path collective is needed.  Only the run summary (per-rank counters, max-over-ranks time)
-crosses ranks."""
+crosses ranks -- plus, when ONE sequence is split into contiguous blocks, the single real exchange step of the path:
+the scan-vs-next-scan probe (SSC::tracking, src/ssc.cpp:1274-1321) of a block's LAST scan needs the voxel table of the
+next block's FIRST scan.  That is a point-to-point message of a few thousand ints to the left neighbour
+(`exchange_boundary_table`), not a collective."""
 import numpy as np
 
 
@@ -29,3 +32,41 @@ def aggregate(dist, device, seconds, scans, points):
     a = torch.tensor([float(scans), float(points)], dtype=torch.float64, device=device)
     dist.all_reduce(a, op=dist.ReduceOp.SUM)
     return float(t.item()), float(a[0].item()), float(a[1].item())
+
+
+def exchange_boundary_table(dist, device, first_keys, first_labels=None):
+    """Block-sharded sequence: every rank sends the sorted voxel key table (and optional labels) of its FIRST scan to
+    rank-1 and receives the table of rank+1's first scan, which is what the tracking probe of its LAST scan runs
+    against.  Returns (keys, labels) as int32 numpy arrays, or (None, None) on the last rank / without a process group.
+    Point-to-point over the job's backend (RCCL on the GPUs, gloo in the CPU tests); sizes first, then payload."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None, None
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    keys = np.ascontiguousarray(first_keys, np.int32)
+    labels = np.ascontiguousarray(first_labels if first_labels is not None else np.zeros(len(keys), np.int32), np.int32)
+    assert len(labels) == len(keys)
+    mine = torch.tensor([len(keys)], dtype=torch.int64, device=device)
+    theirs = torch.zeros(1, dtype=torch.int64, device=device)
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, mine, rank - 1))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.irecv, theirs, rank + 1))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    payload = torch.from_numpy(np.stack([keys, labels])).to(device)          # [2, n] int32
+    n_in = int(theirs.item()) if rank < world - 1 else 0
+    incoming = torch.zeros((2, n_in), dtype=torch.int32, device=device)
+    ops = []
+    if rank > 0 and len(keys):
+        ops.append(dist.P2POp(dist.isend, payload, rank - 1))
+    if rank < world - 1 and n_in:
+        ops.append(dist.P2POp(dist.irecv, incoming, rank + 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if rank == world - 1:
+        return None, None
+    got = incoming.cpu().numpy()
+    return got[0].copy(), got[1].copy()

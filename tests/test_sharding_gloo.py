@@ -87,3 +87,85 @@ def test_block_range_properties():
             assert rs[0][0] == 0 and rs[-1][1] == n
             assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def _boundary_worker(rank, world, port, n_scans, q):
+    sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_py
+    import scvod_py
+    import shard
+    import synth
+    orc = oracle_py.load()
+    P = scvod_py.make_params("parkinglot")
+    lo, hi = shard.block_range(n_scans, rank, world)
+
+    def tables(i):
+        pts, _, pose = synth.make_scan(3, i, "PARK")
+        x = pts.numpy()
+        o = orc.patchwork(P, x, 1)
+        b = orc.bin(P, x[o["nonground_idx"]], True)
+        v = orc.voxelize(P, b["apri"])
+        return b["apri"], v["vox_key"], pose
+
+    first_apri, first_keys, _ = tables(lo)
+    nxt_keys, nxt_labels = shard.exchange_boundary_table(dist, torch.device("cpu"), first_keys, np.arange(len(first_keys), dtype=np.int32) % 7 - 1)
+    out = None
+    if rank < world - 1:
+        # the probe of this block's LAST scan against the NEXT block's first table (ssc.cpp:1274-1321)
+        apri, _, pose_a = tables(hi - 1)
+        _, _, pose_b = tables(hi)                      # only the pose is needed locally (poses are replicated input)
+        T = orc.pose_delta(pose_a, pose_b)
+        m = np.arange(0, len(apri), 5)
+        xyzi = np.stack([apri["x"][m], apri["y"][m], apri["z"][m], apri["intensity"][m]], 1).astype(np.float32)
+        offs = np.arange(0, len(m) + 1, 50, dtype=np.int32)
+        offs[-1] = len(m)
+        hit, uq, ub = orc.track_probe(P, xyzi, offs, T, nxt_keys, nxt_labels)
+        out = (hi - 1, hit.tolist(), ub.tolist(), nxt_keys.tolist(), nxt_labels.tolist())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        q.put(gathered)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_boundary_pair_uses_the_neighbours_table(oracle, scvod):
+    """the one real exchange step of the path: a block's last scan is probed against the first voxel table of the next
+    block, received point-to-point; the result equals the single-process probe of the same pair."""
+    import synth
+    n_scans, world = 4, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_boundary_worker, args=(r, world, port, n_scans, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None and res[0] is not None          # the last rank has no right neighbour
+    last, hit, ub, keys, labels = res[0]
+    assert last == 1                                      # scans [0, 2) on rank 0, [2, 4) on rank 1
+    P = scvod.make_params("parkinglot")
+
+    def tables(i):
+        pts, _, pose = synth.make_scan(3, i, "PARK")
+        x = pts.numpy()
+        o = oracle.patchwork(P, x, 1)
+        b = oracle.bin(P, x[o["nonground_idx"]], True)
+        return b["apri"], oracle.voxelize(P, b["apri"])["vox_key"], pose
+
+    apri, _, pose_a = tables(1)
+    _, keys2, pose_b = tables(2)
+    assert keys == keys2.tolist() and labels == (np.arange(len(keys2)) % 7 - 1).tolist()
+    m = np.arange(0, len(apri), 5)
+    xyzi = np.stack([apri["x"][m], apri["y"][m], apri["z"][m], apri["intensity"][m]], 1).astype(np.float32)
+    offs = np.arange(0, len(m) + 1, 50, dtype=np.int32)
+    offs[-1] = len(m)
+    rhit, _, rub = oracle.track_probe(P, xyzi, offs, oracle.pose_delta(pose_a, pose_b), keys2, (np.arange(len(keys2)) % 7 - 1).astype(np.int32))
+    assert hit == rhit.tolist() and ub == rub.tolist() and (rhit >= 0).any()
