@@ -879,7 +879,9 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A, int coop_cl
 // same sequential fp32 sums, only the nine independent chains run on nine lanes instead of one.
 constexpr int kFitCoopPF = 8;  // steps of 16 points in flight per group
 __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int coop_class) {
-    __shared__ fitq tile[4 * 9 * 4];  // [group][accumulator][16 points]
+    // [group][accumulator][16 points], rows padded to 20 floats: the nine row reads of a group (b128, rows 80 bytes apart)
+    // then spread over the banks instead of alternating between two 16-byte bank groups
+    __shared__ fitq tile[4 * 9 * 5];
     const int lane = threadIdx.x, g = lane >> 4, r = lane & 15, gbase = g << 4;
     int lo, hi;
     order_range(A.order_off, coop_class, 63, lo, hi);
@@ -939,7 +941,7 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
     fit_state_init(F);
     const int n_last = max(n - 1, 0);
     float* tf = (float*)tile;
-    const int acc_row = (g * 9 + (r < 9 ? r : 8)) * 4;  // lanes 9..15 shadow accumulator 8
+    const int acc_row = (g * 9 + (r < 9 ? r : 8)) * 5;  // lanes 9..15 shadow accumulator 8
 
     for (int iter = 0; iter < P.czm.num_iter; ++iter) {
         const float n0 = F.n0, n1 = F.n1, n2 = F.n2, thd = F.thd;
@@ -969,16 +971,16 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
                 }
                 // non-members contribute +0.0f to every sum: zero the point, the products follow (0 * 0 = +0)
                 const float zx = in ? q.x : 0.f, zy = in ? q.y : 0.f, zz = in ? q.z : 0.f;
-                float* col = tf + g * 9 * 16 + r;
-                col[0 * 16] = zx * zx;
-                col[1 * 16] = zx * zy;
-                col[2 * 16] = zx * zz;
-                col[3 * 16] = zy * zy;
-                col[4 * 16] = zy * zz;
-                col[5 * 16] = zz * zz;
-                col[6 * 16] = zx;
-                col[7 * 16] = zy;
-                col[8 * 16] = zz;
+                float* col = tf + g * 9 * 20 + r;
+                col[0 * 20] = zx * zx;
+                col[1 * 20] = zx * zy;
+                col[2 * 20] = zx * zz;
+                col[3 * 20] = zy * zy;
+                col[4 * 20] = zy * zz;
+                col[5 * 20] = zz * zz;
+                col[6 * 20] = zx;
+                col[7 * 20] = zy;
+                col[8 * 20] = zz;
                 m_lane += in ? 1 : 0;
                 // seeds are a prefix of the z-sorted patch: the group stops after the step in which one fails
                 const bool stop = (iter == 0) && (((uint32_t)(__ballot(fails) >> gbase) & 0xffffu) != 0u);
