@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the multi-threaded CPU context number")
     ap.add_argument("--pseudo-clusters", action="store_true", help="differencing stage on synthetic index runs instead of GPU car clusters")
+    ap.add_argument("--no-extras", action="store_true", help="skip the separately reported next-row stages (clustering, boxes, VoxelGrid): profiling runs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0")
     args = ap.parse_args()
@@ -207,6 +208,8 @@ def main():
     # "next" row 8(f)-1, reported separately (not part of `value`): curved-voxel clustering on the resident batch
     cc_ms = ct_ms = None
     try:
+        if args.no_extras:
+            raise RuntimeError("skipped")
         barrier()
         t1 = time.perf_counter()
         for c in chunks:
@@ -231,6 +234,8 @@ def main():
     # "next" row 8(f)-3, reported separately: loader-side VoxelGrid 0.08 m over the resident sequence (into a second buffer)
     vg_ms = vg_ratio = None
     try:
+        if args.no_extras:
+            raise RuntimeError("skipped")
         c = chunks[0]
         d_out = torch.empty_like(c["pts"])
         c["ctx"].batch_voxelgrid(c["pts"], c["offs"], d_out)  # warm-up

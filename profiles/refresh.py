@@ -58,7 +58,7 @@ F, W = load(os.path.join(src, "FETCH_SIZE_counter_collection.csv")), load(os.pat
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     shutil.copy(os.path.join(src, c + "_counter_collection.csv"), os.path.join(here, f"{tag}_pmc_{c}_counter_collection.csv"))
 scans = 512
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --scans 512 --steps 1 --warmup 0 --no-cpu; "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --scans 512 --steps 1 --warmup 0 --no-cpu --no-cpu-all --no-extras; "
                "raw values are KB per dispatch, bytes = KB*1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide "
                "coalesced read; uncalibrated for gathers, so read-side numbers of gather-heavy kernels are upper bounds)",
        "scans_per_launch": scans, "kernels": {}}
