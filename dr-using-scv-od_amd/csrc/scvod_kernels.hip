@@ -427,15 +427,29 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
         }
         Xyz* dst = A.sorted_xyz + (size_t)base + off;
         uint32_t* dsti = A.sorted_idx + (size_t)base + off;
-        for (int j = threadIdx.x; j < n; j += THREADS) {
-            const uint32_t id = key_idx(keys[in_lds ? sort_slot<true>(j) : j]);
-            const float4 q = A.pts[base + id];
-            Xyz o;
-            o.x = q.x;
-            o.y = q.y;
-            o.z = q.z;
-            dst[j] = o;
-            dsti[j] = id;
+        // four independent gathers in flight per thread (the index comes from LDS, the point from anywhere in the scan)
+        for (int j0 = threadIdx.x; j0 < n; j0 += 4 * THREADS) {
+            uint32_t id[4];
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u * THREADS, n - 1);
+                id[u] = key_idx(keys[in_lds ? sort_slot<true>(j) : j]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = A.pts[base + id[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * THREADS;
+                if (j < n) {
+                    Xyz o;
+                    o.x = q[u].x;
+                    o.y = q[u].y;
+                    o.z = q[u].z;
+                    dst[j] = o;
+                    dsti[j] = id[u];
+                }
+            }
         }
         __syncthreads();  // LDS is reused by the next item
     }
