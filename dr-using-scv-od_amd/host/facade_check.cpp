@@ -139,6 +139,22 @@ int main(int argc, char** argv) {
         }
         std::cout << "pair_tracking cars " << c2 << " dynamic " << d2 << " reported " << ssc.dynamic_num_last << " next_clusters "
                   << fb.cluster_set.size() << "\n";
+        // loader step (getCloud's filter + VoxelGrid) on scan a with synthetic labels: every 9th point unlabeled,
+        // every 13th an outlier, the rest some class
+        {
+            std::vector<float> raw(4 * a->points.size());
+            std::vector<uint32_t> lab(a->points.size());
+            for (size_t i = 0; i < a->points.size(); ++i) {
+                raw[4 * i] = a->points[i].x;
+                raw[4 * i + 1] = a->points[i].y;
+                raw[4 * i + 2] = a->points[i].z;
+                raw[4 * i + 3] = a->points[i].intensity;
+                lab[i] = (i % 9 == 0) ? 0u : (i % 13 == 0) ? 0x00030001u : (40u + (uint32_t)(i % 5));
+            }
+            auto loaded = ssc.filterAndDownsample(raw, lab);
+            dump_cloud(pre + "_a_loaded.f32", *loaded);
+            std::cout << "loaded " << a->points.size() << " " << loaded->points.size() << "\n";
+        }
         std::vector<int> bkeys;
         for (auto& kv : fb.hash_cloud) bkeys.push_back(kv.first);
         std::sort(bkeys.begin(), bkeys.end());

@@ -109,6 +109,28 @@ void SSC::makeHashCloud(const std::vector<PointAPRI>& apriIn_) {
     fillHashCloud(r, apriIn_.data());
 }
 
+// getCloud's per-scan filter + downsample (ssc.cpp:1063-1076, 1103-1106) as one call; rgb_cloud / ori_cloud (plots and
+// evaluation copies) are not produced
+pcl::PointCloud<pcl::PointXYZI>::Ptr SSC::filterAndDownsample(const std::vector<float>& values_cloud,
+                                                              const std::vector<uint32_t>& values_label) {
+    const int num_points = (int)values_label.size();
+    if (values_cloud.size() < (size_t)4 * num_points) throw std::runtime_error("filterAndDownsample: cloud shorter than labels");
+    const float leaf[3] = {0.08f, 0.08f, 0.08f};  // sample.setLeafSize(0.08, 0.08, 0.08)
+    std::vector<float> out((size_t)4 * (num_points > 0 ? num_points : 1));
+    int n_out = 0;
+    chk(ctx_, scvod_voxelgrid(ctx_, values_cloud.data(), values_label.data(), num_points, leaf, max_intensity, out.data(), num_points,
+                              &n_out), "scvod_voxelgrid");
+    pcl::PointCloud<pcl::PointXYZI>::Ptr raw_cloud(new pcl::PointCloud<pcl::PointXYZI>());
+    raw_cloud->points.resize(n_out);
+    for (int k = 0; k < n_out; ++k) {
+        raw_cloud->points[k].x = out[4 * k];
+        raw_cloud->points[k].y = out[4 * k + 1];
+        raw_cloud->points[k].z = out[4 * k + 2];
+        raw_cloud->points[k].intensity = out[4 * k + 3];
+    }
+    return raw_cloud;
+}
+
 // SSC::process up to makeHashCloud as ONE trip to the GPU (ssc.cpp:224-241); the debug dumps of the
 // reference (intensityVisualization, recordIntensity) are not part of the hot path.
 void SSC::process(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloudIn_) {

@@ -46,6 +46,10 @@ class SSC : public Utility {
     // clustering (ssc.cpp:299-393) + bounding-box refine / recognise rules (ssc.cpp:437-467, 849-872);
     // no intensity merge, no region growing (building and tree both become `tree`).
     void segmentGpu();
+    // The per-scan body of getCloud (ssc.cpp:1063-1106) without the file I/O: label filter (label & 0xFFFF in {0, 1}
+    // skipped), intensity * max_intensity, pcl::VoxelGrid 0.08 m -- the cloud that cloud_vec receives.
+    pcl::PointCloud<pcl::PointXYZI>::Ptr filterAndDownsample(const std::vector<float>& values_cloud,
+                                                             const std::vector<uint32_t>& values_label);
 
     scvod_ctx* ctx() const { return ctx_; }
     int dynamic_num_last = 0;  // what the reference only logs (ssc.cpp:1424)

@@ -32,6 +32,7 @@ ssc:
   sector_res_: {sector_res}
   azimuth_res_: {azimuth_res}
   occupancy_: {occupancy}
+  max_intensity_: 255.0  # intenisty calibration
   building_: 0  # cluster map
   tree_: 1
   car_: 2
@@ -108,6 +109,14 @@ def test_facade_members_match_oracle(scvod, oracle, tmp_path):
     assert int(t[5]) == dyn and int(t[7]) == ncl
     assert np.array_equal(np.loadtxt(f"{pre}_next_labels.txt", dtype=np.int32), labels)
     assert (st[:, 1] == 1).any() and (st[:, 1] == 0).any()      # both outcomes occur
+    # SSC::filterAndDownsample (getCloud's label filter + intensity scaling + VoxelGrid 0.08 m) == the oracle
+    x = scans[0]
+    i = np.arange(len(x))
+    lab = np.where(i % 9 == 0, 0, np.where(i % 13 == 0, 0x00030001, 40 + i % 5)).astype(np.uint32)
+    ref, _ = oracle.voxelgrid(x, (0.08, 0.08, 0.08), labels=lab, max_intensity=255.0)
+    got = np.fromfile(f"{pre}_a_loaded.f32", np.float32).reshape(-1, 4)
+    assert out["loaded"].split() == [str(len(x)), str(len(ref))]
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
 def test_voxelize_entry_point(scvod, oracle):
