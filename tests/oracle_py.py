@@ -47,7 +47,7 @@ class Oracle:
         self.lib.oracle_grid_dims(C.byref(p), *[C.byref(x) for x in o])
         return tuple(x.value for x in o)
 
-    def patchwork(self, params, xyzi, sort_mode=1):
+    def patchwork(self, params, xyzi, sort_mode=1, pw=None):
         a = np.ascontiguousarray(xyzi, np.float32)
         n = a.shape[0]
         cls = np.zeros(max(n, 1), np.uint8)
@@ -55,7 +55,7 @@ class Oracle:
         ng = np.zeros(max(n, 1), np.int32)
         planes = np.zeros(1024, PLANE_DTYPE)
         n_g, n_ng, n_p = C.c_int32(), C.c_int32(), C.c_int32()
-        self.lib.oracle_patchwork(C.byref(params), None, _p(a), n, sort_mode, _p(cls), _p(g), C.byref(n_g), _p(ng),
+        self.lib.oracle_patchwork(C.byref(params), C.byref(pw) if pw is not None else None, _p(a), n, sort_mode, _p(cls), _p(g), C.byref(n_g), _p(ng),
                                   C.byref(n_ng), _p(planes), C.byref(n_p))
         return dict(cls=cls[:n], ground_idx=g[:n_g.value], nonground_idx=ng[:n_ng.value], planes=planes[:n_p.value])
 

@@ -50,6 +50,48 @@ def test_process_scan_parity(scvod, oracle, kind, preset, seq, idx):
     ctx.close()
 
 
+def _pw(scvod, **kw):
+    import ctypes as C
+    pw = scvod.PwParams()
+    scvod.load_lib().scvod_pw_params_default(C.byref(pw))
+    for k, v in kw.items():
+        if isinstance(v, (list, tuple)):
+            for i, x in enumerate(v):
+                getattr(pw, k)[i] = x
+        else:
+            setattr(pw, k, v)
+    return pw
+
+
+@pytest.mark.parametrize("case", [
+    dict(max_range=50.0, min_range=1.0, num_sectors_each_zone=[12, 20, 36, 24], num_rings_each_zone=[3, 3, 5, 2]),
+    dict(num_iter=2, num_lpr=10, th_seeds=0.3, th_dist=0.2, num_min_pts=20, uprightness_thr=0.8),
+    dict(max_range=120.0, min_range=0.5, num_rings_of_interest=6, adaptive_seed_selection_margin=-0.9,
+         elevation_thr=[-1.0, -0.9, -0.8, -0.7], flatness_thr=[1e-4, 1e-4, 2e-4, 3e-4]),
+])
+def test_custom_patchwork_constants(scvod, oracle, case):
+    """Patchwork constants other than the reference's hard-coded set (patchwork.h:48-51, 115-129): zone / ring /
+    sector layout, seeds, iterations, gates.  Exercises the fp32 fast paths of the patch id against parameters they
+    were not tuned on."""
+    import synth
+    P = _params(scvod, "semantickitti")
+    pw = _pw(scvod, **case)
+    x = synth.make_scan(5, 321, "K64")[0].numpy()
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1, pw=pw)
+    r = ctx.process_scan(x)
+    o = oracle.patchwork(P, x, 1, pw=pw)
+    assert np.array_equal(r["cls"], o["cls"])
+    assert np.array_equal(r["ground_idx"], o["ground_idx"]) and np.array_equal(r["nonground_idx"], o["nonground_idx"])
+    assert r["planes"].shape == o["planes"].shape
+    live = o["planes"]["status"] > 0
+    for f in ("n_pts", "n_ground", "status"):
+        assert np.array_equal(r["planes"][f], o["planes"][f]), f
+    for f in ("normal", "mean", "sv"):
+        assert np.array_equal(r["planes"][f][live].view(np.uint32), o["planes"][f][live].view(np.uint32)), f
+    assert 0 < r["n_ground"] < x.shape[0]
+    ctx.close()
+
+
 def test_batch_matches_per_scan(scvod, oracle):
     import torch
     import synth
