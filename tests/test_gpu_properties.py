@@ -112,3 +112,49 @@ def test_self_probe_hits_every_voxel(scvod):
     assert np.array_equal(r["vox_key"][hit], a["voxel_idx"])
     assert np.array_equal(uq, np.arange(r["n_voxels"]))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_repeated_batches_are_bitwise_identical(scvod):
+    """Scatters and unions use atomics (non-deterministic intermediate order), every exported array is canonical:
+    five runs of the same 24-scan batch must agree bit for bit in everything a caller can fetch, including clusters,
+    types and the tracking counts."""
+    import hashlib
+    import torch
+    import synth
+    P = scvod.make_params("semantickitti")
+    count = 24
+    pts, offs, poses, _ = synth.make_batch(5, 1500, count, "K64", device="cuda")
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)])
+
+    def digest():
+        h = hashlib.sha256()
+        ctx.batch_process(pts, offs)
+        cnt = ctx.batch_counts().copy()
+        h.update(cnt.tobytes())
+        for s in (0, 7, count - 1):
+            r = ctx.batch_fetch(s)
+            for k in ("cls", "ground_idx", "nonground_idx", "planes", "apri", "apri_src", "rejected_src", "vox_key",
+                      "vox_pt_begin", "vox_pts", "vox_av", "vox_cov"):
+                h.update(np.ascontiguousarray(r[k]).tobytes())
+        ctx.batch_cluster()
+        ctx.batch_cluster_types()
+        members, cbegin, pbegin = [], [0], [0]
+        for s in range(count):
+            h.update(ctx.batch_fetch_clusters(s, int(cnt[s, 4])).tobytes())
+            t = ctx.batch_fetch_cluster_types(s, int(cnt[s, 4]))
+            h.update(t.tobytes())
+            if s < count - 1:
+                m = np.nonzero(t == 2)[0].astype(np.int32)
+                members.append(m)
+                cbegin.append(cbegin[-1] + len(m))
+                pbegin.append(len(cbegin) - 1)
+        ctx.batch_track(torch.from_numpy(np.concatenate(members)).cuda(), cbegin, pbegin, T)
+        h.update(ctx.batch_track_counts().tobytes())
+        return h.hexdigest()
+
+    first = digest()
+    for _ in range(4):
+        assert digest() == first
+    ctx.close()
