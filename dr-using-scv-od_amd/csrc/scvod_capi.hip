@@ -166,11 +166,13 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
     A.vg_par = k.take<int32_t>(B * 16);
-    A.vg_range = k.take<int32_t>(1);
+    A.vg_range = k.take<int32_t>(2);  // [0] largest cell-index range of the batch, [1] bin shift of the bucket table
     A.vg_outoff = k.take<int32_t>(B + 1);
     c->d_vb_lut = k.take<uint16_t>(B * kVgLutBins);
     A.vb_lut = nullptr;  // hot path: uniform key ranges (DevParams::vb_shift)
-    A.vb_lut_shift = 0;
+    A.vb_lut_shift = nullptr;
+    A.vg_labels = nullptr;
+    A.vg_max_intensity = 1.f;
     c->d_labels = k.take<uint32_t>(N);
     c->t_hit = k.take<int32_t>(N);
     c->t_work = k.take<uint64_t>(N);
@@ -490,35 +492,26 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     J.max_intensity = max_intensity;
     for (int a = 0; a < 3; ++a) J.inv_leaf[a] = 1.0f / leaf[a];
     J.out = (float4*)d_out;
-    launch_voxelgrid_keys(c->A, J, st);
-    HIPCHK(c, hipGetLastError());
-    int32_t range = 0;
-    HIPCHK(c, hipMemcpyAsync(&range, c->A.vg_range, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    // voxel stage with cell indices as keys: 1022 population-balanced buckets (k_vg_lut) + one for the dropped points
+    // everything on the stream, one synchronisation at the end: bounding boxes + cell keys, the population-balanced
+    // bucket table, the voxel stage in its centroid mode, output offsets, compaction into the caller's buffer
+    Arena Av = c->A;
+    Av.vb_lut = c->d_vb_lut;
+    Av.vb_lut_shift = c->A.vg_range + 1;  // second word of the two-int scratch
+    Av.vg_labels = d_labels;
+    Av.vg_max_intensity = max_intensity;
     DevParams D = c->dev;
     D.key_off = 0;
     D.vb_shift = 0;
     D.n_buckets = kMaxBuckets;
-    int lshift = 0;
-    while (((int64_t)range >> lshift) > kVgLutBins - 1) ++lshift;
-    Arena Av = c->A;
-    Av.vb_lut = c->d_vb_lut;
-    Av.vb_lut_shift = lshift;
+    launch_voxelgrid_keys(Av, J, st);
     launch_voxelgrid_lut(Av, st);
     launch_process(D, Av, st, 3, 0, 1, nullptr, nullptr);
-    launch_voxelgrid_centroids(c->A, J, st);
+    launch_voxelgrid_gather(D, Av, J, (long long)out_cap, st);
     HIPCHK(c, hipGetLastError());
-    std::vector<int32_t> par((size_t)n_scans * 16);
-    HIPCHK(c, hipMemcpyAsync(par.data(), c->A.vg_par, sizeof(int32_t) * par.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_out_off, c->A.vg_outoff, sizeof(int32_t) * (n_scans + 1), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    for (int s = 0; s < n_scans; ++s) h_out_off[s + 1] = h_out_off[s] + par[(size_t)s * 16 + 8];
     if (h_out_off[n_scans] > out_cap)
         return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%lld < %d points)", (long long)out_cap, h_out_off[n_scans]);
-    HIPCHK(c, hipMemcpyAsync(c->A.vg_outoff, h_out_off, sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
-    launch_voxelgrid_gather(c->A, J, st);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(st));  // h_out_off is the caller's pageable memory
     return SCVOD_OK;
 }
 

@@ -109,7 +109,9 @@ struct Arena {
     int32_t* vg_range;        // [1] largest cell index range of the batch
     int32_t* vg_outoff;       // [B+1] output offsets (uploaded by the host between the two phases)
     uint16_t* vb_lut;         // [B][kVgLutBins] monotone key-bin -> bucket table of the VoxelGrid run; nullptr in the hot path
-    int32_t vb_lut_shift;     // key >> vb_lut_shift = bin
+    const int32_t* vb_lut_shift;  // device word: key >> *vb_lut_shift = bin (k_vg_lut derives it from the batch's index range)
+    const uint32_t* vg_labels;    // VoxelGrid run only: per input point label (or nullptr) and the loader's intensity scale
+    float vg_max_intensity;
 };
 
 struct TrackJob {          // scan-vs-next-scan probe
@@ -146,12 +148,11 @@ struct VgJob {                // SSC::getCloud label filter + pcl::VoxelGrid (ss
     const uint32_t* labels;   // per input point, or nullptr (no filter, no intensity scaling)
     float max_intensity;
     float inv_leaf[3];        // 1.f / leaf, fp32 like Eigen::Array4f::Ones() / leaf_size_
-    float4* out;              // caller's output buffer (phase 2)
+    float4* out;              // caller's output buffer
 };
 void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st);
 void launch_voxelgrid_lut(const Arena& A, hipStream_t st);
-void launch_voxelgrid_centroids(const Arena& A, const VgJob& J, hipStream_t st);
-void launch_voxelgrid_gather(const Arena& A, const VgJob& J, hipStream_t st);
+void launch_voxelgrid_gather(const DevParams& P, const Arena& A, const VgJob& J, long long out_capacity, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);

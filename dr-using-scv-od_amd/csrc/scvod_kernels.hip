@@ -1380,17 +1380,22 @@ __global__ __launch_bounds__(256) void k_vg_keys(Arena A, VgJob J) {
 // make buckets of tens of thousands of points.  One workgroup per scan histograms the keys into kVgLutBins equal
 // ranges (≈ a 1 m band of one z layer for a KITTI scan at 0.08 m) and cuts the running count into <= 1022 buckets of about equal population; the table is monotone, so bucket
 // order is still key order.
-__global__ __launch_bounds__(1024) void k_vg_lut(Arena A) {
+__global__ __launch_bounds__(1024) void k_vg_lut(Arena A, int32_t* shift_out) {
     extern __shared__ int hist[];  // kVgLutBins counters (64 KB)
     __shared__ int wsum[17];
     const int s = blockIdx.x;
     const int base = A.scan_off[s];
     const int n = A.scan_off[s + 1] - base;
+    // bin width from the largest cell-index range of the batch (every workgroup derives the same value)
+    const long long range = A.vg_range[0];
+    int shift = 0;
+    while ((range >> shift) > kVgLutBins - 1) ++shift;
+    if (s == 0 && threadIdx.x == 0) *shift_out = shift;
     for (int b = threadIdx.x; b < kVgLutBins; b += 1024) hist[b] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 1024) {
         const int32_t key = A.apri_key[(size_t)base + i];
-        if (key != kVgDropped) atomicAdd(&hist[key >> A.vb_lut_shift], 1);
+        if (key != kVgDropped) atomicAdd(&hist[key >> shift], 1);
     }
     __syncthreads();
     const int kept = A.vg_par[s * 16 + 7];
@@ -1407,40 +1412,33 @@ __global__ __launch_bounds__(1024) void k_vg_lut(Arena A) {
     }
 }
 
-// one lane per cell: CentroidPoint over the cell's points in ascending input index (fp32 running sums, / float(count))
-__global__ __launch_bounds__(256) void k_vg_centroid(Arena A, VgJob J) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int nv = A.counts[s * 8 + 6];
-    const int32_t* vbeg = A.vox_pt_begin + base + s;
-    float4* tmp = (float4*)A.apri;  // the PointAPRI array is idle here: 16 of its 44 bytes per point hold the centroids
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
-        if (A.vox_key[(size_t)base + v] == kVgDropped) continue;
-        const int b0 = vbeg[v], b1 = vbeg[v + 1];
-        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-        for (int k = b0; k < b1; ++k) {
-            const float4 p = A.pts[base + A.vox_pts[(size_t)base + k]];
-            sx += p.x;
-            sy += p.y;
-            sz += p.z;
-            si += J.labels ? p.w * J.max_intensity : p.w;
-        }
-        const float fn = (float)(b1 - b0);
-        tmp[(size_t)base + v] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+// output offsets = exclusive scan over the scans of their cell counts (one workgroup)
+__global__ __launch_bounds__(1024) void k_vg_outoff(Arena A) {
+    __shared__ int wsum[17];
+    int run = 0;
+    for (int s0 = 0; s0 < A.n_scans; s0 += 1024) {
+        const int s = s0 + threadIdx.x;
+        const int c = (s < A.n_scans) ? A.counts[s * 8 + 6] : 0;
+        int total;
+        const int ex = block_excl_scan<1024>(c, total, wsum);
+        if (s < A.n_scans) A.vg_outoff[s] = run + ex;
+        run += total;
+        __syncthreads();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int dropped = (nv > 0 && A.vox_key[(size_t)base + nv - 1] == kVgDropped) ? 1 : 0;
-        A.vg_par[s * 16 + 8] = nv - dropped;
-    }
+    if (threadIdx.x == 0) A.vg_outoff[A.n_scans] = run;
 }
 
-__global__ __launch_bounds__(256) void k_vg_gather(Arena A, VgJob J) {
-    const int s = blockIdx.y;
+// compaction of the per-bucket centroid runs into the caller's buffer (ascending cell index = bucket order)
+__global__ __launch_bounds__(256) void k_vg_final(Arena A, VgJob J, long long out_capacity) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    const int nv = A.vb_nvox[s * kMaxBuckets + b];
+    if (nv == 0) return;
     const int base = A.scan_off[s];
-    const int n_out = A.vg_par[s * 16 + 8];
+    const int src = A.vb_off[s * (kMaxBuckets + 1) + b];
+    const long long dst = (long long)A.vg_outoff[s] + A.vox_off[s * (kMaxBuckets + 1) + b];
     const float4* tmp = (const float4*)A.apri;
-    float4* dst = J.out + A.vg_outoff[s];
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < n_out; v += gridDim.x * 256) dst[v] = tmp[(size_t)base + v];
+    for (int v = threadIdx.x; v < nv; v += 256)
+        if (dst + v < out_capacity) J.out[dst + v] = tmp[(size_t)base + src + v];
 }
 
 // PointAPRI records (ssc.cpp:176-193) of scans [s0, s0 + gridDim.y), rebuilt from the compact apri_vec: the same spec
@@ -1558,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_apri_split(Arena A) {
 __device__ __forceinline__ int vx_bucket_of(const DevParams& P, const Arena& A, int s, int32_t voxel_idx) {
     if (A.vb_lut) {  // VoxelGrid run: population-balanced monotone table (cell indices are far from uniform)
         if (voxel_idx == 0x7fffffff) return kMaxBuckets - 1;
-        return A.vb_lut[(size_t)s * kVgLutBins + (voxel_idx >> A.vb_lut_shift)];
+        return A.vb_lut[(size_t)s * kVgLutBins + (voxel_idx >> *A.vb_lut_shift)];
     }
     int64_t b = ((int64_t)voxel_idx + P.key_off) >> P.vb_shift;
     if (b < 0) b = 0;
@@ -1635,7 +1633,10 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
     }
 }
 
-template <int CAP, int THREADS, int C_LO, int C_HI, int LGE>
+// MODE 0: SSC::makeHashCloud (intensity mean / variance per voxel).  MODE 1: pcl::VoxelGrid run (keys = cell indices):
+// per cell the CentroidPoint sums of its points in ascending input index, straight from the sorted keys in LDS; no
+// point lists, no intensity statistics; the bucket of the dropped points is skipped.
+template <int CAP, int THREADS, int C_LO, int C_HI, int LGE, int MODE = 0>
 __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int SLOTS = CAP + CAP / 8;
@@ -1651,6 +1652,10 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     const int s = code / kMaxBuckets, b = code - s * kMaxBuckets;
     const int m = item.y;
     const int base = item.z, off = item.w;
+    if (MODE == 1 && b == kMaxBuckets - 1) {  // dropped points (label filter): no cells
+        if (threadIdx.x == 0) A.vb_nvox[s * kMaxBuckets + b] = 0;
+        continue;
+    }
     const bool in_lds = (m <= CAP);
     unsigned long long* keys;
     int* vbeg;
@@ -1683,7 +1688,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
             const uint64_t prev = keys[KX(j > 0 ? j - 1 : 0)];
             head = (j == 0) || (key_major(cur) != key_major(prev));
             const uint32_t idx = key_idx(cur);
-            A.vox_pts[(size_t)base + off + j] = (int32_t)idx;
+            if (MODE == 0) A.vox_pts[(size_t)base + off + j] = (int32_t)idx;
         }
         int th;
         int eh = block_excl_scan<THREADS>(head, th, wsum);
@@ -1692,6 +1697,28 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     }
     __syncthreads();
     const int nv = run;
+    if (MODE == 1) {
+        // CentroidPoint (PCL 1.8.1 accumulators.hpp): fp32 running sums of x, y, z, intensity in ascending input index,
+        // each divided by float(count); the intensity is the loader's scaled one when labels are given
+        float4* tmp = (float4*)A.apri;  // idle in a VoxelGrid run: 16 of its 44 bytes per point hold the centroids
+        for (int v = threadIdx.x; v < nv; v += THREADS) {
+            const int j0 = vbeg[v];
+            const int j1 = (v + 1 < nv) ? vbeg[v + 1] : m;
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+            for (int j = j0; j < j1; ++j) {
+                const float4 p = A.pts[base + key_idx(keys[KX(j)])];
+                sx += p.x;
+                sy += p.y;
+                sz += p.z;
+                si += A.vg_labels ? p.w * A.vg_max_intensity : p.w;
+            }
+            const float fn = (float)(j1 - j0);
+            tmp[(size_t)base + off + v] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+        }
+        if (threadIdx.x == 0) A.vb_nvox[s * kMaxBuckets + b] = nv;
+        __syncthreads();  // LDS is reused by the next item
+        continue;
+    }
     if (in_lds) {
         for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + key_idx(keys[KX(j)])];
         __syncthreads();
@@ -2357,6 +2384,24 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_order_offsets, dim3(1), dim3(64), 0, st, A);
         hipLaunchKernelGGL(k_vx_order_scatter, dim3((nb_all + 255) / 256), dim3(256), 0, st, P, A);
         TH_END("vx_order");
+        if (do_patchwork == 3) {  // VoxelGrid run: centroids instead of intensity statistics
+            hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv, 1>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
+            hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 1>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
+            hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv, 1>), dim3(kPersistCUs), dim3(kVoxThreadsL * kTSv),
+                               vox_lds_bytes(kVoxCapL), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 1>), dim3(kPersistCUs * 2), dim3(256 * kTSv),
+                               vox_lds_bytes(4096), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv, 1>), dim3(kPersistCUs * 4), dim3(128 * kTSv),
+                               vox_lds_bytes(2048), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS * kTSv, kClassXS, kClassM - 1, kLGEv, 1>), dim3(kPersistCUs * 8),
+                               dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3, 1>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st,
+                               P, A);
+            hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
+            return;
+        }
         hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
         hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>,
@@ -2402,15 +2447,12 @@ void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st) {
 void launch_voxelgrid_lut(const Arena& A, hipStream_t st) {
     if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
     hipFuncSetAttribute((const void*)k_vg_lut, hipFuncAttributeMaxDynamicSharedMemorySize, kVgLutBins * (int)sizeof(int));
-    hipLaunchKernelGGL(k_vg_lut, dim3(A.n_scans), dim3(1024), kVgLutBins * sizeof(int), st, A);
+    hipLaunchKernelGGL(k_vg_lut, dim3(A.n_scans), dim3(1024), kVgLutBins * sizeof(int), st, A, (int32_t*)A.vb_lut_shift);
 }
-void launch_voxelgrid_centroids(const Arena& A, const VgJob& J, hipStream_t st) {
+void launch_voxelgrid_gather(const DevParams& P, const Arena& A, const VgJob& J, long long out_capacity, hipStream_t st) {
     if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
-    hipLaunchKernelGGL(k_vg_centroid, dim3((A.max_scan_pts + 1023) / 1024, A.n_scans), dim3(256), 0, st, A, J);
-}
-void launch_voxelgrid_gather(const Arena& A, const VgJob& J, hipStream_t st) {
-    if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
-    hipLaunchKernelGGL(k_vg_gather, dim3((A.max_scan_pts + 1023) / 1024, A.n_scans), dim3(256), 0, st, A, J);
+    hipLaunchKernelGGL(k_vg_outoff, dim3(1), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_vg_final, dim3(P.n_buckets, A.n_scans), dim3(256), 0, st, A, J, out_capacity);
 }
 
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st) {
