@@ -791,6 +791,7 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     launch_cluster(c->dev, c->A, st, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     c->clusters_valid = true;
+    c->types_valid = false;  // the link step uses the type array as scratch
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }

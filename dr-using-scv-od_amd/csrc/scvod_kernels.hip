@@ -1837,61 +1837,156 @@ __global__ __launch_bounds__(256) void k_cc_init(Arena A) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         A.cc_parent[(size_t)base + i] = i;
         A.cc_touched[(size_t)base + i] = 0;
+        A.cl_count[(size_t)base + i] = 0;  // runs per voxel (k_cc_runs); cluster sizes only later (k_cc_bbox_init)
     }
 }
 
 constexpr int kCcLdsKeys = 8192;
-// one thread per voxel: neighbourhood look-ups with the index triple(s) of its points
-__global__ __launch_bounds__(256) void k_cc_link(DevParams P, Arena A) {
+// clusterAndCreateFrame walks the points of a voxel in order and searches the 27-neighbourhood only when the index
+// triple differs from the previous point's (ssc.cpp:306-330); a point with the same triple joins the point that opened
+// the run, if that one found any neighbour.  A thread per VOXEL made every wave as slow as its most populated voxel
+// (walls: hundreds of points), so the work is cut by point slot k of the voxel lists instead:
+//   k_cc_runs         per slot: voxel of the slot, does it open a run (first of its voxel or triple != previous)
+//   k_cc_link_starts  per run opener: the neighbourhood searches + unions, remembers whether it found a neighbour
+//   k_cc_link_rest    per other slot: union with its run's opener when that one found a neighbour
+// Same set of unions as the sequential walk, hence the same partition.
+__device__ __forceinline__ int cc_voxel_of_slot(const int32_t* vbeg, int nv, int k) {
+    int lo = 0, hi = nv;  // vbeg[lo] <= k < vbeg[lo + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (vbeg[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_cc_runs(Arena A) {
+    __shared__ int32_t sbeg[kCcLdsKeys + 1];
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
     const int nv = A.counts[s * 8 + 6];
-    // the scan's sorted key table in LDS when it fits (27 binary searches per voxel: eleven dependent L2 round trips
-    // each otherwise)
+    if ((int)blockIdx.x * 256 >= n) return;
+    const int32_t* gbeg = A.vox_pt_begin + base + s;
+    const bool in_lds = nv <= kCcLdsKeys;
+    if (in_lds)
+        for (int i = threadIdx.x; i <= nv; i += 256) sbeg[i] = gbeg[i];
+    __syncthreads();
+    const int32_t* vbeg = in_lds ? sbeg : gbeg;
+    const int32_t* vpts = A.vox_pts + base;
+    const int lane = threadIdx.x & 63;
+    for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) {
+        const int k = k0 + threadIdx.x;
+        const bool valid = k < n;
+        int v = 0, pt = 0, ri = 0, si = 0, ai = 0;
+        if (valid) {
+            v = cc_voxel_of_slot(vbeg, nv, k);
+            pt = vpts[k];
+            A.pt_voxel[(size_t)base + pt] = v;
+            const scvod_apri& a = A.apri[(size_t)base + pt];
+            ri = a.range_idx;
+            si = a.sector_idx;
+            ai = a.azimuth_idx;
+        }
+        // the previous slot's triple comes from the neighbouring lane; only lane 0 of a wave gathers it
+        int pr = __shfl_up(ri, 1), ps = __shfl_up(si, 1), pa = __shfl_up(ai, 1);
+        if (valid) {
+            int start = 1;
+            if (k > vbeg[v]) {
+                if (lane == 0) {
+                    const scvod_apri& q = A.apri[(size_t)base + vpts[k - 1]];
+                    pr = q.range_idx;
+                    ps = q.sector_idx;
+                    pa = q.azimuth_idx;
+                }
+                start = (ri != pr || si != ps || ai != pa) ? 1 : 0;
+            }
+            A.pt_type[(size_t)base + k] = (uint8_t)start;  // per SLOT: bit 0 opens a run, bit 1 (k_cc_link_starts) found a neighbour
+            if (start) atomicAdd(&A.cl_count[(size_t)base + v], 1);
+        }
+    }
+}
+
+// EXTRA = false: one thread per voxel handles the run its first slot opens (dense: every voxel has one).
+// EXTRA = true : one thread per slot handles the openers inside a voxel (index aliasing only: almost none).
+template <bool EXTRA>
+__global__ __launch_bounds__(256) void k_cc_link_starts(DevParams P, Arena A) {
+    // the scan's sorted key table in LDS when it fits (27 binary searches per run)
     __shared__ int32_t skeys[kCcLdsKeys];
-    if ((int)blockIdx.x * 256 >= nv) return;  // the grid is sized for the point count, voxels are far fewer
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    const int nv = A.counts[s * 8 + 6];
+    const int n_items = EXTRA ? n : nv;
+    if ((int)blockIdx.x * 256 >= n_items) return;
+    const int32_t* vbeg = A.vox_pt_begin + base + s;
+    const int32_t* vpts = A.vox_pts + base;
+    if (EXTRA) {  // nothing to do for this block unless one of its slots opens a run inside a voxel
+        const int k = blockIdx.x * 256 + threadIdx.x;
+        bool mine = false;
+        if (k < n && (A.pt_type[(size_t)base + k] & 1)) mine = (k != vbeg[A.pt_voxel[(size_t)base + vpts[k]]]);
+        if (!__syncthreads_or(mine)) return;
+    }
     const int32_t* gkeys = A.vox_key + base;
     const bool in_lds = nv <= kCcLdsKeys;
     if (in_lds)
         for (int i = threadIdx.x; i < nv; i += 256) skeys[i] = gkeys[i];
     __syncthreads();
     const int32_t* keys = in_lds ? skeys : gkeys;
+    int* parent = A.cc_parent + base;
+    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= n_items) return;
+    int k;
+    if (EXTRA) {
+        k = item;
+        if (!(A.pt_type[(size_t)base + k] & 1)) return;
+        if (k == vbeg[A.pt_voxel[(size_t)base + vpts[k]]]) return;  // handled by the per-voxel launch
+    } else {
+        k = vbeg[item];
+    }
+    const int pt = vpts[k];
+    const scvod_apri& a = A.apri[(size_t)base + pt];
+    const int ri = a.range_idx, si = a.sector_idx, ai = a.azimuth_idx;
+    bool found = false;
+    for (int x = ri - 1; x <= ri + 1; ++x) {
+        if (x > R - 1 || x < 0) continue;
+        for (int y = si - 1; y <= si + 1; ++y) {
+            if (y > S - 1 || y < 0) continue;
+            for (int z = ai - 1; z <= ai + 1; ++z) {
+                if (z > Az - 1 || z < 0) continue;
+                const int u = vox_slot_of(keys, nv, x * S + y + z * R * S);
+                if (u < 0) continue;
+                A.cc_touched[(size_t)base + u] = 1;  // every point of u joins (ssc.cpp:316)
+                cc_union(parent, pt, vpts[vbeg[u]]);
+                found = true;
+            }
+        }
+    }
+    if (found) A.pt_type[(size_t)base + k] = 3;
+}
+
+__global__ __launch_bounds__(256) void k_cc_link_rest(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
     const int32_t* vbeg = A.vox_pt_begin + base + s;
     const int32_t* vpts = A.vox_pts + base;
     int* parent = A.cc_parent + base;
-    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
-        const int b0 = vbeg[v], b1 = vbeg[v + 1];
-        int done_r = 0x7fffffff, done_s = 0, done_a = 0;  // triple handled last (voxels are almost always uniform)
-        int leader = -1;
-        for (int k = b0; k < b1; ++k) {
-            const int pt = vpts[k];
-            A.pt_voxel[(size_t)base + pt] = v;
-            const scvod_apri& a = A.apri[(size_t)base + pt];
-            const int ri = a.range_idx, si = a.sector_idx, ai = a.azimuth_idx;
-            if (ri == done_r && si == done_s && ai == done_a) {
-                if (leader >= 0) cc_union(parent, pt, leader);  // same neighbourhood as the leader, which was non-empty
-                continue;
-            }
-            done_r = ri;
-            done_s = si;
-            done_a = ai;
-            leader = -1;
-            for (int x = ri - 1; x <= ri + 1; ++x) {
-                if (x > R - 1 || x < 0) continue;
-                for (int y = si - 1; y <= si + 1; ++y) {
-                    if (y > S - 1 || y < 0) continue;
-                    for (int z = ai - 1; z <= ai + 1; ++z) {
-                        if (z > Az - 1 || z < 0) continue;
-                        const int u = vox_slot_of(keys, nv, x * S + y + z * R * S);
-                        if (u < 0) continue;
-                        A.cc_touched[(size_t)base + u] = 1;  // every point of u joins (ssc.cpp:316)
-                        cc_union(parent, pt, vpts[vbeg[u]]);
-                        leader = pt;
-                    }
-                }
-            }
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        if (A.pt_type[(size_t)base + k] & 1) continue;
+        const int pt = vpts[k];
+        const int v = A.pt_voxel[(size_t)base + pt];
+        int o = vbeg[v];  // a voxel with a single run (almost all of them): its opener is the voxel's first slot
+        if (A.cl_count[(size_t)base + v] > 1) {
+            o = k - 1;
+            while (!(A.pt_type[(size_t)base + o] & 1)) --o;  // slot vbeg[v] always opens a run
         }
+        // plain store, no atomics: pt is still its own root (only run openers are ever the target of a union before this
+        // kernel) and the opener precedes it in the voxel's ascending point list, so parent < child holds
+        if (A.pt_type[(size_t)base + o] & 2) parent[pt] = vpts[o];
     }
 }
 
@@ -2469,7 +2564,10 @@ void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHoo
     hipLaunchKernelGGL(k_cc_init, g, dim3(256), 0, st, A);
     TH_END("cc_init");
     TH_BEGIN("cc_link");
-    hipLaunchKernelGGL(k_cc_link, dim3((A.max_scan_pts / 4 + 255) / 256 + 1, B), dim3(256), 0, st, P, A);
+    hipLaunchKernelGGL(k_cc_runs, g, dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_cc_link_starts<false>, dim3((A.max_scan_pts + 255) / 256, B), dim3(256), 0, st, P, A);
+    hipLaunchKernelGGL(k_cc_link_starts<true>, dim3((A.max_scan_pts + 255) / 256, B), dim3(256), 0, st, P, A);
+    hipLaunchKernelGGL(k_cc_link_rest, g, dim3(256), 0, st, A);
     TH_END("cc_link");
     TH_BEGIN("cc_join");
     hipLaunchKernelGGL(k_cc_join, g, dim3(256), 0, st, A);
