@@ -114,3 +114,35 @@ def test_voxelgrid_batch_feeds_the_hot_path(scvod, oracle):
     o = oracle.patchwork(P, got[out_off[1]:out_off[2]], 1)
     assert np.array_equal(r["ground_idx"], o["ground_idx"])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_voxelgrid_error_conventions(scvod):
+    """status codes, never a silent truncation: output buffer too small, bad leaf, too many scans; an earlier batch
+    result is invalidated because the arena is reused"""
+    import ctypes as C
+    import torch
+    import synth
+    pts, offs, _, _ = synth.make_batch(3, 10, 2, "PARK")
+    P = scvod.make_params("parkinglot")
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=2)
+    d_in = pts.cuda()
+    full = torch.empty_like(d_in)
+    out_off = ctx.batch_voxelgrid(d_in, offs, full)
+    need = int(out_off[-1])
+    small = torch.empty((need - 5, 4), device="cuda")
+    with pytest.raises(scvod.ScvodError):
+        ctx.batch_voxelgrid(d_in, offs, small)
+    assert b"output buffer too small" in ctx.lib.scvod_last_error(ctx.h)
+    with pytest.raises(scvod.ScvodError):
+        ctx.batch_voxelgrid(d_in, offs, full, leaf=(0.08, 0.0, 0.08))
+    three = np.array([0, 10, 20, 30], np.int32)
+    with pytest.raises(scvod.ScvodError):
+        ctx.batch_voxelgrid(d_in, three, full)                     # 3 scans > max_scans 2
+    # a processed batch is invalidated by a VoxelGrid run on the same ctx
+    ctx.batch_process(d_in, offs)
+    assert ctx.batch_counts()[0, 0] == offs[1]
+    ctx.batch_voxelgrid(d_in, offs, full)
+    r = scvod.ScanResult()
+    assert ctx.lib.scvod_batch_fetch(ctx.h, 0, C.byref(r)) == -5    # SCVOD_ERR_STATE
+    ctx.close()
