@@ -576,6 +576,7 @@ int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int devi
                  int32_t max_scans, scvod_ctx** out) {
     if (!params || !out || max_points_total <= 0 || max_scans <= 0) return SCVOD_ERR_INVALID;
     *out = nullptr;
+    if (max_points_total > 2147483583ll) return SCVOD_ERR_CAPACITY;  // scan offsets and point indices are int32
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCVOD_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return SCVOD_ERR_NO_DEVICE;
