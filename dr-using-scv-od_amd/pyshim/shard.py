@@ -70,3 +70,29 @@ def exchange_boundary_table(dist, device, first_keys, first_labels=None):
         return None, None
     got = incoming.cpu().numpy()
     return got[0].copy(), got[1].copy()
+
+
+def gather_static_map(dist, device, local_xyzi, root_only=False):
+    """The sequence-level merge `*map += *cloud_i` (the reference accumulates per-scan clouds into one map, ssc.cpp:554 /
+    :1460-1480, in scan order): every rank contributes the world-frame static points of ITS block of scans, already in
+    scan order; the result is their concatenation in rank order = the single-process accumulation order.  Variable sizes:
+    one all_gather of the lengths, one all_gather of the padded payloads (RCCL over xGMI on the GPUs, gloo on CPU).
+    Returns an [n, 4] float32 numpy array (None on non-root ranks when root_only)."""
+    x = np.ascontiguousarray(local_xyzi, np.float32).reshape(-1, 4)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(t.item()) for t in sizes]
+    cap = max(max(sizes), 1)
+    mine = torch.zeros((cap, 4), dtype=torch.float32, device=device)
+    if x.shape[0]:
+        mine[:x.shape[0]] = torch.from_numpy(x).to(device)
+    parts = [torch.empty((cap, 4), dtype=torch.float32, device=device) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    if root_only and rank != 0:
+        return None
+    return np.concatenate([p[:k].cpu().numpy() for p, k in zip(parts, sizes)], 0)

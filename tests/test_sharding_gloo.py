@@ -169,3 +169,42 @@ def test_boundary_pair_uses_the_neighbours_table(oracle, scvod):
     offs[-1] = len(m)
     rhit, _, rub = oracle.track_probe(P, xyzi, offs, oracle.pose_delta(pose_a, pose_b), keys2, (np.arange(len(keys2)) % 7 - 1).astype(np.int32))
     assert hit == rhit.tolist() and ub == rub.tolist() and (rhit >= 0).any()
+
+
+def _map_worker(rank, world, port, n_scans, q):
+    sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import shard
+    lo, hi = shard.block_range(n_scans, rank, world)
+    rng = [np.random.default_rng(100 + i) for i in range(n_scans)]
+    local = [rng[i].normal(size=(50 + 37 * i, 4)).astype(np.float32) for i in range(lo, hi)]   # ragged per-scan clouds
+    local = np.concatenate(local) if local else np.zeros((0, 4), np.float32)
+    full = shard.gather_static_map(dist, torch.device("cpu"), local)
+    only_root = shard.gather_static_map(dist, torch.device("cpu"), local, root_only=True)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (full.tobytes(), only_root is None))
+    if rank == 0:
+        q.put((gathered, only_root.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_static_map_gather_keeps_scan_order():
+    """three ranks (one of them with an empty block): the gathered map is the single-process accumulation, bit for bit"""
+    n_scans, world = 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_map_worker, args=(r, world, port, n_scans, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered, root = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = np.concatenate([np.random.default_rng(100 + i).normal(size=(50 + 37 * i, 4)).astype(np.float32) for i in range(n_scans)])
+    assert all(g[0] == ref.tobytes() for g in gathered) and root == ref.tobytes()
+    assert [g[1] for g in gathered] == [False, True, True]
