@@ -891,16 +891,22 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A, int coop_cl
 // 16 lanes share a patch: each step they test 16 points and form the 9 products in parallel, pass them through LDS
 // transposed, and lanes 0..8 of the group add "their" accumulator over the 16 points IN ORDER -- the sums are the
 // same sequential fp32 sums, only the nine independent chains run on nine lanes instead of one.
-constexpr int kFitCoopPF = 8;  // steps of 16 points in flight per group
+// GL lanes share a patch, 64 / GL patches per wave.  GL = 16 for sequence shards (throughput: four patches keep the
+// nine adding lanes of each busy); GL = 64 for a handful of scans (latency: the parallel part of the largest patch takes
+// a quarter of the steps, only its sequential adds remain a chain).
+template <int GL>
 __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int coop_class) {
-    // [group][accumulator][16 points], rows padded to 20 floats: the nine row reads of a group (b128, rows 80 bytes apart)
-    // then spread over the banks instead of alternating between two 16-byte bank groups
-    __shared__ fitq tile[4 * 9 * 5];
-    const int lane = threadIdx.x, g = lane >> 4, r = lane & 15, gbase = g << 4;
+    constexpr int NG = 64 / GL;
+    constexpr int ROW = GL + 4;             // floats per product row: padded so the nine row reads spread over the banks
+    constexpr int PF = (GL == 16) ? 8 : 2;  // steps in flight per lane (128 points of the patch either way)
+    constexpr unsigned long long FULL = (GL == 64) ? ~0ull : ((1ull << (GL & 63)) - 1ull);
+    __shared__ fitq tile[NG * 9 * ROW / 4];  // [group][accumulator][GL points]
+    const int lane = threadIdx.x, g = lane / GL, r = lane % GL, gbase = g * GL;
+    auto group_bits = [&](unsigned long long ballot) -> unsigned long long { return (ballot >> gbase) & FULL; };
     int lo, hi;
     order_range(A.order_off, coop_class, 63, lo, hi);
-    if (lo + blockIdx.x * 4 >= hi) return;
-    const int w = lo + blockIdx.x * 4 + g;
+    if (lo + (int)blockIdx.x * NG >= hi) return;
+    const int w = lo + blockIdx.x * NG + g;
     const bool live = w < hi;
     const int4 item = live ? A.order[w] : make_int4(0, 0, 0, 0);
     const int code = item.x;
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
     int n_max = n;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) n_max = max(n_max, __shfl_xor(n_max, d));
-    const int n_blocks = (n_max + 16 * kFitCoopPF - 1) / (16 * kFitCoopPF);
+    const int n_blocks = (n_max + GL * PF - 1) / (GL * PF);
 
     int zone = 0;
     while (zone < 3 && p >= P.czm.patch_base[zone + 1]) ++zone;
@@ -924,11 +930,11 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
         bool searching = live && (zone == 0);
         for (int c = 0; __any(searching); ++c) {
             if (searching) {
-                const int j = c * 16 + r;
+                const int j = c * GL + r;
                 const bool low = (j < n) && ((double)sp[j].z < P.czm.seed_margin_z);
-                const uint32_t m16 = (uint32_t)(__ballot(low) >> gbase) & 0xffffu;
-                if (m16 != 0xffffu) {
-                    init_idx = c * 16 + __builtin_ctz(~m16);
+                const unsigned long long mg = group_bits(__ballot(low));
+                if (mg != FULL) {
+                    init_idx = c * GL + __builtin_ctzll(~mg);
                     searching = false;
                 }
             }
@@ -936,13 +942,13 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
     }
     double sum = 0;
     int cnt = 0;
-    for (int i0 = 0; i0 < P.czm.num_lpr; i0 += 16) {
+    for (int i0 = 0; i0 < P.czm.num_lpr; i0 += GL) {
         const int j = init_idx + i0 + r;
         const float zc = (j < n) ? sp[j].z : 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        const int kmax = min(GL, P.czm.num_lpr - i0);
+        for (int k = 0; k < kmax; ++k) {
             const float z = __shfl(zc, gbase + k);
-            if (i0 + k < P.czm.num_lpr && init_idx + i0 + k < n) {
+            if (init_idx + i0 + k < n) {
                 sum += (double)z;
                 ++cnt;
             }
@@ -955,26 +961,26 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
     fit_state_init(F);
     const int n_last = max(n - 1, 0);
     float* tf = (float*)tile;
-    const int acc_row = (g * 9 + (r < 9 ? r : 8)) * 5;  // lanes 9..15 shadow accumulator 8
+    const int acc_row = (g * 9 + (r < 9 ? r : 8)) * (ROW / 4);  // lanes 9.. shadow accumulator 8
 
     for (int iter = 0; iter < P.czm.num_iter; ++iter) {
         const float n0 = F.n0, n1 = F.n1, n2 = F.n2, thd = F.thd;
         float acc = 0.f;
         int m_lane = 0;
         bool busy = n > 0;
-        Xyz cur[kFitCoopPF], nxt[kFitCoopPF];
+        Xyz cur[PF], nxt[PF];
 #pragma unroll
-        for (int k = 0; k < kFitCoopPF; ++k) cur[k] = sp[min(k * 16 + r, n_last)];
+        for (int k = 0; k < PF; ++k) cur[k] = sp[min(k * GL + r, n_last)];
         for (int b = 0; b < n_blocks; ++b) {
-            const int j0 = b * 16 * kFitCoopPF;
+            const int j0 = b * GL * PF;
             // unconditional (clamped) loads: a load under a branch would have to land before the branch joins, which
             // serialises the whole block behind one memory latency
 #pragma unroll
-            for (int k = 0; k < kFitCoopPF; ++k) nxt[k] = sp[min(j0 + (kFitCoopPF + k) * 16 + r, n_last)];
+            for (int k = 0; k < PF; ++k) nxt[k] = sp[min(j0 + (PF + k) * GL + r, n_last)];
 #pragma unroll
-            for (int k = 0; k < kFitCoopPF; ++k) {
+            for (int k = 0; k < PF; ++k) {
                 const Xyz q = cur[k];
-                const int j = j0 + k * 16 + r;
+                const int j = j0 + k * GL + r;
                 bool in = busy && (j < n);
                 bool fails = false;
                 if (iter == 0) {
@@ -985,50 +991,41 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
                 }
                 // non-members contribute +0.0f to every sum: zero the point, the products follow (0 * 0 = +0)
                 const float zx = in ? q.x : 0.f, zy = in ? q.y : 0.f, zz = in ? q.z : 0.f;
-                float* col = tf + g * 9 * 20 + r;
-                col[0 * 20] = zx * zx;
-                col[1 * 20] = zx * zy;
-                col[2 * 20] = zx * zz;
-                col[3 * 20] = zy * zy;
-                col[4 * 20] = zy * zz;
-                col[5 * 20] = zz * zz;
-                col[6 * 20] = zx;
-                col[7 * 20] = zy;
-                col[8 * 20] = zz;
+                float* col = tf + g * 9 * ROW + r;
+                col[0 * ROW] = zx * zx;
+                col[1 * ROW] = zx * zy;
+                col[2 * ROW] = zx * zz;
+                col[3 * ROW] = zy * zy;
+                col[4 * ROW] = zy * zz;
+                col[5 * ROW] = zz * zz;
+                col[6 * ROW] = zx;
+                col[7 * ROW] = zy;
+                col[8 * ROW] = zz;
                 m_lane += in ? 1 : 0;
                 // seeds are a prefix of the z-sorted patch: the group stops after the step in which one fails
-                const bool stop = (iter == 0) && (((uint32_t)(__ballot(fails) >> gbase) & 0xffffu) != 0u);
+                const bool stop = (iter == 0) && (group_bits(__ballot(fails)) != 0ull);
                 // the LDS unit executes one wave's instructions in order, so the rows written above are what the reads
                 // below see; only the compiler has to be kept from reordering them
                 __builtin_amdgcn_wave_barrier();
-                const fitq v0 = tile[acc_row], v1 = tile[acc_row + 1], v2 = tile[acc_row + 2], v3 = tile[acc_row + 3];
                 // adding +0.0f for non-members is exact: the accumulators can never be -0.0f
-                acc += v0.x;
-                acc += v0.y;
-                acc += v0.z;
-                acc += v0.w;
-                acc += v1.x;
-                acc += v1.y;
-                acc += v1.z;
-                acc += v1.w;
-                acc += v2.x;
-                acc += v2.y;
-                acc += v2.z;
-                acc += v2.w;
-                acc += v3.x;
-                acc += v3.y;
-                acc += v3.z;
-                acc += v3.w;
+#pragma unroll
+                for (int q4 = 0; q4 < GL / 4; ++q4) {
+                    const fitq v = tile[acc_row + q4];
+                    acc += v.x;
+                    acc += v.y;
+                    acc += v.z;
+                    acc += v.w;
+                }
                 __builtin_amdgcn_wave_barrier();
-                if (stop || j0 + (k + 1) * 16 >= n) busy = false;
+                if (stop || j0 + (k + 1) * GL >= n) busy = false;
             }
 #pragma unroll
-            for (int k = 0; k < kFitCoopPF; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < PF; ++k) cur[k] = nxt[k];
             if (!__any(busy)) break;
         }
         int m = m_lane;  // members seen by this lane -> members of the group's patch
 #pragma unroll
-        for (int d = 8; d > 0; d >>= 1) m += __shfl_xor(m, d);
+        for (int d = GL / 2; d > 0; d >>= 1) m += __shfl_xor(m, d);
         const float a0 = __shfl(acc, gbase + 0), a1 = __shfl(acc, gbase + 1), a2 = __shfl(acc, gbase + 2),
                     a3 = __shfl(acc, gbase + 3), a4 = __shfl(acc, gbase + 4), a5 = __shfl(acc, gbase + 5),
                     a6 = __shfl(acc, gbase + 6), a7 = __shfl(acc, gbase + 7), a8 = __shfl(acc, gbase + 8);
@@ -2435,7 +2432,10 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         const int coop_class = (B <= 8) ? kClassWave : kClassFitCoop;
         const int coop_min = 1 << (coop_class / 4);
         TH_BEGIN("pw_fit_large");
-        hipLaunchKernelGGL(k_pw_fit_coop, dim3((int)(A.total_pts / coop_min / 4) + 1), dim3(64), 0, st, P, A, coop_class);
+        if (B <= 8)
+            hipLaunchKernelGGL(k_pw_fit_coop<64>, dim3((int)(A.total_pts / coop_min) + 1), dim3(64), 0, st, P, A, coop_class);
+        else
+            hipLaunchKernelGGL(k_pw_fit_coop<16>, dim3((int)(A.total_pts / coop_min / 4) + 1), dim3(64), 0, st, P, A, coop_class);
         TH_END("pw_fit_large");
         TH_BEGIN("pw_fit");
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A, coop_class);
