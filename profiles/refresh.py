@@ -41,6 +41,10 @@ def label(k):
          "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_track_probe_pair": "track_probe", "k_pw_sort_wave": "pw_sort_small"}
     if k in m:
         return m[k]
+    if k.startswith("k_pw_fit_coop"):
+        return "pw_fit_large"
+    if k.startswith("k_cc_link_starts"):
+        return "k_cc_link_starts"
     if k.startswith("k_track_unique"):
         return "track_unique"
     if k.startswith("k_pw_order"):
