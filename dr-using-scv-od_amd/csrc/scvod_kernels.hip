@@ -1,20 +1,27 @@
 // scvod_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the SCV-OD hot path.
 //
 // Stage map (reference file:line -> kernel):
-//   PatchWork::estimate_ground prologue + pc2czm   patchwork.h:277-325,416-459 -> k_pw_classify, k_pw_offsets, k_pw_scatter
-//   extract_piecewiseground / seeds / plane fit    patchwork.h:217-268,463-504 -> k_pw_patch (one workgroup per patch)
-//   gating + emission order                        patchwork.h:326-391         -> k_pw_patch epilogue, k_emit_offsets, k_emit
-//   SSC::makeApriVec                               ssc.cpp:155-195             -> k_emit (fused), k_bin_direct
-//   SSC::makeHashCloud                             ssc.cpp:253-289             -> k_vx_count, k_vx_offsets, k_vx_scatter, k_vx_bucket, k_vx_final*
-//   SSC::tracking bulk part                        ssc.cpp:1274-1321           -> k_track_probe, k_track_unique
-//   kd-tree look-ups of evaluate.cpp:79-145        -> k_nn_brute
+//   PatchWork::estimate_ground prologue + pc2czm   patchwork.h:277-325,416-459 -> k_pw_classify, k_pw_offsets, k_pw_scatter,
+//                                                                                  k_pw_order_*, k_pw_sort_wave, k_pw_sort<...>
+//   extract_piecewiseground / seeds / plane fit    patchwork.h:217-268,463-504 -> k_pw_fit_coop<16|64>, k_pw_fit
+//   gating + emission order                        patchwork.h:326-391         -> fit_finish, k_pw_arrange, k_emit_offsets, k_emit
+//   SSC::makeApriVec                               ssc.cpp:155-195             -> k_emit (fused, compact apri_vec), k_apri_expand,
+//                                                                                  k_bin_direct
+//   SSC::makeHashCloud                             ssc.cpp:253-289             -> k_vx_count, k_vx_offsets, k_vx_scatter, k_vx_order_*,
+//                                                                                  k_vx_bucket<...>, k_vx_final*
+//   SSC::tracking bulk part                        ssc.cpp:1274-1321           -> k_track_probe_pair, k_track_probe, k_track_unique_bits
+//   SSC::clusterAndCreateFrame (next row f-1)      ssc.cpp:299-393             -> k_cc_init/runs/link_starts/link_rest/join/flatten
+//   refineClusterByBoundingBox + recognize rules   ssc.cpp:437-467,849-872     -> k_cc_bbox_init/bbox/type
+//   SSC::getCloud filter + pcl::VoxelGrid (f-3)    ssc.cpp:1063-1076,1103-1106 -> k_vg_minmax/keys/lut/outoff/final, k_vx_bucket<..., 1>
+//   kd-tree look-ups of evaluate.cpp:79-145                                    -> k_nn_count/fill/query, k_nn_brute_list
 //
 // Design notes: the path is gather/scatter + histogramming + short serial
 // fp32 chains; there is no dense contraction, so no MFMA.  Bit-exact parity with the CPU
 // restatement requires (a) the z-sort order inside every patch, (b) strictly sequential
 // fp32 accumulation of the 9 covariance moments in that order, (c) sequential per-voxel
-// intensity sums in point order.  Parallelism therefore comes from patches x scans
-// (504 x B workgroups) and voxels x scans, not from tree reductions of those sums.
+// intensity sums in point order.  Parallelism therefore comes from patches x scans and
+// voxels x scans (and, inside a large patch, from its nine independent sums), not from
+// tree reductions of those sums.
 #include "scvod_kernels.h"
 
 namespace scvod {
@@ -376,16 +383,14 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
 // ------------------------------------------------------------------------------------------
 // Patchwork stage 2 (extract_piecewiseground + gating), split so that every phase has the
 // parallel shape that fits it:
-//   k_pw_sort     one workgroup per (scan, patch): LDS bitonic sort by (z, idx), then writes the
-//                 patch's points in sorted order as float4 {x, y, z, idx | keep-bit} (keep = verdict
-//                 of makeApriVec's range/FOV test).  Tiers: 1024 keys/64 threads, 8192/512, global.
-//   k_pw_order_*  orders the live patches of the whole batch by size class so that the 64 lanes of a
-//                 wave of k_pw_fit walk patches of similar length.
-//   k_pw_fit      ONE THREAD PER PATCH.  The reference's plane fit is a strictly sequential fp32
-//                 computation per patch (9 running sums in z order, 3x3 Jacobi SVD, repeat 3x); it
-//                 cannot be tree-reduced without changing bits, but 504 x B patches are independent,
-//                 so each lane streams its own patch (16 B per point) and keeps the 9 accumulators in
-//                 registers.  No LDS, no cross-lane traffic, SVD runs in all 64 lanes at once.
+//   k_pw_order_*  counting sort of the live patches of the whole batch by quarter-octave size class into order[];
+//                 every later kernel is list-driven (persistent grids striding over their slice of the list).
+//   k_pw_sort*    tiers by size class: LDS bitonic sort of the patch's (z, idx) keys, then the patch's points are
+//                 written in sorted order (packed xyz + input index).
+//   k_pw_fit_coop patches of >= 512 points (>= 64 for a handful of scans): GL lanes per patch; products in parallel,
+//                 the nine sequential fp32 sums on nine lanes.
+//   k_pw_fit      the smaller patches, ONE LANE PER PATCH (the 3x3 Jacobi SVD then costs one lane, not one wave),
+//                 reads staged cooperatively through LDS.
 //   k_pw_arrange  one wave per patch: final plane test, [ground part | non-ground part] arrangement
 //                 and the per-patch counters the ordered emission needs.
 // ------------------------------------------------------------------------------------------
