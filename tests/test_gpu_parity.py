@@ -142,6 +142,38 @@ def test_edge_cases(scvod, oracle):
     ctx.close()
 
 
+def test_patch_sizes_at_every_tier_boundary(scvod, oracle):
+    """one patch of exactly n points for every n next to a size-class boundary of the sort tiers (64 / 256 / 1024 / 2048 /
+    4096 / 8192), of the two plane-fit kernels (512, and 64 for small batches) and of num_min_pts (10): once as a batch
+    (sequence configuration, 16 lanes per large patch) and once scan by scan (latency configuration, 64 lanes), with z
+    ties and duplicated points"""
+    import torch
+    rng = np.random.default_rng(21)
+    P = _params(scvod, "semantickitti")
+    sizes = [9, 10, 11, 12, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096,
+             4097, 8191, 8192, 8193]
+    scans = []
+    for n in sizes:
+        ang = rng.uniform(0.02, 0.37, n)
+        rad = rng.uniform(3.2, 6.8, n)
+        z = np.round(rng.normal(-1.7, 0.04, n), 2)            # many exact z ties
+        x = np.stack([rad * np.cos(ang), rad * np.sin(ang), z, rng.integers(0, 255, n)], 1).astype(np.float32)
+        if n > 20:
+            x[5:9] = x[4]                                       # exact duplicates
+        scans.append(x)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
+    allpts = np.concatenate(scans)
+    ctx = scvod.Ctx(P, max_points_total=len(allpts) + 64, max_scans=len(scans))
+    d = torch.from_numpy(allpts).cuda()
+    ctx.batch_process(d, offs)
+    for s, x in enumerate(scans):
+        o, _, _ = _check_scan(oracle, P, x, ctx.batch_fetch(s), f"batch n={len(x)}")
+        assert int((o["planes"]["n_pts"] > 0).sum()) == 1 and int(o["planes"]["n_pts"].max()) == len(x)   # really ONE patch
+    for x in scans:
+        _check_scan(oracle, P, x, ctx.process_scan(x), f"single n={len(x)}")
+    ctx.close()
+
+
 def test_bin_scan_unfiltered_and_filtered(scvod, oracle):
     rng = np.random.default_rng(3)
     P = _params(scvod, "parkinglot")
