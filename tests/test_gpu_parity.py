@@ -174,6 +174,28 @@ def test_patch_sizes_at_every_tier_boundary(scvod, oracle):
     ctx.close()
 
 
+def test_voxel_bucket_sizes_at_every_tier_boundary(scvod, oracle):
+    """one key bucket of exactly m points for every m next to a tier boundary of the voxel-stage sorts (caller-supplied
+    apri_vec through scvod_voxelize), with heavily repeated keys (many points per voxel) and single-point voxels"""
+    rng = np.random.default_rng(22)
+    P = _params(scvod, "semantickitti")
+    sizes = [1, 2, 63, 64, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 20000]
+    ctx = scvod.Ctx(P, max_points_total=max(sizes) + 64, max_scans=1)
+    for m in sizes:
+        apri = np.zeros(m, scvod.APRI_DTYPE)
+        base_key = 4096 * 37                                   # one bucket of the 72 x 300 x 60 grid (shift 12)
+        apri["voxel_idx"] = base_key + rng.integers(0, 4096 if m % 2 else 40, m)
+        apri["intensity"] = rng.integers(0, 255, m).astype(np.float32) * np.float32(0.37)
+        apri["range_idx"] = apri["voxel_idx"] % 300            # any consistent-looking triple: the stage only uses the key
+        r = ctx.voxelize(apri)
+        v = oracle.voxelize(P, apri)
+        assert np.array_equal(r["vox_key"], v["vox_key"]), m
+        assert np.array_equal(r["vox_pt_begin"], v["vox_pt_begin"]) and np.array_equal(r["vox_pts"], v["vox_pts"]), m
+        assert np.array_equal(r["vox_av"].view(np.uint32), v["vox_av"].view(np.uint32)), m
+        assert np.array_equal(r["vox_cov"].view(np.uint32), v["vox_cov"].view(np.uint32)), m
+    ctx.close()
+
+
 def test_bin_scan_unfiltered_and_filtered(scvod, oracle):
     rng = np.random.default_rng(3)
     P = _params(scvod, "parkinglot")
