@@ -337,13 +337,6 @@ int ensure_counts(scvod_ctx* c) {
     return SCVOD_OK;
 }
 
-template <typename T>
-int dl(scvod_ctx* c, std::vector<T>& dst, const T* src, size_t n) {
-    dst.resize(n ? n : 1);
-    if (n) HIPCHK(c, hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost));
-    return SCVOD_OK;
-}
-
 int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
     int rc = ensure_counts(c);
     if (rc) return rc;

@@ -400,7 +400,6 @@ constexpr int kClassXS = 32, kClassM = 40, kClassM2 = 44, kClassL = 48;  // n >=
 #define SCVOD_FIT_COOP_CLASS 36
 #endif
 constexpr int kClassFitCoop = SCVOD_FIT_COOP_CLASS;  // 36: n >= 512: plane fit by 16 lanes per patch (k_pw_fit_coop)
-constexpr int kFitCoopMin = 1 << (kClassFitCoop / 4);
 
 // order[] lists live items by descending size class; positions of classes [C_LO, C_HI]
 __device__ __forceinline__ void order_range(const int32_t* off, int c_lo, int c_hi, int& lo, int& hi) {
@@ -891,7 +890,7 @@ __global__ __launch_bounds__(64) void k_pw_fit(DevParams P, Arena A, int coop_cl
     fit_finish(P, A, s, p, n, zone, ring, concentric_idx, F);
 }
 
-// Patches of kFitCoopMin points or more: a lane per patch leaves the chip almost empty (a K64 scan has ~40 such
+// Patches of 512 points or more (class kClassFitCoop): a lane per patch leaves the chip almost empty (a K64 scan has ~40 such
 // patches holding 80 % of its points) and runs each of them as one dependent chain thousands of points long.  Here
 // 16 lanes share a patch: each step they test 16 points and form the 9 products in parallel, pass them through LDS
 // transposed, and lanes 0..8 of the group add "their" accumulator over the 16 points IN ORDER -- the sums are the
@@ -2379,11 +2378,9 @@ constexpr int kTS = (kLGE == 4) ? 1 : 2;      // thread multiplier: 8 keys per t
 constexpr int kLGEv = 3, kTSv = 2;             // voxel-bucket sorts measured faster with 8 keys per thread
 constexpr int kPersistCUs = 256;  // MI355X: 256 CUs; list-driven kernels launch a few workgroups per CU
 constexpr int kSortCapS = 1024, kSortThreadsS = 64;
-constexpr int kSortCapM = 4096, kSortThreadsM = 256;
 constexpr int kSortCapL = 8192, kSortThreadsL = 512;
 constexpr size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8; }
 constexpr int kVoxCapS = 1024, kVoxThreadsS = 64;
-constexpr int kVoxCapM = 4096, kVoxThreadsM = 256;
 constexpr int kVoxCapL = 8192, kVoxThreadsL = 512;
 constexpr size_t vox_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8 + (size_t)cap * 8 + 128; }
 
