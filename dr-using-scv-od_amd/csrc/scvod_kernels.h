@@ -22,6 +22,7 @@ struct Xyz {
 struct DevParams {
     BinParams bin;
     CzmParams czm;
+    KeepFast keep;       // shortcut of the range / FOV verdict (scvod_math.h::keep_of_point)
     int64_t key_off;     // added to voxel_idx before bucketing (R*S + S + 1)
     int32_t vb_shift;    // bucket = clamp((voxel_idx + key_off) >> vb_shift, 0, n_buckets-1)
     int32_t n_buckets;

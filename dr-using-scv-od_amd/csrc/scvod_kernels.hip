@@ -1104,8 +1104,7 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
                 g = plane_res(q, n0, n1, n2) < thd;
                 // range/FOV verdict of makeApriVec, only for points that reach the non-ground stream
                 if (!g || rejected) {
-                    Apri a;
-                    keep = apri_of_point(P.bin, q.x, q.y, q.z, 0.f, a);
+                    keep = keep_of_point(P.bin, P.keep, q.x, q.y, q.z);
                     w |= keep ? 0x80000000u : 0u;
                 }
             }

@@ -377,6 +377,42 @@ SCVOD_HD int apri_of_point(const BinParams& g, float x, float y, float z, float 
     return keep;
 }
 
+// ---- range / FOV verdict of makeApriVec WITHOUT the two atan2f of apri_of_point, for callers that only need the
+// verdict (k_pw_arrange).  Same result by construction:
+//   * range: the same fp32 sqrt and comparisons.
+//   * angle: with min_angle <= 0 and max_angle >= 360 the test cannot fail -- polar_angle_deg returns at most
+//     fl32(fl32(2 pi) * 180 / pi) = 360.0f (360.00001 rounds down, the float spacing there is 3e-5) and never a
+//     negative value; NaN compares false in both forms.
+//   * azimuth: atan2f(z, dis) and the conversion to degrees are within 1.2e-5 deg of atan(z / dis) * 180 / pi, so when
+//     t = z / dis is farther than 2e-6 * (1 + t^2) (six times that error, in units of t) from tan(min_azimuth) and
+//     tan(max_azimuth) the decision is known; only points inside that sliver evaluate apri_of_point.
+struct KeepFast {
+    int32_t ok;      // the shortcut is valid for this parameter set
+    float tan_lo, tan_hi;
+};
+inline KeepFast keep_fast_of(const BinParams& g) {
+    KeepFast k;
+    k.ok = (g.min_angle <= 0.0f && g.max_angle >= 360.0f && g.min_azimuth > -89.0f && g.max_azimuth < 89.0f &&
+            g.min_azimuth < g.max_azimuth)
+               ? 1
+               : 0;
+    k.tan_lo = (float)__builtin_tan((double)g.min_azimuth * SCVOD_M_PI / 180.0);
+    k.tan_hi = (float)__builtin_tan((double)g.max_azimuth * SCVOD_M_PI / 180.0);
+    return k;
+}
+SCVOD_HD int keep_of_point(const BinParams& g, const KeepFast& k, float x, float y, float z) {
+    if (k.ok) {
+        const float dis = point_distance2d(x, y);
+        if (dis < g.min_dis || dis > g.max_dis) return 0;
+        const float t = z / dis;  // dis == 0: inf / NaN, which fails every comparison below -> reference arithmetic
+        const float m = 2.0e-6f * (1.0f + t * t);
+        if (t > k.tan_lo + m && t < k.tan_hi - m) return 1;
+        if (t < k.tan_lo - m || t > k.tan_hi + m) return 0;
+    }
+    Apri a;
+    return apri_of_point(g, x, y, z, 0.f, a);
+}
+
 // ---- Patchwork concentric zone model: pc2czm / xy2theta / xy2radius
 // (include/patchwork.h:416-459) ------------------------------------------------------------
 struct CzmParams {

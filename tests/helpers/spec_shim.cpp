@@ -51,6 +51,30 @@ void spec_patch_ids(float sensor_height, const float* xyzi, long n, int* pid) {
     scvod::czm_finalize(c);
     for (long i = 0; i < n; ++i) pid[i] = scvod::czm_patch_of(c, xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2]);
 }
+// fast range/FOV verdict vs the reference arithmetic on n points; returns the number of disagreements and, in
+// *n_fast, how many points the shortcut decided
+long spec_keep_compare(const float g[9], const float* xyz, long n, long* n_fast) {
+    scvod::BinParams b;
+    b.min_dis = g[0]; b.max_dis = g[1]; b.min_angle = g[2]; b.max_angle = g[3]; b.min_azimuth = g[4];
+    b.max_azimuth = g[5]; b.range_res = g[6]; b.sector_res = g[7]; b.azimuth_res = g[8];
+    b.range_num = b.sector_num = b.azimuth_num = b.bin_num = 1;
+    const scvod::KeepFast k = scvod::keep_fast_of(b);
+    scvod::KeepFast off = k;
+    off.ok = 0;
+    long bad = 0, fast = 0;
+    for (long i = 0; i < n; ++i) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const int a = scvod::keep_of_point(b, k, x, y, z), e = scvod::keep_of_point(b, off, x, y, z);
+        bad += (a != e);
+        if (k.ok) {
+            const float dis = scvod::point_distance2d(x, y);
+            const float t = z / dis, m = 2.0e-6f * (1.0f + t * t);
+            fast += (dis < b.min_dis || dis > b.max_dis || (t > k.tan_lo + m && t < k.tan_hi - m) || t < k.tan_lo - m || t > k.tan_hi + m);
+        }
+    }
+    *n_fast = fast;
+    return bad;
+}
 int spec_apri(const float g[9], const int dims[4], const float p[4], float out_f[7], int out_i[4]) {
     scvod::BinParams b;
     b.min_dis = g[0]; b.max_dis = g[1]; b.min_angle = g[2]; b.max_angle = g[3]; b.min_azimuth = g[4];

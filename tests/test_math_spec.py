@@ -128,3 +128,38 @@ def test_patch_ids_spec_equals_libm_oracle(spec, oracle, scvod):
     oracle.lib.oracle_patch_ids(C.byref(P), x.ctypes.data_as(C.c_void_p), n, ref.ctypes.data_as(C.c_void_p))
     assert np.array_equal(got, ref)
     assert (ref >= 0).sum() > n // 2 and ref.max() == 503
+
+
+def test_fast_keep_verdict_equals_reference_arithmetic(spec, scvod):
+    """keep_of_point (range test + tan() window instead of two atan2f) == apri_of_point's verdict on random clouds and on
+    points packed around every boundary (min/max range, azimuth limits within 1e-7..1e-3 rad, the +x axis from below where
+    the polar angle wraps to 360, the z axis), for both YAML presets and a preset that disables the shortcut."""
+    rng = np.random.default_rng(31)
+    for name, extra in (("semantickitti", {}), ("parkinglot", {}), ("semantickitti", dict(max_angle=300.0))):
+        P = scvod.make_params(name, **extra)
+        g = np.array([P.min_dis, P.max_dis, P.min_angle, P.max_angle, P.min_azimuth, P.max_azimuth, P.range_res, P.sector_res,
+                      P.azimuth_res], np.float32)
+        n = 3_000_000
+        r = rng.uniform(0.0, 1.2 * P.max_dis, n)
+        th = rng.uniform(0, 2 * np.pi, n)
+        az = np.deg2rad(rng.uniform(-89, 89, n))
+        # azimuth limits: a third of the points within 1e-7 .. 1e-3 rad of one of them
+        k = n // 3
+        lim = np.deg2rad(rng.choice([P.min_azimuth, P.max_azimuth], k))
+        az[:k] = lim + rng.choice([-1, 1], k) * 10.0 ** rng.uniform(-7.5, -3, k)
+        # range limits
+        r[k:k + k // 2] = rng.choice([P.min_dis, P.max_dis], k // 2) * (1 + rng.choice([-1, 1], k // 2) * 10.0 ** rng.uniform(-8, -4, k // 2))
+        x = np.stack([r * np.cos(th), r * np.sin(th), r * np.tan(az)], 1).astype(np.float32)
+        x[-3000:-2000, 1] = -np.abs(x[-3000:-2000, 1]) * 1e-6       # just below the +x axis: polar angle -> 360
+        x[-3000:-2000, 0] = np.abs(x[-3000:-2000, 0])
+        x[-2000:-1000, :2] = 0.0                                     # on the z axis (dis == 0)
+        x[-1000:-500, 2] = 0.0
+        x[-500:] = rng.integers(0, 2**32, (500, 3), dtype=np.uint64).astype(np.uint32).view(np.float32)   # arbitrary bit patterns
+        n_fast = C.c_long(0)
+        spec.spec_keep_compare.restype = C.c_long
+        bad = spec.spec_keep_compare(g.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_long(n), C.byref(n_fast))
+        assert bad == 0, (name, extra, bad)
+        if extra:
+            assert n_fast.value == 0                                  # shortcut disabled: max_angle < 360
+        else:
+            assert n_fast.value > 0.6 * n                             # and it really decides most points
