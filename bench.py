@@ -38,10 +38,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 #   voxels    : 20 V                                                   -> vx_* kernels
 #   tracking  : 16 N_car + 4 N_car + 64                                -> track_* kernels
 STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter": "patchwork",
-            "pw_sort_small": "patchwork", "pw_sort_mid": "patchwork", "pw_sort_large": "patchwork", "pw_order": "patchwork", "pw_fit": "patchwork", "pw_fit_large": "patchwork",
+            "pw_sort_wave": "patchwork", "pw_sort_256": "patchwork", "pw_sort_1024": "patchwork", "pw_sort_2048": "patchwork", "pw_sort_4096": "patchwork", "pw_sort_8192": "patchwork", "pw_order": "patchwork", "pw_fit": "patchwork", "pw_fit_large": "patchwork",
             "pw_arrange": "patchwork", "emit_offsets": "patchwork",
             "emit": "binning", "vx_count": "voxels", "vx_offsets": "voxels", "vx_order": "voxels", "vx_scatter": "voxels",
-            "vx_bucket_small": "voxels", "vx_bucket_mid": "voxels", "vx_bucket_large": "voxels", "vx_final_offsets": "voxels",
+            "vx_bucket_256": "voxels", "vx_bucket_1024": "voxels", "vx_bucket_2048": "voxels", "vx_bucket_4096": "voxels", "vx_bucket_8192": "voxels", "vx_final_offsets": "voxels",
             "vx_final": "voxels", "track_probe": "tracking", "track_unique": "tracking"}
 
 

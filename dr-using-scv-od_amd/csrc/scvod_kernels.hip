@@ -2410,23 +2410,29 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_END("pw_order");
         hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, 63, kLGE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortCapL));
-        TH_BEGIN("pw_sort_large");  // largest first: their tail overlaps the smaller tiers' launches
+        TH_BEGIN("pw_sort_8192");  // one timing label per kernel; largest first: their tail overlaps the smaller tiers' launches
         hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, 63, kLGE>), dim3(kPersistCUs * 2), dim3(kSortThreadsL * kTS),
                            sort_lds_bytes(kSortCapL), st, P, A);
-        TH_END("pw_sort_large");
-        TH_BEGIN("pw_sort_mid");
+        TH_END("pw_sort_8192");
+        TH_BEGIN("pw_sort_4096");
         hipLaunchKernelGGL((k_pw_sort<4096, 256 * kTS, kClassM2, kClassL - 1, kLGE>), dim3(kPersistCUs * 4), dim3(256 * kTS),
                            sort_lds_bytes(4096), st, P, A);
+        TH_END("pw_sort_4096");
+        TH_BEGIN("pw_sort_2048");
         hipLaunchKernelGGL((k_pw_sort<2048, 128 * kTS, kClassM, kClassM2 - 1, kLGE>), dim3(kPersistCUs * 8), dim3(128 * kTS),
                            sort_lds_bytes(2048), st, P, A);
-        TH_END("pw_sort_mid");
-        TH_BEGIN("pw_sort_small");
+        TH_END("pw_sort_2048");
+        TH_BEGIN("pw_sort_1024");
         hipLaunchKernelGGL((k_pw_sort<kSortCapS, kSortThreadsS * kTS, kClassXS, kClassM - 1, kLGE>), dim3(kPersistCUs * 16),
                            dim3(kSortThreadsS * kTS), sort_lds_bytes(kSortCapS), st, P, A);
+        TH_END("pw_sort_1024");
+        TH_BEGIN("pw_sort_256");
         hipLaunchKernelGGL((k_pw_sort<256, 64, kClassWave, kClassXS - 1, 3>), dim3(kPersistCUs * 32), dim3(64),
                            sort_lds_bytes(256), st, P, A);
+        TH_END("pw_sort_256");
+        TH_BEGIN("pw_sort_wave");
         hipLaunchKernelGGL(k_pw_sort_wave, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
-        TH_END("pw_sort_small");
+        TH_END("pw_sort_wave");
         // Throughput (a sequence shard) wants the 16-lane fit only where a lane per patch starves the chip (>= 512
         // points); a handful of scans (the per-scan host API) has too few patches to fill it either way, and the lane-per-
         // patch chain of a 500-point patch is then the latency: everything from 64 points up goes to the 16-lane kernel.
@@ -2502,22 +2508,26 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
         hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
-        TH_BEGIN("vx_bucket_large");
+        TH_BEGIN("vx_bucket_8192");
         hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv>), dim3(kPersistCUs), dim3(kVoxThreadsL * kTSv),
                            vox_lds_bytes(kVoxCapL), st, P, A);
-        TH_END("vx_bucket_large");
-        TH_BEGIN("vx_bucket_mid");
+        TH_END("vx_bucket_8192");
+        TH_BEGIN("vx_bucket_4096");
         hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>), dim3(kPersistCUs * 2), dim3(256 * kTSv),
                            vox_lds_bytes(4096), st, P, A);
+        TH_END("vx_bucket_4096");
+        TH_BEGIN("vx_bucket_2048");
         hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv>), dim3(kPersistCUs * 4), dim3(128 * kTSv),
                            vox_lds_bytes(2048), st, P, A);
-        TH_END("vx_bucket_mid");
-        TH_BEGIN("vx_bucket_small");
+        TH_END("vx_bucket_2048");
+        TH_BEGIN("vx_bucket_1024");
         hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS * kTSv, kClassXS, kClassM - 1, kLGEv>), dim3(kPersistCUs * 8),
                            dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS), st, P, A);
+        TH_END("vx_bucket_1024");
+        TH_BEGIN("vx_bucket_256");
         hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st,
                            P, A);
-        TH_END("vx_bucket_small");
+        TH_END("vx_bucket_256");
         TH_BEGIN("vx_final_offsets");
         hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("vx_final_offsets");

@@ -38,7 +38,7 @@ def label(k):
     m = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_pw_fit_coop": "pw_fit_large",
          "k_pw_arrange": "pw_arrange", "k_emit_offsets": "emit_offsets", "k_emit": "emit", "k_vx_count": "vx_count",
          "k_vx_offsets": "vx_offsets", "k_vx_scatter": "vx_scatter", "k_vx_final_offsets": "vx_final_offsets",
-         "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_track_probe_pair": "track_probe", "k_pw_sort_wave": "pw_sort_small"}
+         "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_track_probe_pair": "track_probe", "k_pw_sort_wave": "pw_sort_wave"}
     if k in m:
         return m[k]
     if k.startswith("k_pw_fit_coop"):
@@ -54,7 +54,7 @@ def label(k):
     for pre, l in (("k_pw_sort", "pw_sort"), ("k_vx_bucket", "vx_bucket")):
         if k.startswith(pre):
             cap = int(re.search(r"<(\d+)", k).group(1))
-            return l + ("_small" if cap <= 1024 else "_mid" if cap <= 4096 else "_large")
+            return l + "_" + str(cap)
     return k
 
 
