@@ -63,6 +63,8 @@ struct scvod_ctx {
     hipStream_t last_stream = nullptr;
     int32_t last_track_clusters = 0;
     // host staging for scvod_scan_result
+    void* nn_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // scvod_nn_search scratch (grow-only)
+    size_t nn_cap[6] = {0, 0, 0, 0, 0, 0};
     void* stage = nullptr;       // pinned host block holding the arrays of the last scvod_scan_result
     size_t stage_bytes = 0;
     // timing
@@ -628,6 +630,8 @@ void scvod_destroy(scvod_ctx* c) {
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->arena_base) hipFree(c->arena_base);
     if (c->stage) hipHostFree(c->stage);
+    for (void* b : c->nn_buf)
+        if (b) hipFree(b);
     delete c;
 }
 
@@ -946,48 +950,73 @@ int scvod_voxelgrid(scvod_ctx* c, const float* h_xyzi, const uint32_t* h_labels,
     return SCVOD_OK;
 }
 
-int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,
-                    float radius, int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within) {
-    if (!c || n_map < 0 || n_query < 0) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
-    HIPCHK(c, hipSetDevice(c->device));
-    float *d_map = nullptr, *d_q = nullptr, *d_sq = nullptr;
-    int32_t* d_idx = nullptr;
-    uint8_t* d_w = nullptr;
-    int* d_work = nullptr;
-    const size_t nm = n_map ? n_map : 1, nq = n_query ? n_query : 1;
-    // grid: cell edge >= radius (so `within` is decided by the 27-cell probe), origin = min corner of the map
-    float origin[3] = {0.f, 0.f, 0.f};
-    for (int i = 0; i < n_map; ++i)
-        for (int k = 0; k < 3; ++k)
-            if (i == 0 || h_map_xyz[3 * (size_t)i + k] < origin[k]) origin[k] = h_map_xyz[3 * (size_t)i + k];
+// grow-only device scratch owned by the ctx (no allocation on the steady-state path, nothing to leak on an error return)
+static int nn_reserve(scvod_ctx* c, int slot, size_t bytes, void** out) {
+    if (bytes > c->nn_cap[slot]) {
+        if (c->nn_buf[slot]) hipFree(c->nn_buf[slot]);
+        c->nn_buf[slot] = nullptr;
+        c->nn_cap[slot] = 0;
+        HIPCHK(c, hipMalloc(&c->nn_buf[slot], bytes + bytes / 4));
+        c->nn_cap[slot] = bytes + bytes / 4;
+    }
+    *out = c->nn_buf[slot];
+    return SCVOD_OK;
+}
+
+static int nn_run(scvod_ctx* c, const float* d_map, int32_t n_map, const float* d_q, int32_t n_query, float radius,
+                  int32_t* d_idx, float* d_sq, uint8_t* d_w, const float origin[3], hipStream_t st) {
+    // grid: cell edge >= radius (so `within` is decided by the 27-cell probe); the origin only shifts the hash
     const float cell = radius > 0.2f ? radius : 0.2f;
     int32_t buckets = 1024;
     while (buckets < 2 * n_map && buckets < (1 << 26)) buckets <<= 1;
+    const size_t nm = n_map ? n_map : 1, nq = n_query ? n_query : 1;
     const size_t work_ints = 3 * (size_t)buckets + nm + nq + 8 + (size_t)buckets / 1024 + 1;
-    HIPCHK(c, hipMalloc(&d_map, nm * 12));
-    HIPCHK(c, hipMalloc(&d_q, nq * 12));
-    HIPCHK(c, hipMalloc(&d_sq, nq * 4));
-    HIPCHK(c, hipMalloc(&d_idx, nq * 4));
-    HIPCHK(c, hipMalloc(&d_w, nq));
-    HIPCHK(c, hipMalloc(&d_work, work_ints * sizeof(int)));
+    void* d_work = nullptr;
+    int rc = nn_reserve(c, 5, work_ints * sizeof(int), &d_work);
+    if (rc) return rc;
+    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, origin, cell, buckets, (int*)d_work, st);
+    HIPCHK(c, hipGetLastError());
+    return SCVOD_OK;
+}
+
+int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,
+                    float radius, int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within) {
+    if (!c || n_map < 0 || n_query < 0 || (n_map > 0 && !h_map_xyz) || (n_query > 0 && !h_query_xyz))
+        return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nm = n_map ? n_map : 1, nq = n_query ? n_query : 1;
+    float origin[3] = {0.f, 0.f, 0.f};  // min corner of the map (keeps the cell coordinates small)
+    for (int i = 0; i < n_map; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (i == 0 || h_map_xyz[3 * (size_t)i + k] < origin[k]) origin[k] = h_map_xyz[3 * (size_t)i + k];
+    void *d_map, *d_q, *d_sq, *d_idx, *d_w;
+    int rc;
+    if ((rc = nn_reserve(c, 0, nm * 12, &d_map)) || (rc = nn_reserve(c, 1, nq * 12, &d_q)) || (rc = nn_reserve(c, 2, nq * 4, &d_sq)) ||
+        (rc = nn_reserve(c, 3, nq * 4, &d_idx)) || (rc = nn_reserve(c, 4, nq, &d_w)))
+        return rc;
     hipStream_t st = c->stream;
     if (n_map) HIPCHK(c, hipMemcpyAsync(d_map, h_map_xyz, (size_t)n_map * 12, hipMemcpyHostToDevice, st));
     if (n_query) HIPCHK(c, hipMemcpyAsync(d_q, h_query_xyz, (size_t)n_query * 12, hipMemcpyHostToDevice, st));
-    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, origin, cell, buckets, d_work, st);
-    HIPCHK(c, hipGetLastError());
+    if ((rc = nn_run(c, (const float*)d_map, n_map, (const float*)d_q, n_query, radius, (int32_t*)d_idx, (float*)d_sq, (uint8_t*)d_w,
+                     origin, st)))
+        return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     if (n_query) {
         if (h_nn_idx) HIPCHK(c, hipMemcpy(h_nn_idx, d_idx, (size_t)n_query * 4, hipMemcpyDeviceToHost));
         if (h_nn_sqdist) HIPCHK(c, hipMemcpy(h_nn_sqdist, d_sq, (size_t)n_query * 4, hipMemcpyDeviceToHost));
         if (h_within) HIPCHK(c, hipMemcpy(h_within, d_w, (size_t)n_query, hipMemcpyDeviceToHost));
     }
-    hipFree(d_map);
-    hipFree(d_q);
-    hipFree(d_sq);
-    hipFree(d_idx);
-    hipFree(d_w);
-    hipFree(d_work);
     return SCVOD_OK;
+}
+
+int scvod_nn_search_device(scvod_ctx* c, const float* d_map_xyz, int32_t n_map, const float* d_query_xyz, int32_t n_query,
+                           float radius, int32_t* d_nn_idx, float* d_nn_sqdist, uint8_t* d_within, void* stream) {
+    if (!c || n_map < 0 || n_query < 0 || (n_map > 0 && !d_map_xyz) || (n_query > 0 && (!d_query_xyz || !d_nn_idx || !d_nn_sqdist || !d_within)))
+        return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const float origin[3] = {0.f, 0.f, 0.f};
+    return nn_run(c, d_map_xyz, n_map, d_query_xyz, n_query, radius, d_nn_idx, d_nn_sqdist, d_within, origin,
+                  stream ? (hipStream_t)stream : c->stream);
 }
 
 }  // extern "C"

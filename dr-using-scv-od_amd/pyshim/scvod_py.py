@@ -119,6 +119,7 @@ def load_lib():
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
         "scvod_set_timing": (C.c_int, [vp, i32]),
         "scvod_nn_search": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp]),
+        "scvod_nn_search_device": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp, vp]),
         "scvod_batch_voxelgrid": (C.c_int, [vp, vp, vp, vp, i32, vp, f32, vp, i64, vp, vp]),
         "scvod_voxelgrid": (C.c_int, [vp, vp, vp, i32, vp, f32, vp, i32, vp]),
     }
@@ -136,7 +137,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
                     "scvod_batch_track", "scvod_batch_track_counts",
-                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
+                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
 
 
 def make_params(preset=None, **kw):
@@ -350,6 +351,19 @@ class Ctx:
 
     def arena_bytes(self):
         return int(self.lib.scvod_arena_bytes(self.h))
+
+    def nn_search_device(self, d_map_xyz, d_query_xyz, radius, stream=None):
+        """torch CUDA tensors [n, 3] float32 in, (idx int32, sqdist float32, within uint8) CUDA tensors out."""
+        import torch
+        nq = int(d_query_xyz.shape[0])
+        idx = torch.empty(max(nq, 1), dtype=torch.int32, device=d_query_xyz.device)
+        sq = torch.empty(max(nq, 1), dtype=torch.float32, device=d_query_xyz.device)
+        w = torch.empty(max(nq, 1), dtype=torch.uint8, device=d_query_xyz.device)
+        self._chk(self.lib.scvod_nn_search_device(self.h, C.c_void_p(d_map_xyz.data_ptr()), int(d_map_xyz.shape[0]),
+                                                  C.c_void_p(d_query_xyz.data_ptr()), nq, float(radius), C.c_void_p(idx.data_ptr()),
+                                                  C.c_void_p(sq.data_ptr()), C.c_void_p(w.data_ptr()),
+                                                  C.c_void_p(stream) if stream else None))
+        return idx[:nq], sq[:nq], w[:nq]
 
     def voxelgrid(self, xyzi, leaf=(0.08, 0.08, 0.08), labels=None, max_intensity=1.0):
         """SSC::getCloud label filter + pcl::VoxelGrid of one host scan (ssc.cpp:1063-1076, 1103-1106)."""

@@ -298,6 +298,12 @@ int scvod_nn_search(scvod_ctx* ctx, const float* h_map_xyz, int32_t n_map,
                     const float* h_query_xyz, int32_t n_query, float radius,
                     int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within);
 
+/* The same search on arrays already resident in HBM (packed xyz, 12 B per point); asynchronous on `stream`
+ * (NULL = the ctx's stream).  For sequence-scale evaluation without host round trips. */
+int scvod_nn_search_device(scvod_ctx* ctx, const float* d_map_xyz, int32_t n_map,
+                           const float* d_query_xyz, int32_t n_query, float radius,
+                           int32_t* d_nn_idx, float* d_nn_sqdist, uint8_t* d_within, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

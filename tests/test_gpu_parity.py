@@ -441,6 +441,25 @@ def P_car(P):
     return 2   # ssc/car_ in both YAML files
 
 
+def test_nn_search_device_resident(scvod, oracle):
+    """the device-pointer form of the correspondence search gives the same neighbours as the host form and the
+    brute-force oracle (its grid origin differs -- only the hashing may depend on it, never the result)"""
+    import torch
+    rng = np.random.default_rng(13)
+    m = (rng.uniform(-40, 40, (30000, 3)) * np.array([1, 1, 0.05])).astype(np.float32) + np.float32(1000.0)   # far from the origin
+    q = m[rng.integers(0, len(m), 4000)] + rng.normal(0, 0.08, (4000, 3)).astype(np.float32)
+    q[:50] += 30.0                                                        # no neighbour within a cell: exact fall-back list
+    ctx = scvod.Ctx(_params(scvod, "semantickitti"), max_points_total=1000, max_scans=1)
+    hi, hs, hw = ctx.nn_search(m, q, 0.15)
+    di, ds, dw = ctx.nn_search_device(torch.from_numpy(m).cuda(), torch.from_numpy(q).cuda(), 0.15)
+    torch.cuda.synchronize()
+    oi, osq, ow = oracle.nn_search(m, q, 0.15)
+    assert np.array_equal(di.cpu().numpy(), oi) and np.array_equal(hi, oi)
+    assert np.array_equal(ds.cpu().numpy().view(np.uint32), osq.view(np.uint32)) and np.array_equal(dw.cpu().numpy(), ow)
+    assert 0 < ow.sum() < len(q)
+    ctx.close()
+
+
 def test_nn_search_large_grid_path(scvod, oracle):
     """Grid-hash correspondence search at map scale, against scipy's kd-tree (the reference uses PCL's kd-tree)."""
     from scipy.spatial import cKDTree
