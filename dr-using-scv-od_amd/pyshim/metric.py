@@ -32,3 +32,33 @@ def preservation_rejection(gt_xyz, gt_label, est_xyz, est_label, nn_fn, voxelsiz
                 num_est_dynamic=int(est_dyn.sum()), num_preserved=int(np.count_nonzero(inl)),
                 num_static_preserved=num_static_preserved, num_dynamic_preserved=num_dynamic_preserved, PR=pr, RR=rr,
                 F1=f1)
+
+
+# ---- evaluate() of src/evaluate.cpp:79-145: the colour classes of the reference's map viewer --------------------
+TP_STATIC, FN_STATIC, TN_DYNAMIC, FN_DYNAMIC, UNMATCHED = 1, 2, 3, 4, 0
+
+
+def classify_map_points(original_xyz, predicted_static, static_xyz, dynamic_xyz, nn_fn):
+    """Per point of the original map: predicted static (g != 0 in the reference's RGB encoding) -> TP_STATIC when a
+    ground-truth static point lies within 0.15 m, else FN_STATIC (orange) when a ground-truth dynamic point lies within
+    0.10 m; predicted dynamic -> TN_DYNAMIC when a dynamic point lies within 0.15 m, else FN_DYNAMIC (pink) when a
+    static point lies within 0.10 m; UNMATCHED otherwise (not drawn).  pcl::KdTreeFLANN::radiusSearch is non-empty iff
+    the nearest neighbour's squared distance is below radius^2 (FLANN's RadiusResultSet keeps dist < r^2; parity
+    unpinned), so four 1-NN searches of the A7 kernel answer it."""
+    o = np.asarray(original_xyz, np.float32).reshape(-1, 3)
+    ps = np.asarray(predicted_static, bool)
+    out = np.zeros(len(o), np.int32)
+
+    def near(cloud, radius):
+        c = np.asarray(cloud, np.float32).reshape(-1, 3)
+        if len(c) == 0:
+            return np.zeros(len(o), bool)
+        _, sq, _ = nn_fn(c, o, radius)
+        return sq < np.float32(radius) * np.float32(radius)
+
+    s15, s10, d15, d10 = near(static_xyz, 0.15), near(static_xyz, 0.1), near(dynamic_xyz, 0.15), near(dynamic_xyz, 0.1)
+    out[ps & s15] = TP_STATIC
+    out[ps & ~s15 & d10] = FN_STATIC
+    out[~ps & d15] = TN_DYNAMIC
+    out[~ps & ~d15 & s10] = FN_DYNAMIC
+    return out

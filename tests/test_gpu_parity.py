@@ -460,6 +460,22 @@ def test_nn_search_device_resident(scvod, oracle):
     ctx.close()
 
 
+def test_map_point_classes_on_gpu(scvod, oracle):
+    """evaluate.cpp:79-145 (viewer classes) with the GPU correspondence kernel == the same with the brute-force oracle"""
+    import metric
+    rng = np.random.default_rng(17)
+    static = rng.uniform(-20, 20, (20000, 3)).astype(np.float32) * np.array([1, 1, 0.05], np.float32)
+    dynamic = rng.uniform(-20, 20, (3000, 3)).astype(np.float32) * np.array([1, 1, 0.05], np.float32)
+    orig = np.concatenate([static[::3] + rng.normal(0, 0.06, (len(static[::3]), 3)).astype(np.float32),
+                           dynamic + rng.normal(0, 0.06, dynamic.shape).astype(np.float32)])
+    pred = rng.random(len(orig)) < 0.7
+    ctx = scvod.Ctx(_params(scvod, "semantickitti"), max_points_total=1000, max_scans=1)
+    got = metric.classify_map_points(orig, pred, static, dynamic, ctx.nn_search)
+    ref = metric.classify_map_points(orig, pred, static, dynamic, oracle.nn_search)
+    assert np.array_equal(got, ref) and len(np.unique(ref)) == 5
+    ctx.close()
+
+
 def test_nn_search_large_grid_path(scvod, oracle):
     """Grid-hash correspondence search at map scale, against scipy's kd-tree (the reference uses PCL's kd-tree)."""
     from scipy.spatial import cKDTree

@@ -2,6 +2,7 @@
 (SURVEY.md 8c "golden vectors to commit").  Not gpu."""
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -167,3 +168,25 @@ def test_metric_matches_reference_golden(oracle):
                   "num_static_preserved", "num_dynamic_preserved"):
             assert m[k] == g[k], (g["case"], k)
         assert abs(m["PR"] - g["PR"]) < 1e-9 and abs(m["RR"] - g["RR"]) < 1e-9 and abs(m["F1"] - g["F1"]) < 1e-9
+
+
+def test_map_point_classes_of_the_evaluation_viewer(oracle):
+    """evaluate.cpp:79-145 by hand: one point per branch, radii 0.15 / 0.10 with strict comparisons"""
+    sys_path_hack = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dr-using-scv-od_amd", "pyshim")
+    if sys_path_hack not in sys.path:
+        sys.path.insert(0, sys_path_hack)
+    import metric
+    static = np.array([[0, 0, 0], [10, 0, 0]], np.float32)
+    dynamic = np.array([[5, 0, 0], [20, 0, 0]], np.float32)
+    orig = np.array([[0.10, 0, 0],     # predicted static, static within 0.15          -> TP
+                     [5.05, 0, 0],     # predicted static, no static, dynamic within 0.10 -> FN (orange)
+                     [5.12, 0, 0],     # predicted static, dynamic only within 0.15 (not 0.10) -> unmatched
+                     [5.12, 0, 0],     # predicted dynamic, dynamic within 0.15        -> TN
+                     [10.08, 0, 0],    # predicted dynamic, no dynamic, static within 0.10 -> FN (pink)
+                     [10.12, 0, 0],    # predicted dynamic, static only within 0.15   -> unmatched
+                     [50, 0, 0]], np.float32)
+    pred_static = np.array([1, 1, 1, 0, 0, 0, 1], bool)
+    got = metric.classify_map_points(orig, pred_static, static, dynamic, oracle.nn_search)
+    assert got.tolist() == [metric.TP_STATIC, metric.FN_STATIC, metric.UNMATCHED, metric.TN_DYNAMIC, metric.FN_DYNAMIC,
+                            metric.UNMATCHED, metric.UNMATCHED]
+    assert (metric.classify_map_points(orig, pred_static, static, np.zeros((0, 3), np.float32), oracle.nn_search)[[1, 3]] == 0).all()
