@@ -1041,16 +1041,25 @@ __global__ __launch_bounds__(64) void k_pw_fit_coop(DevParams P, Arena A, int co
 
 // one wave per (scan, patch): final plane test of every point (patchwork.h:488-501), keeps the
 // z order inside the ground part and the non-ground part, counts what k_emit_offsets needs.
+// GL lanes per patch: 64 for patches of 64 points or more, 16 (four patches per wave) for the many smaller ones, whose
+// cost is the per-patch latency chain, not the points.
+template <int GL, int C_LO, int C_HI>
 __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
+    constexpr int NG = 64 / GL;
+    constexpr unsigned long long FULL = (GL == 64) ? ~0ull : ((1ull << (GL & 63)) - 1ull);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int total = A.order_off[64];
-    const int stride = gridDim.x * 4;
-    int wi = blockIdx.x * 4 + wave;
-    if (wi >= total) return;
+    const int g_ = lane / GL, r = lane % GL, gbase = g_ * GL;
+    auto group_bits = [&](unsigned long long ballot) -> unsigned long long { return (ballot >> gbase) & FULL; };
+    int lo, total;
+    order_range(A.order_off, C_LO, C_HI, lo, total);
+    if (lo >= total) return;
+    const int stride = gridDim.x * 4 * NG;
+    int wi = lo + (blockIdx.x * 4 + wave) * NG + g_;
+    if (lo + (int)(blockIdx.x * 4 + wave) * NG >= total) return;
     // Half of the live patches hold fewer than 64 points: a wave would spend its time in the dependent chain
     // order[] -> plane -> points.  So the chain is software-pipelined ACROSS patches: the list item two patches ahead
-    // and the plane + first 64 points of the next patch are in flight while the current patch is arranged (all loads
+    // and the plane + first points of the next patch are in flight while the current patch is arranged (all loads
     // unconditional with clamped indices, so none has to land before a branch joins).
     struct Head {
         float n0, n1, n2, thd;
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
     auto load_item = [&](int k) -> int4 { return A.order[min(k, total - 1)]; };
     auto load_head = [&](const int4& it) -> Head {
         const int slot = it.x;  // scan * kMaxPatches + patch
-        const size_t first = (size_t)it.z + it.w + min(lane, it.y - 1);
+        const size_t first = (size_t)it.z + it.w + min(r, it.y - 1);
         Head h;
         h.n0 = A.planes[slot].normal[0];
         h.n1 = A.planes[slot].normal[1];
@@ -1074,32 +1083,40 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
     };
     int4 item = load_item(wi), item1 = load_item(wi + stride);
     Head head = load_head(item);
-    for (; wi < total; wi += stride) {
+    for (; __any(wi < total); wi += stride) {
         const int4 item2 = load_item(wi + 2 * stride);
         const Head head1 = load_head(item1);
+        const bool live = wi < total;  // uniform inside a group
         const int code = item.x;
         const int s = code / kMaxPatches, p = code - s * kMaxPatches;
-        const int n = item.y, base = item.z, off = item.w;
+        const int n = live ? item.y : 0, base = item.z, off = item.w;
+        const int n_last = max(n - 1, 0);
         const Xyz* __restrict__ sp = A.sorted_xyz + (size_t)base + off;
         const uint32_t* __restrict__ si = A.sorted_idx + (size_t)base + off;
         const float n0 = head.n0, n1 = head.n1, n2 = head.n2;
         const float thd = head.thd;
         const int status = head.status;
         const bool rejected = (status >= 2);
+        int n_max = n;
+        if (NG > 1) {
+#pragma unroll
+            for (int d = 32; d >= GL; d >>= 1) n_max = max(n_max, __shfl_xor(n_max, d));
+        }
         // ONE pass: ground part grows from the front in z order, the non-ground part from the back
         // (element r of the non-ground part lives at seg[n - 1 - r]; k_emit reads it that way)
         int n_g = 0, n_ng = 0, a_g = 0, a_ng = 0;
         uint32_t* seg = A.seg + (size_t)base + off;
-        // the next 64 points are in flight while this step is classified (clamped, unconditional loads)
+        // the next GL points are in flight while this step is classified (clamped, unconditional loads)
         Xyz q_next = head.q;
         uint32_t w_next = head.w;
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
+        const unsigned long long below = (1ull << r) - 1ull;
+        for (int j0 = 0; j0 < n_max; j0 += GL) {
+            const int j = j0 + r;
             int g = 0, keep = 0;
             const Xyz q = q_next;
             uint32_t w = w_next;
-            q_next = sp[min(j + 64, n - 1)];
-            w_next = si[min(j + 64, n - 1)];
+            q_next = sp[min(j + GL, n_last)];
+            w_next = si[min(j + GL, n_last)];
             if (j < n) {
                 g = plane_res(q, n0, n1, n2) < thd;
                 // range/FOV verdict of makeApriVec, only for points that reach the non-ground stream
@@ -1108,28 +1125,27 @@ __global__ __launch_bounds__(256) void k_pw_arrange(DevParams P, Arena A) {
                     w |= keep ? 0x80000000u : 0u;
                 }
             }
-            const unsigned long long bg = __ballot(g);
-            const unsigned long long bn = __ballot(!g && j < n);
-            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long bg = group_bits(__ballot(g));
+            const unsigned long long bn = group_bits(__ballot(!g && j < n));
             if (j < n) {
                 if (g)
                     seg[n_g + __popcll(bg & below)] = w;
                 else
                     seg[n - 1 - (n_ng + __popcll(bn & below))] = w;
             }
-            a_g += __popcll(__ballot(g && keep));
-            a_ng += __popcll(__ballot(!g && keep && j < n));
+            a_g += __popcll(group_bits(__ballot(g && keep)));
+            a_ng += __popcll(group_bits(__ballot(!g && keep && j < n)));
             n_g += __popcll(bg);
             n_ng += __popcll(bn);
         }
-        if (lane == 0) {
-            PatchRec r;
-            r.n = n;
-            r.n_g = n_g;
-            r.status = status;
-            r.a_g = a_g;
-            r.a_ng = a_ng;
-            A.patch_rec[s * kMaxPatches + p] = r;
+        if (live && r == 0) {
+            PatchRec rec;
+            rec.n = n;
+            rec.n_g = n_g;
+            rec.status = status;
+            rec.a_g = a_g;
+            rec.a_ng = a_ng;
+            A.patch_rec[s * kMaxPatches + p] = rec;
             A.planes[s * kMaxPatches + p].n_ground = n_g;
         }
         item = item1;
@@ -2448,7 +2464,8 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A, coop_class);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");
-        hipLaunchKernelGGL(k_pw_arrange, dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
+        hipLaunchKernelGGL((k_pw_arrange<64, kClassWave, 63>), dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
+        hipLaunchKernelGGL((k_pw_arrange<16, 0, kClassWave - 1>), dim3(kPersistCUs * 4), dim3(256), 0, st, P, A);
         TH_END("pw_arrange");
         TH_BEGIN("emit_offsets");
         hipLaunchKernelGGL(k_emit_offsets, dim3(B), dim3(1024), 0, st, P, A);
