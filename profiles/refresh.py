@@ -43,6 +43,8 @@ def label(k):
         return m[k]
     if k.startswith("k_pw_fit_coop"):
         return "pw_fit_large"
+    if k.startswith("k_pw_arrange"):
+        return "pw_arrange"
     if k.startswith("k_cc_link_starts"):
         return "k_cc_link_starts"
     if k.startswith("k_track_unique"):
