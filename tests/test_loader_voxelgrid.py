@@ -146,3 +146,24 @@ def test_voxelgrid_error_conventions(scvod):
     r = scvod.ScanResult()
     assert ctx.lib.scvod_batch_fetch(ctx.h, 0, C.byref(r)) == -5    # SCVOD_ERR_STATE
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_voxelgrid_degenerate_clouds(scvod, oracle):
+    """everything in ONE cell (a single key bucket far beyond the LDS tiers: global-memory sort, one 30 000-term fp32
+    sum), a cloud on a single line, and two far-apart clusters (almost every histogram bin empty)"""
+    rng = np.random.default_rng(9)
+    ctx = scvod.Ctx(scvod.make_params("semantickitti"), max_points_total=70000, max_scans=1)
+    one = np.tile(np.array([[1.01, 2.02, -0.53, 7.0]], np.float32), (30000, 1))
+    one[:, :3] += rng.uniform(0, 0.01, (30000, 3)).astype(np.float32)
+    one = np.concatenate([one, np.array([[5, 5, 0, 1], [-5, 5, 0, 2]], np.float32)])
+    line = np.zeros((5000, 4), np.float32)
+    line[:, 0] = np.linspace(-30, 30, 5000)
+    line[:, 3] = np.arange(5000)
+    far = np.concatenate([rng.normal([-70, -70, -2, 50], 0.3, (20000, 4)), rng.normal([70, 70, 2, 50], 0.3, (20000, 4))]).astype(np.float32)
+    for name, x in (("one cell", one), ("line", line), ("two clusters", far)):
+        got = ctx.voxelgrid(x, (0.08, 0.08, 0.08))
+        ref, rc = oracle.voxelgrid(x, (0.08, 0.08, 0.08))
+        assert rc == 0 and got.shape == ref.shape, name
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), name
+    ctx.close()
