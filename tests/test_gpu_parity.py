@@ -196,6 +196,23 @@ def test_voxel_bucket_sizes_at_every_tier_boundary(scvod, oracle):
     ctx.close()
 
 
+def test_degenerate_patches(scvod, oracle):
+    """rank-deficient covariances and exact ties everywhere: identical points (zero matrix), a perfectly flat plane (exact z
+    ties, rank 2), a vertical pole (rank 1), two alternating points, a patch of exactly num_min_pts + 1 points"""
+    rng = np.random.default_rng(4)
+    P = _params(scvod, "semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=30000, max_scans=1)
+    same = np.tile(np.array([[4.0, 1.0, -1.7, 3.0]], np.float32), (5000, 1))
+    ang, rad = rng.uniform(0.02, 0.37, 6000), rng.uniform(3.2, 6.8, 6000)
+    flat = np.stack([rad * np.cos(ang), rad * np.sin(ang), np.full(6000, -1.73), rng.integers(0, 255, 6000)], 1).astype(np.float32)
+    pole = np.stack([np.full(3000, 5.0), np.full(3000, 1.2), rng.uniform(-1.7, 2.0, 3000), np.zeros(3000)], 1).astype(np.float32)
+    two = np.tile(np.array([[4.0, 1.0, -1.7, 3.0], [4.5, 1.1, -1.6, 9.0]], np.float32), (2000, 1))
+    eleven = np.stack([rad[:11] * np.cos(ang[:11]), rad[:11] * np.sin(ang[:11]), rng.normal(-1.7, 0.02, 11), np.zeros(11)], 1).astype(np.float32)
+    for name, x in (("identical", same), ("flat", flat), ("pole", pole), ("two points", two), ("eleven", eleven)):
+        _check_scan(oracle, P, x, ctx.process_scan(x), name)
+    ctx.close()
+
+
 def test_bin_scan_unfiltered_and_filtered(scvod, oracle):
     rng = np.random.default_rng(3)
     P = _params(scvod, "parkinglot")
