@@ -213,6 +213,42 @@ def test_degenerate_patches(scvod, oracle):
     ctx.close()
 
 
+def test_random_small_scans_fuzz(scvod, oracle):
+    """sixty seeded random scans (1 .. 6000 points; noisy tilted ground, boxes, uniform clutter, far outliers, duplicated
+    and axis-aligned points, quantised z) through ONE batch and, every fifth, through the per-scan API"""
+    import torch
+    rng = np.random.default_rng(2024)
+    P = _params(scvod, "parkinglot")
+    scans = []
+    for i in range(60):
+        n = int(rng.integers(1, 6000))
+        k = rng.random(n)
+        r = rng.uniform(0.5, 60, n) ** rng.uniform(0.6, 1.0)
+        th = rng.uniform(0, 2 * np.pi, n)
+        x, y = r * np.cos(th), r * np.sin(th)
+        tilt = rng.normal(0, 0.03, 2)
+        z = -1.83 + tilt[0] * x + tilt[1] * y + rng.normal(0, 0.03, n)
+        box = k > 0.7
+        z[box] = rng.uniform(-1.8, 1.5, box.sum())
+        far = k > 0.97
+        x[far] *= 5
+        pts = np.stack([x, y, z, rng.integers(0, 255, n)], 1).astype(np.float32)
+        if n > 50:
+            pts[:10, 1] = 0.0                       # on the x axis
+            pts[10:20, 0] = 0.0                     # on the y axis
+            pts[20:30] = pts[20]                    # duplicates
+            pts[30:50, 2] = np.round(pts[30:50, 2], 1)   # z ties
+        scans.append(pts)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=len(scans))
+    ctx.batch_process(torch.from_numpy(np.concatenate(scans)).cuda(), offs)
+    for s, x in enumerate(scans):
+        _check_scan(oracle, P, x, ctx.batch_fetch(s), f"fuzz {s} (n={len(x)})")
+    for s in range(0, len(scans), 5):
+        _check_scan(oracle, P, scans[s], ctx.process_scan(scans[s]), f"fuzz single {s}")
+    ctx.close()
+
+
 def test_bin_scan_unfiltered_and_filtered(scvod, oracle):
     rng = np.random.default_rng(3)
     P = _params(scvod, "parkinglot")
