@@ -177,6 +177,42 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n) {
 }
 #undef IX
 
+// Histogram / rank atomics on an LDS bin table when neighbouring lanes mostly hit the SAME bin (consecutive points of a
+// scan fall into the same patch / key bucket): same-address LDS atomics serialise lane by lane, so the wave first groups
+// its lanes by bin and one lane per distinct bin adds the group's count.  wave_bin_rank returns the old bin value + the
+// lane's rank inside its group (what atomicAdd(&hist[bin], 1) would have returned for SOME serialisation); bin < 0 = idle.
+__device__ __forceinline__ int wave_bin_rank(int* hist, int bin) {
+    const int lane = threadIdx.x & 63;
+    int rank = 0;
+    bool todo = bin >= 0;
+    while (__any(todo)) {
+        const int first = __ffsll((long long)__ballot(todo)) - 1;
+        const int b0 = __shfl(bin, first);
+        const bool mine = todo && (bin == b0);
+        const unsigned long long mask = __ballot(mine);
+        int old = 0;
+        if (lane == first) old = atomicAdd(&hist[b0], __popcll(mask));
+        old = __shfl(old, first);
+        if (mine) {
+            rank = old + __popcll(mask & ((1ull << lane) - 1ull));
+            todo = false;
+        }
+    }
+    return rank;
+}
+__device__ __forceinline__ void wave_bin_add(int* hist, int bin) {
+    const int lane = threadIdx.x & 63;
+    bool todo = bin >= 0;
+    while (__any(todo)) {
+        const int first = __ffsll((long long)__ballot(todo)) - 1;
+        const int b0 = __shfl(bin, first);
+        const bool mine = todo && (bin == b0);
+        const unsigned long long mask = __ballot(mine);
+        if (lane == first) atomicAdd(&hist[b0], __popcll(mask));
+        if (mine) todo = false;
+    }
+}
+
 // ---- power-of-two bitonic sort for the LDS tiers -------------------------------------------------
 // Classic bitonic network on np2 = 2^q slots (slots >= n hold +inf, the LDS tiers always have room
 // for them), every level a butterfly whose direction is given by bit k of the element index, so ALL
@@ -325,7 +361,7 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_classify(DevParams P, Arena 
             int pid = czm_patch_of(P.czm, p.x, p.y, p.z);
             A.pid[base + i] = (int16_t)pid;
             A.zkey[base + i] = float_sort_key(p.z);
-            if (pid >= 0) atomicAdd(&hist[pid], 1);
+            if (pid >= 0) atomicAdd(&hist[pid], 1);  // (grouping the wave's lanes by bin first costs more than it saves here)
         }
     }
     __syncthreads();
@@ -366,7 +402,7 @@ __global__ __launch_bounds__(kClsThreads) void k_pw_scatter(DevParams P, Arena A
     }
 #pragma unroll
     for (int it = 0; it < kClsItems; ++it)
-        if (pid[it] >= 0) rank[it] = atomicAdd(&hist[pid[it]], 1);
+        rank[it] = wave_bin_rank(hist, pid[it]);
     __syncthreads();
     for (int b = threadIdx.x; b < P.n_patches; b += kClsThreads) {
         int c = hist[b];
@@ -1597,7 +1633,7 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_count(DevParams P, Arena A) {
 #pragma unroll
     for (int it = 0; it < kVxItems; ++it) {
         int i = start + it * kVxThreads + threadIdx.x;
-        if (i < n) atomicAdd(&hist[vx_bucket_of(P, A, s, A.apri_key[(size_t)base + i])], 1);
+        wave_bin_add(hist, (i < n) ? vx_bucket_of(P, A, s, A.apri_key[(size_t)base + i]) : -1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < P.n_buckets; b += kVxThreads) {
