@@ -45,6 +45,16 @@ STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter":
             "vx_final": "voxels", "track_probe": "tracking", "track_unique": "tracking"}
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def stage_bytes(n_pts, n_vox, n_car, n_scans):
     return {"patchwork": 16.0 * n_pts, "binning": 5.0 * n_pts, "voxels": 20.0 * n_vox,
             "tracking": 20.0 * n_car + 64.0 * n_scans}
@@ -300,6 +310,7 @@ def main():
             cpu = {"value": ns / cpu_dt, "unit": "scans/s", "cores": 1, "kind": "port",
                    "sample": f"first {ns} scans of the same synthetic seq-05 sequence (Patchwork+binning+voxel descriptors, "
                              f"oracle/liboracle.so, g++ -O3 no -march, 1 thread; {os.cpu_count()} host cores present)",
+                   "host_cpu": _cpu_model(),
                    "stage_ms_per_scan": {"patchwork": 1e3 * stages[0] / ns, "bin": 1e3 * stages[1] / ns,
                                          "voxelize": 1e3 * stages[2] / ns}}
         # context only: the same oracle with one scan per host thread (ctypes releases the GIL), bounded to ~10 s
