@@ -50,6 +50,14 @@ struct scvod_ctx {
     uint32_t* d_labels = nullptr;   // staging of the host API's label array (scvod_voxelgrid)
     int32_t* t_count = nullptr;
     float* t_T = nullptr;
+    int32_t* d_next_scan = nullptr;   // [cap_scans] successor table of scvod_batch_track
+    const int4** d_ext = nullptr;     // [cap_scans] external (boundary) tables
+    std::vector<float> up_T;          // what the device copies of T / next_scan / ext currently hold (re-uploaded on change only)
+    std::vector<int32_t> up_next;
+    std::vector<const void*> up_ext;
+    bool track_valid = false;
+    std::vector<int32_t> tk_stage;    // host staging of scvod_batch_fetch_track
+    std::vector<uint8_t> tk_stage_dyn;
     // last batch
     bool batch_valid = false;
     std::vector<int32_t> h_scan_off;
@@ -58,10 +66,10 @@ struct scvod_ctx {
     bool have_patchwork = false;
     int batch_mode = 0;          // do_patchwork of the last batch: 1 Patchwork+binning, 0 binning only, 2 caller's apri_vec
     bool apri_compact = false;   // PointAPRI records not materialised yet (k_apri_expand on request)
+    bool voxels_valid = false;   // the last batch ran the voxel stage in descriptor mode (not VoxelGrid)
     bool clusters_valid = false;
     bool types_valid = false;
     hipStream_t last_stream = nullptr;
-    int32_t last_track_clusters = 0;
     // host staging for scvod_scan_result
     void* nn_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // scvod_nn_search scratch (grow-only)
     size_t nn_cap[6] = {0, 0, 0, 0, 0, 0};
@@ -184,6 +192,23 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     c->t_pairpt = k.take<int32_t>(B + 1);
     c->t_count = k.take<int32_t>(N);
     c->t_T = k.take<float>(12 * (B + 1));
+    // sequence differencing on the device: the per-pair scratch above is never in use at the same time
+    A.tk_hit = c->t_hit;
+    A.tk_uniq = c->t_uniq;
+    A.tk_nuniq = c->t_count;
+    A.tk_cursor = c->t_pair;
+    A.tk_mbegin = c->t_begin;
+    A.vox_track = k.take<int4>(N);
+    A.cl_nvox = k.take<int32_t>(N);
+    A.cl_state = k.take<int8_t>(N);
+    A.tk_members = k.take<int32_t>(N);
+    A.tk_pairs = k.take<int2>(N);
+    A.tk_npairs = k.take<int32_t>(N);
+    A.tk_clusters = k.take<int32_t>(N);
+    A.tk_scan = k.take<int32_t>(B * 4);
+    A.pt_dyn = k.take<uint8_t>(N);
+    c->d_next_scan = k.take<int32_t>(B);
+    c->d_ext = k.take<const int4*>(B);
     *total = align_up(k.off, 256);
 }
 
@@ -314,14 +339,17 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->tim_used = 0;
     c->batch_valid = false;
     c->counts_valid = false;
+    c->voxels_valid = false;
     c->clusters_valid = false;
     c->types_valid = false;
+    c->track_valid = false;
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     if (mx == 0) {
         HIPCHK(c, hipMemsetAsync(c->A.counts, 0, sizeof(int32_t) * 8 * n_scans, st));
     }
     c->batch_valid = true;
+    c->voxels_valid = (do_voxels != 0);
     c->have_patchwork = (do_patchwork == 1);
     c->batch_mode = do_patchwork;
     c->apri_compact = (do_patchwork == 1);
@@ -477,7 +505,7 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     c->A.max_scan_pts = mx;
     c->A.total_pts = total;
     c->tim_used = 0;
-    c->batch_valid = c->counts_valid = c->clusters_valid = c->types_valid = false;  // the arena is reused
+    c->batch_valid = c->counts_valid = c->voxels_valid = c->clusters_valid = c->types_valid = c->track_valid = false;  // the arena is reused
     h_out_off[0] = 0;
     if (mx == 0) {
         for (int s = 0; s < n_scans; ++s) h_out_off[s + 1] = 0;
@@ -511,7 +539,31 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     return SCVOD_OK;
 }
 
+// Re-upload a small host table only when its contents changed since the last call: the staging vector belongs to the ctx
+// and an earlier asynchronous copy may still be reading it, so a change first drains the stream (steady-state sequence
+// loops pass the same tables every step and never synchronise here).
+template <typename T>
+int upload_if_changed(scvod_ctx* c, std::vector<T>& held, const T* src, size_t n, void* dst, hipStream_t st) {
+    if (held.size() == n && (n == 0 || memcmp(held.data(), src, n * sizeof(T)) == 0)) return SCVOD_OK;
+    HIPCHK(c, hipStreamSynchronize(st));
+    held.assign(src, src + n);
+    if (n) HIPCHK(c, hipMemcpyAsync(dst, held.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
+    return SCVOD_OK;
+}
+
 }  // namespace
+
+// internal bridge for scvod_map.hip (not part of the public header)
+extern "C" int scvod__ctx_view(scvod_ctx* c, Arena* arena, int* device, int* track_valid, int* batch_valid, int* n_scans,
+                               int* max_scan_pts) {
+    *arena = c->A;
+    *device = c->device;
+    *track_valid = c->track_valid ? 1 : 0;
+    *batch_valid = (c->batch_valid && c->batch_mode != 3) ? 1 : 0;
+    *n_scans = c->A.n_scans;
+    *max_scan_pts = c->A.max_scan_pts;
+    return 0;
+}
 
 extern "C" {
 
@@ -709,7 +761,11 @@ int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offset
                       const int32_t* h_next_keys, const int32_t* h_next_labels, int32_t n_next_vox, int32_t* h_hit_slot,
                       int32_t* h_uniq_slots, int32_t* h_uniq_begin) {
     if (!c || n_clusters < 0 || !h_offsets || !T || n_next_vox < 0) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (h_offsets[0] != 0) return fail(c, SCVOD_ERR_INVALID, "cluster offsets must start at 0");
+    for (int k = 0; k < n_clusters; ++k)
+        if (h_offsets[k + 1] < h_offsets[k]) return fail(c, SCVOD_ERR_INVALID, "cluster offsets not monotone");
     const int32_t n_pts = h_offsets[n_clusters];
+    if ((n_pts > 0 && !h_xyzi) || (n_next_vox > 0 && !h_next_keys)) return fail(c, SCVOD_ERR_INVALID, "null input array");
     if (n_pts > c->cap_pts || n_clusters > c->cap_pts || n_next_vox > c->cap_pts)
         return fail(c, SCVOD_ERR_CAPACITY, "track probe larger than the ctx capacity");
     HIPCHK(c, hipSetDevice(c->device));
@@ -778,7 +834,8 @@ int scvod_batch_fetch(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
 
 int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     if (!c) return SCVOD_ERR_INVALID;
-    if (!c->batch_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_cluster needs a processed batch");
+    if (!c->batch_valid || !c->voxels_valid)
+        return fail(c, SCVOD_ERR_STATE, "scvod_batch_cluster needs a processed batch with voxel descriptors");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
@@ -791,6 +848,7 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     HIPCHK(c, hipGetLastError());
     c->clusters_valid = true;
     c->types_valid = false;  // the link step uses the type array as scratch
+    c->track_valid = false;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
@@ -848,59 +906,122 @@ int scvod_cluster(scvod_ctx* c, const scvod_apri* h_apri, int32_t n, int32_t* h_
     return rc < 0 ? rc : SCVOD_OK;
 }
 
-int scvod_batch_track(scvod_ctx* c, const int32_t* d_members, const int32_t* h_cluster_begin, int32_t n_clusters,
-                      const int32_t* h_pair_cluster_begin, const float* h_T, void* stream, int32_t sync) {
-    if (!c || !d_members || !h_cluster_begin || !h_pair_cluster_begin || !h_T || n_clusters < 0)
-        return fail(c, SCVOD_ERR_INVALID, "bad arguments");
-    if (!c->batch_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track needs a processed batch");
-    const int n_pairs = c->A.n_scans - 1;
-    if (n_pairs < 1) return fail(c, SCVOD_ERR_INVALID, "need at least two scans");
-    const int32_t n_pts = h_cluster_begin[n_clusters];
-    if (n_pts > c->cap_pts || n_clusters > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "too many cluster points");
+int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan, const void* const* h_ext_tables, int32_t n_ext,
+                      void* stream, int32_t sync) {
+    if (!c || !h_T || n_ext < 0 || (n_ext > 0 && !h_ext_tables)) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (!c->batch_valid || !c->voxels_valid || !c->clusters_valid || !c->types_valid)
+        return fail(c, SCVOD_ERR_STATE, "scvod_batch_track needs scvod_batch_process, scvod_batch_cluster and scvod_batch_cluster_types first");
+    if (c->batch_mode == 3) return fail(c, SCVOD_ERR_STATE, "the last batch was a VoxelGrid run");
+    const int B = c->A.n_scans;
+    if (n_ext > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "too many external tables");
+    std::vector<int32_t> next(B);
+    for (int s = 0; s < B; ++s) {
+        const int32_t v = h_next_scan ? h_next_scan[s] : (s + 1 < B ? s + 1 : -1);
+        if (v >= B || (v <= -2 && -2 - v >= n_ext)) return fail(c, SCVOD_ERR_INVALID, "next_scan[%d] = %d out of range", s, v);
+        next[s] = v;
+    }
+    for (int e = 0; e < n_ext; ++e)
+        if (!h_ext_tables[e]) return fail(c, SCVOD_ERR_INVALID, "external table %d is NULL", e);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
     c->tim_used = 0;
-    std::vector<int32_t> pair(n_clusters > 0 ? n_clusters : 1), pair_pt(n_pairs + 1);
-    int32_t max_pair_pts = 0;
-    for (int p = 0; p < n_pairs; ++p) {
-        for (int k = h_pair_cluster_begin[p]; k < h_pair_cluster_begin[p + 1]; ++k) pair[k] = p;
-        pair_pt[p] = h_cluster_begin[h_pair_cluster_begin[p]];
-        pair_pt[p + 1] = h_cluster_begin[h_pair_cluster_begin[p + 1]];
-        if (pair_pt[p + 1] - pair_pt[p] > max_pair_pts) max_pair_pts = pair_pt[p + 1] - pair_pt[p];
-    }
-    HIPCHK(c, hipMemcpyAsync(c->t_pairpt, pair_pt.data(), sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->t_begin, h_cluster_begin, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
-    if (n_clusters) HIPCHK(c, hipMemcpyAsync(c->t_pair, pair.data(), sizeof(int32_t) * n_clusters, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->t_T, h_T, sizeof(float) * 12 * n_pairs, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));  // `pair` is a pageable temporary
-    TrackJob J;
-    memset(&J, 0, sizeof(J));
-    J.members = d_members;
-    J.pt_cluster_begin = c->t_begin;
-    J.n_clusters = n_clusters;
-    J.n_pts = n_pts;
-    J.cluster_pair = c->t_pair;
-    J.pair_pt_begin = c->t_pairpt;
-    J.n_pairs = n_pairs;
-    J.max_pair_pts = max_pair_pts;
+    int rc;
+    if ((rc = upload_if_changed(c, c->up_T, h_T, (size_t)12 * B, c->t_T, st))) return rc;
+    if ((rc = upload_if_changed(c, c->up_next, next.data(), (size_t)B, c->d_next_scan, st))) return rc;
+    if ((rc = upload_if_changed(c, c->up_ext, h_ext_tables, (size_t)n_ext, (void*)c->d_ext, st))) return rc;
+    TrackBatch J;
+    J.next_scan = c->d_next_scan;
+    J.ext_tables = c->d_ext;
+    J.n_ext = n_ext;
     J.T = c->t_T;
-    J.hit_slot = c->t_hit;
-    J.work = c->t_work;
-    J.uniq_slots = c->t_uniq;
-    J.uniq_count = c->t_count;
-    launch_track(c->dev, c->A, J, c->batch_mode == 2 ? 2 : 1, st, timer_hook, c);
+    J.occupancy = c->params.occupancy;
+    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, st, timer_hook, c);
     HIPCHK(c, hipGetLastError());
-    c->last_track_clusters = n_clusters;
+    c->track_valid = true;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
 
-int scvod_batch_track_counts(scvod_ctx* c, int32_t* h_out_unique, int32_t n_clusters) {
-    if (!c || !h_out_unique || n_clusters < 0 || n_clusters > c->last_track_clusters) return SCVOD_ERR_INVALID;
+int scvod_batch_export_table(scvod_ctx* c, int32_t s, void* d_out, int64_t cap_records, void* stream) {
+    if (!c || !d_out || cap_records < 1) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (!c->track_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_export_table needs scvod_batch_track first");
+    if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
     HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    launch_export_table(c->A, s, (int4*)d_out, (long long)cap_records, st);
+    HIPCHK(c, hipGetLastError());
+    return SCVOD_OK;
+}
+
+int scvod_batch_fetch_track(scvod_ctx* c, int32_t s, scvod_track_result* out) {
+    if (!c || !out) return SCVOD_ERR_INVALID;
+    if (!c->track_valid) return fail(c, SCVOD_ERR_STATE, "no tracking result for the last batch");
+    int rc = ensure_counts(c);
+    if (rc) return rc;
+    if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
-    if (n_clusters) HIPCHK(c, hipMemcpy(h_out_unique, c->t_count, sizeof(int32_t) * n_clusters, hipMemcpyDeviceToHost));
+    const Arena& A = c->A;
+    const size_t base = (size_t)c->h_scan_off[s];
+    const int n = c->h_counts[(size_t)s * 8 + 4];
+    int32_t sc[4];
+    HIPCHK(c, hipMemcpy(sc, A.tk_scan + (size_t)s * 4, sizeof(sc), hipMemcpyDeviceToHost));
+    const int ncl = sc[0];
+    memset(out, 0, sizeof(*out));
+    out->n_apri = n;
+    out->n_clusters = ncl;
+    out->n_car_points = sc[1];
+    out->n_dynamic_clusters = sc[2];
+    out->n_dynamic_points = sc[3];
+    // per-root device arrays of this scan -> compact per-cluster host arrays
+    const size_t nn = n > 0 ? (size_t)n : 1;
+    std::vector<int32_t> roots(nn), cnt(nn), nuq(nn), npr(nn), mbeg(nn);
+    std::vector<int8_t> state(nn);
+    std::vector<int2> pairs(nn);
+    c->tk_stage_dyn.resize(nn);
+    if (n) {
+        HIPCHK(c, hipMemcpy(roots.data(), A.tk_clusters + base, 4 * (size_t)(ncl > 0 ? ncl : 0), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(cnt.data(), A.cl_count + base, 4 * nn, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(nuq.data(), A.tk_nuniq + base, 4 * nn, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(npr.data(), A.tk_npairs + base, 4 * nn, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(mbeg.data(), A.tk_mbegin + base, 4 * nn, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(state.data(), A.cl_state + base, nn, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(pairs.data(), A.tk_pairs + base, 8 * nn, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->tk_stage_dyn.data(), A.pt_dyn + base, nn, hipMemcpyDeviceToHost));
+    }
+    size_t n_pairs = 0;
+    for (int k = 0; k < ncl; ++k) n_pairs += (size_t)npr[roots[k]];
+    std::vector<int32_t>& h = c->tk_stage;
+    h.assign((size_t)5 * ncl + 1 + 2 * n_pairs + 8, 0);
+    int32_t* p_root = h.data();
+    int32_t* p_size = p_root + ncl;
+    int32_t* p_state = p_size + ncl;
+    int32_t* p_nuq = p_state + ncl;
+    int32_t* p_pbeg = p_nuq + ncl;
+    int32_t* p_plab = p_pbeg + ncl + 1;
+    int32_t* p_pcnt = p_plab + n_pairs;
+    size_t o = 0;
+    for (int k = 0; k < ncl; ++k) {
+        const int r = roots[k];
+        p_root[k] = r;
+        p_size[k] = cnt[r];
+        p_state[k] = state[r];
+        p_nuq[k] = nuq[r];
+        p_pbeg[k] = (int32_t)o;
+        for (int j = 0; j < npr[r]; ++j, ++o) {
+            p_plab[o] = pairs[(size_t)mbeg[r] + j].x;
+            p_pcnt[o] = pairs[(size_t)mbeg[r] + j].y;
+        }
+    }
+    p_pbeg[ncl] = (int32_t)o;
+    out->cluster_root = p_root;
+    out->cluster_size = p_size;
+    out->cluster_state = p_state;
+    out->n_unique = p_nuq;
+    out->pair_begin = p_pbeg;
+    out->pair_label = p_plab;
+    out->pair_count = p_pcnt;
+    out->pt_dyn = c->tk_stage_dyn.data();
     return SCVOD_OK;
 }
 

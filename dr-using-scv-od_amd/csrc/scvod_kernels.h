@@ -105,6 +105,23 @@ struct Arena {
     uint32_t* cl_bbox;        // [6N] per cluster root: min xyz / max xyz in order-preserving uint encoding
     int32_t* cl_count;        // [N] per cluster root: number of points
     uint8_t* pt_type;         // [N] per apri point: 0 erased, 1 other, 2 car
+    // sequence differencing on the device (scvod_batch_track, scvod_track.hip)
+    int4* vox_track;          // [N] per voxel: {key, label = cluster root of its points or -1, |occupy_voxels| of that
+                              //     cluster, its type}: the table the probe of the PREVIOUS scan runs against; also the
+                              //     boundary message between sequence shards (scvod_batch_export_table)
+    int32_t* cl_nvox;         // [N] per cluster root: number of voxels labelled with it (Cluster::occupy_voxels.size())
+    int8_t* cl_state;         // [N] per cluster root: Cluster::state (-1 untouched, 0 static, 1 dynamic)
+    int32_t* tk_mbegin;       // [N] per car root: first slot of its members in tk_members (scan-local)
+    int32_t* tk_cursor;       // [N] per car root: scatter cursor
+    int32_t* tk_members;      // [N] per scan: apri indices of the car points, grouped by cluster
+    int32_t* tk_hit;          // [N] per member slot: slot of the next table hit by the transformed point, or -1
+    int32_t* tk_uniq;         // [N] per cluster region: sorted unique hit slots (sampleVec, ssc.cpp:1319-1321)
+    int32_t* tk_nuniq;        // [N] per car root
+    int2* tk_pairs;           // [N] per cluster region: (next label, unique voxels) = remap_name (ssc.cpp:1275,1304-1316)
+    int32_t* tk_npairs;       // [N] per car root: remap_name.size()
+    int32_t* tk_clusters;     // [N] per scan: roots of its car clusters, ascending
+    int32_t* tk_scan;         // [B][4] per scan: car clusters, car points, dynamic clusters, dynamic points
+    uint8_t* pt_dyn;          // [N] per apri point: SCVOD_DYN_*
     // loader-side VoxelGrid
     int32_t* vg_par;          // [B][16] per scan: min_b[3], mul[3], overflow flag, kept points, distinct cells
     int32_t* vg_range;        // [1] largest cell index range of the batch
@@ -137,6 +154,14 @@ struct TrackJob {          // scan-vs-next-scan probe
     int32_t* uniq_count;   // [n_clusters]
 };
 
+struct TrackBatch {            // scvod_batch_track: every scan of the batch against its successor
+    const int32_t* next_scan;      // [B] successor of scan s: index in the batch, -1 = none, <= -2 = external table -2 - v
+    const int4* const* ext_tables; // device array of external tables: record 0 = {n_voxels, 0, 0, 0}, then vox_track records
+    int32_t n_ext;
+    const float* T;                // [B][12] trans_next^-1 * trans_pre of (s, successor)
+    float occupancy;               // ssc/occupancy_
+};
+
 typedef void (*TimerHook)(void* user, const char* name, int begin);
 
 // Launches.  `th`/`tu` optional per-kernel timing hook (called before and after each launch).
@@ -159,6 +184,9 @@ void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHoo
 void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
+void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, hipStream_t st, TimerHook th,
+                        void* tu);
+void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
                float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work,
                hipStream_t st);

@@ -1,0 +1,336 @@
+// scvod_map.hip -- world-frame static map of a sequence shard, and its merge across shards (gfx950).
+//
+// Reference analogue: the sequence-level accumulation `*instance_map += *rgb_ptr` of the clouds that are not dynamic
+// (SSC::saveSegCloud mode 3, /root/reference/src/ssc.cpp:477-500, 532-554) together with the ground clouds and the
+// range/FOV rejects the evaluation adds (ssc.cpp:1460-1480 `g_cloud_vec`, `cloud_eva_static` ssc.cpp:161-172), every
+// scan moved to the world frame by pcl::getTransformation(pose) (ssc.cpp:1455-1458).  The reference appends points to one
+// growing PCL cloud on one thread; a sequence sharded over GPUs needs a merge that does not depend on which shard saw a
+// point first, so the map is kept as a SET OF OCCUPIED CELLS (edge `leaf`), one record per cell:
+//     key = the cell's integer coordinates, val = the smallest packed {x, y, z offset inside the cell, intensity} of the
+//     points that fell into it (16 bits each) -- an actual measured point, chosen by a rule that is independent of order.
+// Insertion is one 64-bit atomicMin per point on an open-addressing table in HBM (linear probing, 16-byte records), so
+// accumulating scans in any order, on any number of shards, and merging the shards' record lists (scvod_map_merge, the
+// payload of the RCCL all_gather) gives bit-identical maps.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scvod_dev.h"
+
+using namespace scvod;
+
+struct MapRec {
+    unsigned long long key;  // ~0 = empty
+    unsigned long long val;  // packed {qx, qy, qz, qi}, 16 bits each, smallest wins
+};
+static_assert(sizeof(MapRec) == 16, "map record");
+
+struct scvod_map {
+    int device = 0;
+    float leaf = 0.2f;
+    long long capacity = 0;  // power of two
+    MapRec* table = nullptr;
+    unsigned long long* counters = nullptr;  // [0] records exported, [1] insertions dropped (table full / out of range)
+    float* d_pose = nullptr;                 // [pose_cap][12]
+    long long pose_cap = 0;
+    std::vector<float> up_pose;
+    std::string err;
+};
+
+namespace {
+
+constexpr unsigned long long kEmpty = ~0ull;
+constexpr int kCellBits = 21, kCellBias = 1 << 20;
+
+int mfail(scvod_map* m, int code, const char* fmt, ...) {
+    if (m) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        m->err = buf;
+    }
+    return code;
+}
+#define MHIP(m, call)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e__ = (call);                                                                         \
+        if (e__ != hipSuccess) return mfail(m, SCVOD_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+__device__ __forceinline__ unsigned long long map_mix(unsigned long long k) {  // murmur3 finaliser
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// cell + packed in-cell offset of a world point.  floor(p * inv_leaf) like pcl::VoxelGrid's cell index; the offset is
+// quantised to 16 bits of the cell edge, the intensity to 1/256 (clamped to [0, 255.996]).
+__device__ __forceinline__ bool map_encode(float x, float y, float z, float intensity, float inv_leaf, unsigned long long& key,
+                                           unsigned long long& val) {
+    const float fx = x * inv_leaf, fy = y * inv_leaf, fz = z * inv_leaf;
+    const float cx = floor_f(fx), cy = floor_f(fy), cz = floor_f(fz);
+    if (!(cx >= -(float)kCellBias && cx < (float)kCellBias && cy >= -(float)kCellBias && cy < (float)kCellBias &&
+          cz >= -(float)kCellBias && cz < (float)kCellBias))
+        return false;  // also NaN
+    const unsigned long long ux = (unsigned long long)((int)cx + kCellBias), uy = (unsigned long long)((int)cy + kCellBias),
+                             uz = (unsigned long long)((int)cz + kCellBias);
+    key = (ux << (2 * kCellBits)) | (uy << kCellBits) | uz;
+    auto q16 = [](float f) -> unsigned long long {
+        int q = (int)(f * 65536.0f);
+        return (unsigned long long)(q < 0 ? 0 : (q > 65535 ? 65535 : q));
+    };
+    float in = intensity * 256.0f;
+    in = in < 0.f ? 0.f : (in > 65535.f ? 65535.f : in);
+    val = (q16(fx - cx) << 48) | (q16(fy - cy) << 32) | (q16(fz - cz) << 16) | (unsigned long long)(int)in;
+    return true;
+}
+
+__device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mask, unsigned long long key, unsigned long long val) {
+    unsigned long long h = map_mix(key) & mask;
+    for (unsigned long long probes = 0; probes <= mask; ++probes) {
+        unsigned long long k = __hip_atomic_load(&table[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == kEmpty) {
+            k = atomicCAS(&table[h].key, kEmpty, key);
+            if (k == kEmpty) k = key;
+        }
+        if (k == key) {
+            // most points find a cell an earlier scan opened and a value that already beats theirs: test before the atomic
+            if (val < __hip_atomic_load(&table[h].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&table[h].val, val);
+            return true;
+        }
+        h = (h + 1) & mask;
+    }
+    return false;
+}
+
+// static points of scan blockIdx.y: cloud_out (ground), cloud_eva_static (range/FOV rejects) and the apri points that are
+// not dynamic, moved to the world frame with explicit fp32 dot products (the arithmetic of Utility::transformCloud,
+// utility.h:400-405)
+__global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
+                                                        float inv_leaf, int with_ground, int with_rejected, int have_dyn,
+                                                        unsigned long long* counters) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n_g = with_ground ? A.counts[s * 8 + 1] : 0;
+    const int n_r = with_rejected ? A.counts[s * 8 + 5] : 0;
+    const int n_a = A.counts[s * 8 + 4];
+    const int total = n_g + n_r + n_a;
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = pose[12 * s + i];
+    int dropped = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        int src;
+        if (t < n_g) {
+            src = A.ground_idx[(size_t)base + t];
+        } else if (t < n_g + n_r) {
+            src = A.rejected_src[(size_t)base + (t - n_g)];
+        } else {
+            const int i = t - n_g - n_r;
+            if (have_dyn && A.pt_dyn[(size_t)base + i] == SCVOD_DYN_DYNAMIC) continue;
+            src = A.apri_src[(size_t)base + i];
+        }
+        const float4 q = A.pts[base + src];
+        const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
+        const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
+        const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
+        unsigned long long key, val;
+        if (!map_encode(x, y, z, q.w, inv_leaf, key, val) || !map_insert(table, mask, key, val)) ++dropped;
+    }
+    if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
+}
+
+__global__ __launch_bounds__(256) void k_map_merge(const MapRec* __restrict__ recs, long long n, MapRec* table, unsigned long long mask,
+                                                   unsigned long long* counters) {
+    int dropped = 0;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        const MapRec r = recs[t];
+        if (r.key == kEmpty) continue;  // padding of a gathered list
+        if (!map_insert(table, mask, r.key, r.val)) ++dropped;
+    }
+    if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
+}
+
+// occupied records -> dense list (order = whatever the atomics give: consumers that need a canonical order sort by key)
+__global__ __launch_bounds__(256) void k_map_export(const MapRec* __restrict__ table, long long capacity, MapRec* out, long long cap_out,
+                                                    float4* out_xyzi, float leaf, unsigned long long* counters) {
+    const int lane = threadIdx.x & 63;
+    for (long long t0 = blockIdx.x * 256ll; t0 < capacity; t0 += (long long)gridDim.x * 256) {
+        const long long t = t0 + threadIdx.x;
+        MapRec r;
+        r.key = kEmpty;
+        if (t < capacity) r = table[t];
+        const bool occ = r.key != kEmpty;
+        const unsigned long long bal = __ballot(occ);
+        if (!bal) continue;
+        unsigned long long start = 0;
+        if (lane == 0) start = atomicAdd(&counters[0], (unsigned long long)__popcll(bal));
+        start = __shfl(start, 0);
+        if (occ) {
+            const long long o = (long long)start + __popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap_out) {
+                if (out) out[o] = r;
+                if (out_xyzi) {
+                    const int cx = (int)(r.key >> (2 * kCellBits)) - kCellBias, cy = (int)((r.key >> kCellBits) & ((1u << kCellBits) - 1u)) - kCellBias,
+                              cz = (int)(r.key & ((1u << kCellBits) - 1u)) - kCellBias;
+                    const float qx = (float)((r.val >> 48) & 0xffffu), qy = (float)((r.val >> 32) & 0xffffu), qz = (float)((r.val >> 16) & 0xffffu);
+                    out_xyzi[o] = make_float4(((float)cx + (qx + 0.5f) / 65536.0f) * leaf, ((float)cy + (qy + 0.5f) / 65536.0f) * leaf,
+                                              ((float)cz + (qz + 0.5f) / 65536.0f) * leaf, (float)(r.val & 0xffffu) / 256.0f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// the one place the map code needs the batch context: its arena, parameters and validity flags
+struct scvod_ctx;
+extern "C" int scvod__ctx_view(scvod_ctx* ctx, Arena* arena, int* device, int* track_valid, int* batch_valid, int* n_scans,
+                               int* max_scan_pts);
+
+extern "C" {
+
+int scvod_map_create(int device, int64_t capacity_cells, float leaf, scvod_map** out) {
+    if (!out || capacity_cells < 1024 || !(leaf > 0.f)) return SCVOD_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SCVOD_ERR_NO_DEVICE;
+    scvod_map* m = new scvod_map();
+    m->device = device;
+    m->leaf = leaf;
+    long long cap = 1024;
+    while (cap < capacity_cells) cap <<= 1;
+    m->capacity = cap;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&m->table, sizeof(MapRec) * (size_t)cap) != hipSuccess ||
+        hipMalloc(&m->counters, 16) != hipSuccess || hipMemset(m->table, 0xff, sizeof(MapRec) * (size_t)cap) != hipSuccess ||
+        hipMemset(m->counters, 0, 16) != hipSuccess) {
+        if (m->table) hipFree(m->table);
+        if (m->counters) hipFree(m->counters);
+        delete m;
+        return SCVOD_ERR_HIP;
+    }
+    *out = m;
+    return SCVOD_OK;
+}
+
+void scvod_map_destroy(scvod_map* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    hipDeviceSynchronize();
+    if (m->table) hipFree(m->table);
+    if (m->counters) hipFree(m->counters);
+    if (m->d_pose) hipFree(m->d_pose);
+    delete m;
+}
+
+const char* scvod_map_last_error(const scvod_map* m) { return m ? m->err.c_str() : "null map"; }
+int64_t scvod_map_capacity(const scvod_map* m) { return m ? (int64_t)m->capacity : 0; }
+
+int scvod_map_clear(scvod_map* m, void* stream) {
+    if (!m) return SCVOD_ERR_INVALID;
+    MHIP(m, hipSetDevice(m->device));
+    MHIP(m, hipMemsetAsync(m->table, 0xff, sizeof(MapRec) * (size_t)m->capacity, (hipStream_t)stream));
+    MHIP(m, hipMemsetAsync(m->counters, 0, 16, (hipStream_t)stream));
+    return SCVOD_OK;
+}
+
+// pcl::getTransformation(x, y, z, roll, pitch, yaw) as a row-major 3x4 matrix (the arithmetic scvod_pose_delta uses)
+void scvod_pose_matrix(const float p[6], float t[12]) {
+    const float x = p[0], y = p[1], z = p[2], roll = p[3], pitch = p[4], yaw = p[5];
+    const float A = std::cos(yaw), B = std::sin(yaw), C = std::cos(pitch), D = std::sin(pitch), E = std::cos(roll), F = std::sin(roll),
+                DE = D * E, DF = D * F;
+    t[0] = A * C;
+    t[1] = A * DF - B * E;
+    t[2] = B * F + A * DE;
+    t[3] = x;
+    t[4] = B * C;
+    t[5] = A * E + B * DF;
+    t[6] = B * DE - A * F;
+    t[7] = y;
+    t[8] = -D;
+    t[9] = C * F;
+    t[10] = C * E;
+    t[11] = z;
+}
+
+int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_poses, int32_t flags, void* stream) {
+    if (!ctx || !m || !h_poses) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
+    Arena A;
+    int device = 0, track_valid = 0, batch_valid = 0, n_scans = 0, max_pts = 0;
+    scvod__ctx_view(ctx, &A, &device, &track_valid, &batch_valid, &n_scans, &max_pts);
+    if (!batch_valid) return mfail(m, SCVOD_ERR_STATE, "scvod_batch_map_accumulate needs a processed batch");
+    const int use_dyn = !(flags & SCVOD_MAP_IGNORE_DYNAMIC);
+    if (use_dyn && !track_valid) return mfail(m, SCVOD_ERR_STATE, "no tracking result: run scvod_batch_track or pass SCVOD_MAP_IGNORE_DYNAMIC");
+    if (device != m->device) return mfail(m, SCVOD_ERR_INVALID, "map and ctx live on different devices");
+    MHIP(m, hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> T((size_t)12 * n_scans);
+    for (int s = 0; s < n_scans; ++s) scvod_pose_matrix(h_poses + 6 * s, T.data() + 12 * s);
+    if (m->pose_cap < n_scans) {
+        MHIP(m, hipStreamSynchronize(st));
+        if (m->d_pose) hipFree(m->d_pose);
+        m->d_pose = nullptr;
+        m->pose_cap = 0;
+        m->up_pose.clear();
+        MHIP(m, hipMalloc(&m->d_pose, sizeof(float) * 12 * (size_t)n_scans));
+        m->pose_cap = n_scans;
+    }
+    if (m->up_pose != T) {  // the staging vector may still feed an earlier asynchronous copy
+        MHIP(m, hipStreamSynchronize(st));
+        m->up_pose = T;
+        MHIP(m, hipMemcpyAsync(m->d_pose, m->up_pose.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice, st));
+    }
+    if (max_pts > 0) {
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+                           (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
+                           (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, m->counters);
+        MHIP(m, hipGetLastError());
+    }
+    return SCVOD_OK;
+}
+
+static int map_export(scvod_map* m, void* d_records, void* d_xyzi, int64_t cap, int64_t* n_out, void* stream) {
+    if (!m || !n_out || cap < 0) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
+    MHIP(m, hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    MHIP(m, hipMemsetAsync(m->counters, 0, 8, st));
+    hipLaunchKernelGGL(k_map_export, dim3(256 * 8), dim3(256), 0, st, m->table, m->capacity, (MapRec*)d_records, (long long)cap, (float4*)d_xyzi,
+                       m->leaf, m->counters);
+    MHIP(m, hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    MHIP(m, hipMemcpyAsync(h, m->counters, 16, hipMemcpyDeviceToHost, st));
+    MHIP(m, hipStreamSynchronize(st));
+    *n_out = (int64_t)h[0];
+    if (h[1]) return mfail(m, SCVOD_ERR_CAPACITY, "%llu points did not fit the map (table of %lld cells full or coordinates out of range)", h[1], m->capacity);
+    if ((d_records || d_xyzi) && (int64_t)h[0] > cap) return mfail(m, SCVOD_ERR_CAPACITY, "output buffer too small (%lld < %llu cells)", (long long)cap, h[0]);
+    return SCVOD_OK;
+}
+
+int scvod_map_export(scvod_map* m, void* d_records, int64_t cap_records, int64_t* n_out, void* stream) {
+    return map_export(m, d_records, nullptr, cap_records, n_out, stream);
+}
+int scvod_map_points(scvod_map* m, void* d_xyzi, void* d_keys_records, int64_t cap, int64_t* n_out, void* stream) {
+    return map_export(m, d_keys_records, d_xyzi, cap, n_out, stream);
+}
+
+int scvod_map_merge(scvod_map* m, const void* d_records, int64_t n, void* stream) {
+    if (!m || n < 0 || (n > 0 && !d_records)) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
+    if (n == 0) return SCVOD_OK;
+    MHIP(m, hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_map_merge, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const MapRec*)d_records, (long long)n, m->table,
+                       (unsigned long long)(m->capacity - 1), m->counters);
+    MHIP(m, hipGetLastError());
+    return SCVOD_OK;
+}
+
+}  // extern "C"

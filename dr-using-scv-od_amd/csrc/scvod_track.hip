@@ -1,0 +1,406 @@
+// scvod_track.hip -- scan-vs-next-scan differencing of a whole sequence shard on the device (gfx950, wave64).
+//
+// Reference: SSC::tracking, /root/reference/src/ssc.cpp:1250-1426, as SSC::segDF drives it (ssc.cpp:1449-1451: every
+// frame against its successor).  For every `car` cluster of scan s (type from the bounding-box rules, ssc.cpp:849-872):
+//   transform its points into the successor's frame (utility.h:394-406), re-bin them WITHOUT range/FOV rejection or
+//   clamping (ssc.cpp:1280-1286), look the voxel up in the successor's hash_cloud and keep it when its label != -1
+//   (ssc.cpp:1304-1305); group the hits by that label, sampleVec each group (ssc.cpp:1319-1321) -> remap_name;
+//   state = 1 (dynamic) when remap_name is empty (ssc.cpp:1323-1326) or when it has ONE label whose cluster is a car and
+//   (float)|hits| / (float)|occupy_voxels| < occupancy (ssc.cpp:1336-1349); state = 0 (static) for one non-car label below
+//   the ratio (ssc.cpp:1351-1352), one car label at or above it (ssc.cpp:1378-1380) and for several labels (ssc.cpp:1396-1397);
+//   one non-car label at or above the ratio leaves the state untouched (-1).
+// The labels / cluster sizes / types of the successor are those of its fresh segmentation (clusterAndCreateFrame +
+// refineClusterByBoundingBox + the box rules of recognize), i.e. the state SSC::tracking finds before an earlier pair has
+// re-labelled anything: the FIRST-ORDER decision.  The re-labelling chain of ssc.cpp:1354-1372 / 1399-1419 (a pair mutates
+// the successor's cluster_set before the next pair reads it) is sequential host bookkeeping and lives in host/ssc.cpp.
+//
+// Everything stays in HBM: cluster names and types come from scvod_batch_cluster / scvod_batch_cluster_types, the member
+// lists of the car clusters are built here (counting sort by cluster root), no host round trip inside a call.
+#include "scvod_dev.h"
+
+namespace scvod {
+
+constexpr int kTkSamples = 8192;     // sampled successor keys staged in LDS (32 KB)
+constexpr int kTkBitWords = 16384;   // bitset over the successor's voxel table: 2^19 slots = SCVOD_MAX_SCAN_POINTS
+
+// lanes of a wave that hold the same key (neighbouring apri points / voxels mostly do): leader lane, rank inside the group
+// and group size, so that ONE lane per distinct key issues the atomic.  key < 0 = idle lane.
+__device__ __forceinline__ void wave_group(int key, int& leader, int& rank, int& count) {
+    const int lane = threadIdx.x & 63;
+    bool todo = key >= 0;
+    leader = lane;
+    rank = 0;
+    count = 0;
+    while (__any(todo)) {
+        const int first = __ffsll((long long)__ballot(todo)) - 1;
+        const int k0 = __shfl(key, first);
+        const bool mine = todo && (key == k0);
+        const unsigned long long mask = __ballot(mine);
+        if (mine) {
+            leader = first;
+            rank = __popcll(mask & ((1ull << lane) - 1ull));
+            count = __popcll(mask);
+            todo = false;
+        }
+    }
+}
+
+struct NextTable {
+    const int4* tab;  // records {key, label, cluster voxels, cluster type}, ascending key
+    int nv;
+};
+__device__ __forceinline__ NextTable next_table_of(const Arena& A, const TrackBatch& J, int s) {
+    NextTable t;
+    t.tab = nullptr;
+    t.nv = -1;  // no successor
+    const int nxt = J.next_scan[s];
+    if (nxt >= 0) {
+        t.tab = A.vox_track + A.scan_off[nxt];
+        t.nv = A.counts[nxt * 8 + 6];
+    } else if (nxt <= -2 && (-2 - nxt) < J.n_ext) {
+        const int4* e = J.ext_tables[-2 - nxt];
+        t.nv = e[0].x;
+        t.tab = e + 1;
+    }
+    return t;
+}
+
+// per cluster root: reset the per-cluster words this call accumulates into
+__global__ __launch_bounds__(256) void k_tk_init(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    if (blockIdx.x == 0 && threadIdx.x < 4) A.tk_scan[s * 4 + threadIdx.x] = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (A.pt_cluster[(size_t)base + i] != i) continue;
+        A.cl_nvox[(size_t)base + i] = 0;
+        A.tk_cursor[(size_t)base + i] = 0;
+        A.cl_state[(size_t)base + i] = -1;
+        A.tk_npairs[(size_t)base + i] = 0;
+        A.tk_nuniq[(size_t)base + i] = 0;
+    }
+}
+
+// Voxel::label after clusterAndCreateFrame + refineClusterByBoundingBox (ssc.cpp:388-392, 461-466): the cluster of the
+// voxel's points (all points of a voxel share one), -1 when the bounding-box refine erased that cluster; and
+// |occupy_voxels| per cluster (sampleVec of its points' voxel_idx, ssc.cpp:382-384) = the number of voxels carrying its label.
+__global__ __launch_bounds__(256) void k_tk_voxlabel(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int nv = A.counts[s * 8 + 6];
+    const int32_t* vbeg = A.vox_pt_begin + base + s;
+    for (int v0 = blockIdx.x * 256; v0 < nv; v0 += gridDim.x * 256) {
+        const int v = v0 + threadIdx.x;
+        int label = -1;
+        if (v < nv) {
+            const int p = A.vox_pts[(size_t)base + vbeg[v]];
+            label = A.pt_type[(size_t)base + p] ? A.pt_cluster[(size_t)base + p] : -1;
+            A.vox_track[(size_t)base + v] = make_int4(A.vox_key[(size_t)base + v], label, 0, 0);
+        }
+        int leader, rank, count;
+        wave_group(label, leader, rank, count);
+        if (label >= 0 && rank == 0) atomicAdd(&A.cl_nvox[(size_t)base + label], count);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tk_voxfill(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int nv = A.counts[s * 8 + 6];
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+        const int label = A.vox_track[(size_t)base + v].y;
+        if (label < 0) continue;
+        A.vox_track[(size_t)base + v].z = A.cl_nvox[(size_t)base + label];
+        A.vox_track[(size_t)base + v].w = (int)A.pt_type[(size_t)base + label];  // the root is a member: its type is the cluster's
+    }
+}
+
+// one workgroup per scan: offsets of the member lists of its car clusters (exclusive scan of the cluster sizes over
+// the roots in ascending order) and the list of those roots
+__global__ __launch_bounds__(1024) void k_tk_members(Arena A) {
+    __shared__ int wsum[17];
+    const int s = blockIdx.x;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    int run_p = 0, run_c = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        const bool is_root = (i < n) && A.pt_cluster[(size_t)base + i] == i && A.pt_type[(size_t)base + i] == 2;
+        const int cnt = is_root ? A.cl_count[(size_t)base + i] : 0;
+        int tp, tc;
+        const int ep = block_excl_scan<1024>(cnt, tp, wsum);
+        const int ec = block_excl_scan<1024>(is_root ? 1 : 0, tc, wsum);
+        if (is_root) {
+            A.tk_mbegin[(size_t)base + i] = run_p + ep;
+            A.tk_clusters[(size_t)base + run_c + ec] = i;
+        }
+        run_p += tp;
+        run_c += tc;
+    }
+    if (threadIdx.x == 0) {
+        A.tk_scan[s * 4 + 0] = run_c;
+        A.tk_scan[s * 4 + 1] = run_p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tk_scatter(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        int r = -1;
+        if (i < n && A.pt_type[(size_t)base + i] == 2) r = A.pt_cluster[(size_t)base + i];
+        int leader, rank, count;
+        wave_group(r, leader, rank, count);
+        int old = 0;
+        if (r >= 0 && rank == 0) old = atomicAdd(&A.tk_cursor[(size_t)base + r], count);
+        old = __shfl(old, leader);
+        if (r >= 0) A.tk_members[(size_t)base + A.tk_mbegin[(size_t)base + r] + old + rank] = i;
+    }
+}
+
+// Transform + unfiltered re-bin + look-up of every car point of scan s in its successor's table.  The table's keys are
+// staged in LDS sampled every 2^shift entries (<= 8192 samples); the last <= 2^shift candidates are one or two cache
+// lines of the table itself.
+__global__ __launch_bounds__(256) void k_tk_probe(DevParams P, Arena A, TrackBatch J, int from_apri) {
+    __shared__ int32_t skeys[kTkSamples];
+    const int s = blockIdx.y;
+    const int n_car = A.tk_scan[s * 4 + 1];
+    if ((int)blockIdx.x * 256 >= n_car) return;
+    const NextTable N = next_table_of(A, J, s);
+    if (N.nv < 0) return;
+    const int base = A.scan_off[s];
+    int shift = 0;
+    while (((N.nv + (1 << shift) - 1) >> shift) > kTkSamples) ++shift;
+    const int ns = (N.nv + (1 << shift) - 1) >> shift;
+    for (int j = threadIdx.x; j < ns; j += 256) skeys[j] = N.tab[(size_t)j << shift].x;
+    __syncthreads();
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = J.T[12 * s + i];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n_car; k += gridDim.x * 256) {
+        const int i = A.tk_members[(size_t)base + k];
+        float4 q;
+        if (!from_apri) {  // the point itself is read through apri_src (cloud_use[i] = input point apri_src[i])
+            q = A.pts[base + A.apri_src[(size_t)base + i]];
+        } else {  // apri_vec supplied by the caller (no input cloud on the device)
+            const scvod_apri& a = A.apri[(size_t)base + i];
+            q = make_float4(a.x, a.y, a.z, a.intensity);
+        }
+        // Utility::transformCloud (utility.h:401-404): explicit fp32 dot products, no FMA
+        const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
+        const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
+        const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
+        Apri a;
+        apri_of_point(P.bin, x, y, z, q.w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
+        const int key = a.voxel_idx;
+        int lo = 0, hi = ns;  // first sample > key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (skeys[mid] <= key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        int slot = -1;
+        if (lo > 0) {
+            int a0 = (lo - 1) << shift;
+            const int a1 = min(a0 + (1 << shift), N.nv);
+            for (; a0 < a1; ++a0) {
+                const int4 rec = N.tab[a0];
+                if (rec.x >= key) {
+                    if (rec.x == key && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
+                    break;
+                }
+            }
+        }
+        A.tk_hit[(size_t)base + k] = slot;
+    }
+}
+
+__device__ __forceinline__ int block_min_128(int v, int* red) {  // 128 threads; red: LDS int[2]
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return min(red[0], red[1]);
+}
+__device__ __forceinline__ int block_sum_128(int v, int* red) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1];
+}
+
+// One workgroup per car cluster (persistent over the clusters of its scan): bitset of the hit slots -> sorted unique
+// list (sampleVec without a sort), grouped by label -> remap_name, then the state rule.
+__global__ __launch_bounds__(128) void k_tk_decide(Arena A, TrackBatch J) {
+    __shared__ uint32_t bits[kTkBitWords];
+    __shared__ int wsum[3];
+    __shared__ int red[2];
+    const int s = blockIdx.y;
+    const int ncl = A.tk_scan[s * 4 + 0];
+    if ((int)blockIdx.x >= ncl) return;
+    const NextTable N = next_table_of(A, J, s);
+    if (N.nv < 0) return;  // last scan of a sequence: no tracking call, states stay -1
+    const int base = A.scan_off[s];
+    const int nw = min((N.nv + 31) >> 5, kTkBitWords);
+    for (int w = threadIdx.x; w < nw; w += 128) bits[w] = 0u;
+    __syncthreads();
+    for (int ord = blockIdx.x; ord < ncl; ord += gridDim.x) {
+        const int root = A.tk_clusters[(size_t)base + ord];
+        const int k0 = A.tk_mbegin[(size_t)base + root];
+        const int m = A.cl_count[(size_t)base + root];
+        int wlo = 0x7fffffff, whi = -1;
+        for (int j = threadIdx.x; j < m; j += 128) {
+            const int slot = A.tk_hit[(size_t)base + k0 + j];
+            if (slot >= 0 && (slot >> 5) < nw) {
+                atomicOr(&bits[slot >> 5], 1u << (slot & 31));
+                wlo = min(wlo, slot >> 5);
+                whi = max(whi, slot >> 5);
+            }
+        }
+        wlo = block_min_128(wlo, red);
+        whi = -block_min_128(-whi, red);
+        // sorted unique slots of the cluster, only over the words it touched; the words are cleared on the way
+        int run = 0;
+        for (int w0 = wlo; w0 <= whi; w0 += 128) {
+            const int w = w0 + threadIdx.x;
+            uint32_t word = 0u;
+            if (w <= whi) {
+                word = bits[w];
+                bits[w] = 0u;
+            }
+            int total;
+            const int ex = block_excl_scan<128>(__popc(word), total, wsum);
+            int o = k0 + run + ex;
+            while (word) {
+                const int b = __ffs(word) - 1;
+                word &= word - 1;
+                A.tk_uniq[(size_t)base + o++] = (w << 5) + b;
+            }
+            run += total;
+        }
+        __syncthreads();  // tk_uniq of this cluster is complete (global writes of this block, read back below)
+        const int U = run;
+        // remap_name: labels in ascending order with the number of unique voxels each
+        int npairs = 0, one_count = 0, one_nvox = 1, one_type = 0;
+        int cur = -1;
+        for (;;) {
+            int mn = 0x7fffffff;
+            for (int j = threadIdx.x; j < U; j += 128) {
+                const int lab = N.tab[A.tk_uniq[(size_t)base + k0 + j]].y;
+                if (lab > cur) mn = min(mn, lab);
+            }
+            mn = block_min_128(mn, red);
+            if (mn == 0x7fffffff) break;
+            int cnt = 0, nvx = 0, typ = 0;
+            for (int j = threadIdx.x; j < U; j += 128) {
+                const int4 rec = N.tab[A.tk_uniq[(size_t)base + k0 + j]];
+                if (rec.y == mn) {
+                    ++cnt;
+                    nvx = rec.z;
+                    typ = rec.w;
+                }
+            }
+            const int any_nvx = -block_min_128(-nvx, red), any_typ = -block_min_128(-typ, red);
+            cnt = block_sum_128(cnt, red);
+            if (threadIdx.x == 0) A.tk_pairs[(size_t)base + k0 + npairs] = make_int2(mn, cnt);
+            if (npairs == 0) {
+                one_count = cnt;
+                one_nvox = any_nvx;
+                one_type = any_typ;
+            }
+            ++npairs;
+            cur = mn;
+        }
+        if (threadIdx.x == 0) {
+            int state;
+            if (npairs == 0) {
+                state = 1;  // nothing of the successor under the transformed cluster (ssc.cpp:1323-1326)
+            } else if (npairs == 1) {
+                const float ratio = (float)one_count / (float)one_nvox;  // ssc.cpp:1336
+                if (ratio < J.occupancy)
+                    state = (one_type == 2) ? 1 : 0;  // ssc.cpp:1337-1352
+                else
+                    state = (one_type == 2) ? 0 : -1;  // ssc.cpp:1377-1380; a non-car successor leaves it untouched
+            } else {
+                state = 0;  // ssc.cpp:1396-1397
+            }
+            A.cl_state[(size_t)base + root] = (int8_t)state;
+            A.tk_nuniq[(size_t)base + root] = U;
+            A.tk_npairs[(size_t)base + root] = npairs;
+            if (state == 1) {
+                atomicAdd(&A.tk_scan[s * 4 + 2], 1);
+                atomicAdd(&A.tk_scan[s * 4 + 3], m);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// per apri point: dynamic when its cluster was decided dynamic; points of clusters the bounding-box refine erased belong
+// to no cluster (the reference lists them as static, ssc.cpp:450-454)
+__global__ __launch_bounds__(256) void k_tk_dyn(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int t = A.pt_type[(size_t)base + i];
+        uint8_t d = SCVOD_DYN_STATIC;
+        if (t == 0)
+            d = SCVOD_DYN_UNCLUSTERED;
+        else if (t == 2 && A.cl_state[(size_t)base + A.pt_cluster[(size_t)base + i]] == 1)
+            d = SCVOD_DYN_DYNAMIC;
+        A.pt_dyn[(size_t)base + i] = d;
+    }
+}
+
+// boundary message of a sequence shard: header {n_voxels, 0, 0, 0} + the vox_track records of scan s
+__global__ __launch_bounds__(256) void k_tk_export(Arena A, int s, int4* out, long long cap_records) {
+    const int base = A.scan_off[s];
+    const int nv = A.counts[s * 8 + 6];
+    const long long fit = cap_records - 1 < (long long)nv ? cap_records - 1 : (long long)nv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = make_int4((int)fit, nv, 0, 0);
+    for (long long v = blockIdx.x * 256 + threadIdx.x; v < fit; v += (long long)gridDim.x * 256) out[1 + v] = A.vox_track[(size_t)base + v];
+}
+
+#define TH_BEGIN(name) \
+    if (th) th(tu, name, 1)
+#define TH_END(name) \
+    if (th) th(tu, name, 0)
+
+void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, hipStream_t st, TimerHook th,
+                        void* tu) {
+    const int B = A.n_scans;
+    if (B <= 0 || A.max_scan_pts <= 0) return;
+    const dim3 g((A.max_scan_pts + 2047) / 2048, B);
+    TH_BEGIN("tk_labels");
+    hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_tk_voxlabel, g, dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_tk_voxfill, g, dim3(256), 0, st, A);
+    TH_END("tk_labels");
+    TH_BEGIN("tk_members");
+    hipLaunchKernelGGL(k_tk_members, dim3(B), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_tk_scatter, g, dim3(256), 0, st, A);
+    TH_END("tk_members");
+    TH_BEGIN("tk_probe");
+    hipLaunchKernelGGL(k_tk_probe, dim3((A.max_scan_pts + 4095) / 4096, B), dim3(256), 0, st, P, A, J, from_apri);
+    TH_END("tk_probe");
+    TH_BEGIN("tk_decide");
+    hipLaunchKernelGGL(k_tk_decide, dim3(32, B), dim3(128), 0, st, A, J);
+    TH_END("tk_decide");
+    TH_BEGIN("tk_dyn");
+    hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A);
+    TH_END("tk_dyn");
+}
+
+void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st) {
+    hipLaunchKernelGGL(k_tk_export, dim3(64), dim3(256), 0, st, A, s, out, cap_records);
+}
+
+}  // namespace scvod

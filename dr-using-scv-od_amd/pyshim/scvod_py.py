@@ -47,6 +47,13 @@ class ScanResult(C.Structure):
                                           "rejected_src", "vox_key", "vox_pt_begin", "vox_pts", "vox_av", "vox_cov")]
 
 
+class TrackResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_apri", "n_clusters", "n_car_points", "n_dynamic_clusters", "n_dynamic_points",
+                                          "reserved")] + \
+               [(n, C.c_void_p) for n in ("cluster_root", "cluster_size", "cluster_state", "n_unique", "pair_begin",
+                                          "pair_label", "pair_count", "pt_dyn")]
+
+
 # ssc/ keys of config/*.yaml -> Params fields (include/utility.h:283-310)
 YAML_KEYS = {"sensor_height_": "sensor_height", "min_dis_": "min_dis", "max_dis_": "max_dis", "min_angle_": "min_angle",
              "max_angle_": "max_angle", "min_azimuth_": "min_azimuth", "max_azimuth_": "max_azimuth",
@@ -114,8 +121,19 @@ def load_lib():
         "scvod_cluster": (C.c_int, [vp, vp, i32, vp]),
         "scvod_batch_cluster_types": (C.c_int, [vp, vp, i32]),
         "scvod_batch_fetch_cluster_types": (C.c_int, [vp, i32, i32, i32, vp, i32]),
-        "scvod_batch_track": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, i32]),
-        "scvod_batch_track_counts": (C.c_int, [vp, vp, i32]),
+        "scvod_batch_track": (C.c_int, [vp, vp, vp, vp, i32, vp, i32]),
+        "scvod_batch_fetch_track": (C.c_int, [vp, i32, C.POINTER(TrackResult)]),
+        "scvod_batch_export_table": (C.c_int, [vp, i32, vp, i64, vp]),
+        "scvod_map_create": (C.c_int, [C.c_int, i64, f32, C.POINTER(vp)]),
+        "scvod_map_destroy": (None, [vp]),
+        "scvod_map_last_error": (C.c_char_p, [vp]),
+        "scvod_map_capacity": (i64, [vp]),
+        "scvod_map_clear": (C.c_int, [vp, vp]),
+        "scvod_pose_matrix": (None, [vp, vp]),
+        "scvod_batch_map_accumulate": (C.c_int, [vp, vp, vp, i32, vp]),
+        "scvod_map_export": (C.c_int, [vp, vp, i64, C.POINTER(i64), vp]),
+        "scvod_map_merge": (C.c_int, [vp, vp, i64, vp]),
+        "scvod_map_points": (C.c_int, [vp, vp, vp, i64, C.POINTER(i64), vp]),
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
         "scvod_set_timing": (C.c_int, [vp, i32]),
         "scvod_nn_search": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp]),
@@ -136,7 +154,9 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_track_counts",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_batch_export_table",
+                    "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
+                    "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
 
 
@@ -327,18 +347,41 @@ class Ctx:
         self._chk(self.lib.scvod_cluster(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)))
         return out[:a.shape[0]]
 
-    def batch_track(self, d_members, cluster_begin, pair_cluster_begin, T, stream=None, sync=True):
-        cb, pcb = self._i32(cluster_begin)
-        pb, ppb = self._i32(pair_cluster_begin)
+    def batch_track(self, T, next_scan=None, ext_tables=None, stream=None, sync=True):
+        """T [n_scans, 12] (row s: delta of scan s to its successor); next_scan [n_scans] or None (s + 1);
+        ext_tables: list of torch device tensors written by batch_export_table on another shard."""
         t, pt = self._f32(T)
-        self._n_track_clusters = cb.shape[0] - 1
-        self._chk(self.lib.scvod_batch_track(self.h, C.c_void_p(d_members.data_ptr()), pcb, self._n_track_clusters, ppb,
-                                             pt, C.c_void_p(stream or 0), int(sync)))
+        assert t.size == 12 * self._n_scans, "one 3x4 transform per scan"
+        pn = None
+        if next_scan is not None:
+            nx, pn = self._i32(next_scan)
+            assert nx.shape[0] == self._n_scans
+        n_ext = len(ext_tables) if ext_tables else 0
+        ptrs = (C.c_void_p * max(n_ext, 1))(*[C.c_void_p(e.data_ptr()) for e in (ext_tables or [])])
+        self._ext_keep = ext_tables  # the device buffers must outlive the asynchronous launch
+        self._chk(self.lib.scvod_batch_track(self.h, pt, pn, ptrs if n_ext else None, n_ext, C.c_void_p(stream or 0), int(sync)))
 
-    def batch_track_counts(self):
-        out = np.zeros(max(self._n_track_clusters, 1), np.int32)
-        self._chk(self.lib.scvod_batch_track_counts(self.h, out.ctypes.data_as(C.c_void_p), self._n_track_clusters))
-        return out[:self._n_track_clusters]
+    def batch_fetch_track(self, s):
+        r = TrackResult()
+        self._chk(self.lib.scvod_batch_fetch_track(self.h, int(s), C.byref(r)))
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32 if dt == np.int32 else C.c_uint8)), shape=(n,)).copy()
+        ncl = r.n_clusters
+        pb = arr(r.pair_begin, ncl + 1, np.int32)
+        npair = int(pb[-1]) if ncl else 0
+        return dict(n_apri=r.n_apri, n_clusters=ncl, n_car_points=r.n_car_points, n_dynamic_clusters=r.n_dynamic_clusters,
+                    n_dynamic_points=r.n_dynamic_points, cluster_root=arr(r.cluster_root, ncl, np.int32),
+                    cluster_size=arr(r.cluster_size, ncl, np.int32), cluster_state=arr(r.cluster_state, ncl, np.int32),
+                    n_unique=arr(r.n_unique, ncl, np.int32), pair_begin=pb, pair_label=arr(r.pair_label, npair, np.int32),
+                    pair_count=arr(r.pair_count, npair, np.int32), pt_dyn=arr(r.pt_dyn, r.n_apri, np.uint8))
+
+    def batch_export_table(self, s, d_out, stream=None):
+        """d_out: torch int32 device tensor [cap_records, 4]"""
+        self._chk(self.lib.scvod_batch_export_table(self.h, int(s), C.c_void_p(d_out.data_ptr()), int(d_out.shape[0]),
+                                                    C.c_void_p(stream or 0)))
 
     def set_timing(self, on):
         self._chk(self.lib.scvod_set_timing(self.h, int(bool(on))))
@@ -400,3 +443,72 @@ class Ctx:
         self._chk(self.lib.scvod_nn_search(self.h, pm, m.shape[0], pq, nq, float(radius), idx.ctypes.data_as(C.c_void_p),
                                            sq.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
         return idx[:nq], sq[:nq], w[:nq]
+
+
+MAP_NO_GROUND, MAP_NO_REJECTED, MAP_IGNORE_DYNAMIC = 1, 2, 4
+
+
+class StaticMap:
+    """World-frame static map (include/scvod.h, scvod_map_*): device-resident set of occupied cells, mergeable across shards."""
+
+    def __init__(self, capacity_cells, leaf=0.2, device=0):
+        self.lib = load_lib()
+        h = C.c_void_p()
+        rc = self.lib.scvod_map_create(int(device), int(capacity_cells), float(leaf), C.byref(h))
+        if rc != 0:
+            raise ScvodError(f"scvod_map_create failed with status {rc}")
+        self.h = h
+        self.leaf = float(leaf)
+        self.device = int(device)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ScvodError(f"status {rc}: {self.lib.scvod_map_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.scvod_map_destroy(self.h)
+            self.h = None
+
+    def clear(self, stream=None):
+        self._chk(self.lib.scvod_map_clear(self.h, C.c_void_p(stream or 0)))
+
+    def accumulate(self, ctx, poses, flags=0, stream=None):
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        assert p.shape[0] == ctx._n_scans
+        self._chk(self.lib.scvod_batch_map_accumulate(ctx.h, self.h, p.ctypes.data_as(C.c_void_p), int(flags), C.c_void_p(stream or 0)))
+
+    def count(self, stream=None):
+        n = C.c_int64()
+        self._chk(self.lib.scvod_map_export(self.h, None, 0, C.byref(n), C.c_void_p(stream or 0)))
+        return int(n.value)
+
+    def export(self, d_records=None, stream=None):
+        """records as a torch int64 device tensor [n, 2] (cell key, packed point); unspecified order"""
+        import torch
+        if d_records is None:
+            d_records = torch.empty((max(self.count(stream), 1), 2), dtype=torch.int64, device=torch.device("cuda", self.device))
+        n = C.c_int64()
+        self._chk(self.lib.scvod_map_export(self.h, C.c_void_p(d_records.data_ptr()), int(d_records.shape[0]), C.byref(n), C.c_void_p(stream or 0)))
+        return d_records[:int(n.value)]
+
+    def merge(self, d_records, stream=None):
+        self._chk(self.lib.scvod_map_merge(self.h, C.c_void_p(d_records.data_ptr()), int(d_records.shape[0]), C.c_void_p(stream or 0)))
+
+    def points(self, stream=None):
+        """(xyzi float32 [n, 4], records int64 [n, 2]) device tensors, same (unspecified) order"""
+        import torch
+        n0 = max(self.count(stream), 1)
+        dev = torch.device("cuda", self.device)
+        xyzi = torch.empty((n0, 4), dtype=torch.float32, device=dev)
+        rec = torch.empty((n0, 2), dtype=torch.int64, device=dev)
+        n = C.c_int64()
+        self._chk(self.lib.scvod_map_points(self.h, C.c_void_p(xyzi.data_ptr()), C.c_void_p(rec.data_ptr()), n0, C.byref(n), C.c_void_p(stream or 0)))
+        return xyzi[:int(n.value)], rec[:int(n.value)]
+
+
+def pose_matrix(pose):
+    p = np.ascontiguousarray(pose, np.float32)
+    t = np.zeros(12, np.float32)
+    load_lib().scvod_pose_matrix(p.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+    return t

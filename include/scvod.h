@@ -248,17 +248,55 @@ int scvod_batch_counts(scvod_ctx* ctx, int32_t* h_out);
 /* Download the full result of scan `s` of the last batch. */
 int scvod_batch_fetch(scvod_ctx* ctx, int32_t s, scvod_scan_result* out);
 
-/* Scan-vs-next-scan probe over every consecutive pair (s, s+1) of the last batch, device
- * resident.  Cluster c of pair s is the apri points of scan s listed in
- * d_members[h_cluster_begin[c] .. h_cluster_begin[c+1]) (indices into scan s's apri_vec);
- * h_pair_cluster_begin[n_scans] gives the first cluster of each pair (last entry = total).
- * h_T: [n_scans-1][12].  Labels of the next table are taken as "!= -1" for every voxel
- * (the freshly segmented state).  Results stay on the device; counts are returned by
- * scvod_batch_track_counts: out[n_clusters] = number of unique voxels hit. */
-int scvod_batch_track(scvod_ctx* ctx, const int32_t* d_members, const int32_t* h_cluster_begin,
-                      int32_t n_clusters, const int32_t* h_pair_cluster_begin, const float* h_T,
-                      void* stream, int32_t sync);
-int scvod_batch_track_counts(scvod_ctx* ctx, int32_t* h_out_unique, int32_t n_clusters);
+/* Scan-vs-next-scan differencing of the whole batch on the device: SSC::tracking (src/ssc.cpp:1250-1426) for every scan
+ * against its successor, the way SSC::segDF drives it (src/ssc.cpp:1449-1451).  Needs scvod_batch_cluster and
+ * scvod_batch_cluster_types of the same batch: the clusters walked are those whose type is `car` (ssc.cpp:1262), the
+ * successor's Voxel::label is the cluster of the voxel's points, -1 where refineClusterByBoundingBox erased it
+ * (ssc.cpp:461-466), Cluster::occupy_voxels.size() the number of voxels carrying a label (ssc.cpp:382-392).
+ *   h_T          [n_scans][12]  trans_next^-1 * trans_pre of (s, successor) (scvod_pose_delta); unused rows ignored
+ *   h_next_scan  [n_scans] or NULL: successor of scan s -- an index of the batch, -1 = none (last scan of a sequence),
+ *                -2 - e = the external table e.  NULL: s + 1, none for the last scan.
+ *   h_ext_tables [n_ext] device pointers to tables written by scvod_batch_export_table on ANOTHER shard (the first scan of
+ *                the next block of the sequence): how a block's last scan is tracked across a shard boundary.
+ * Per cluster: the transformed points are re-binned without range/FOV rejection (ssc.cpp:1280-1286) and looked up in the
+ * successor's table; hits are grouped by label and de-duplicated (remap_name, ssc.cpp:1304-1321); Cluster::state follows
+ * ssc.cpp:1323-1397 with the successor in its freshly segmented state (FIRST-ORDER decision: the re-labelling a previous
+ * pair would have applied to the successor, ssc.cpp:1354-1372 / 1399-1419, is not replayed; SSC::tracking of the host
+ * facade does that sequential bookkeeping on top of scvod_track_probe).  Per apri point a SCVOD_DYN_* byte.
+ * No host synchronisation inside the call; h_T / h_next_scan / h_ext_tables are copied (and re-uploaded only when they
+ * differ from the previous call). */
+#define SCVOD_DYN_STATIC 0      /* member of a cluster that is not dynamic                                        */
+#define SCVOD_DYN_DYNAMIC 1     /* member of a `car` cluster with state == 1                                      */
+#define SCVOD_DYN_UNCLUSTERED 2 /* its cluster was erased by the bounding-box refine (listed static, ssc.cpp:450-454) */
+int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_scan, const void* const* h_ext_tables,
+                      int32_t n_ext, void* stream, int32_t sync);
+
+/* Tracking result of scan `s` of the last scvod_batch_track.  Pointers are host memory owned by the ctx, valid until the
+ * next fetch.  Clusters are the `car` clusters of the scan in ascending canonical name (smallest apri index). */
+typedef struct scvod_track_result {
+    int32_t n_apri;
+    int32_t n_clusters;
+    int32_t n_car_points;
+    int32_t n_dynamic_clusters;
+    int32_t n_dynamic_points;
+    int32_t reserved;
+    const int32_t* cluster_root;  /* [n_clusters] canonical cluster name                                  */
+    const int32_t* cluster_size;  /* [n_clusters] |occupy_pts|                                            */
+    const int32_t* cluster_state; /* [n_clusters] Cluster::state: -1 untouched, 0 static, 1 dynamic       */
+    const int32_t* n_unique;      /* [n_clusters] unique labelled voxels of the successor under the cluster */
+    const int32_t* pair_begin;    /* [n_clusters+1] offsets into pair_label / pair_count                   */
+    const int32_t* pair_label;    /* remap_name keys (canonical names in the successor), ascending         */
+    const int32_t* pair_count;    /* remap_name[label].size() after sampleVec                              */
+    const uint8_t* pt_dyn;        /* [n_apri] SCVOD_DYN_*                                                  */
+} scvod_track_result;
+int scvod_batch_fetch_track(scvod_ctx* ctx, int32_t s, scvod_track_result* out);
+
+/* Boundary message of a sequence shard: writes 1 + n_voxels records of 16 bytes into d_out (device memory, capacity
+ * cap_records): record 0 = {records that follow, n_voxels, 0, 0}, then per voxel of scan `s` in ascending key
+ * {key, label, |occupy_voxels| of the label's cluster, its type (0 erased, 1 other, 2 car)}.  Asynchronous on `stream`.
+ * The shard that owns the PREVIOUS scan of the sequence passes the buffer (after a device-to-device / RCCL transfer) as
+ * an external table to scvod_batch_track. */
+int scvod_batch_export_table(scvod_ctx* ctx, int32_t s, void* d_out, int64_t cap_records, void* stream);
 
 /* Curved-voxel clustering of the last batch (SSC::clusterAndCreateFrame, src/ssc.cpp:299-352):
  * connected components of apri points under the reference's 3x3x3 occupied-voxel neighbourhood (grid
@@ -303,6 +341,34 @@ int scvod_nn_search(scvod_ctx* ctx, const float* h_map_xyz, int32_t n_map,
 int scvod_nn_search_device(scvod_ctx* ctx, const float* d_map_xyz, int32_t n_map,
                            const float* d_query_xyz, int32_t n_query, float radius,
                            int32_t* d_nn_idx, float* d_nn_sqdist, uint8_t* d_within, void* stream);
+
+/* ---- world-frame static map of a sequence, mergeable across shards -------------------------------------------------
+ * Reference analogue: `*instance_map += *rgb_ptr` over the clusters that are not dynamic (SSC::saveSegCloud mode 3,
+ * src/ssc.cpp:477-554) plus the ground clouds and range/FOV rejects of the evaluation block (ssc.cpp:1460-1480), each scan
+ * moved to the world by pcl::getTransformation(pose) (ssc.cpp:1455-1458).  Kept as a set of occupied cells of edge `leaf`
+ * with ONE representative point per cell chosen by an order-independent rule (smallest packed in-cell offset), so that
+ * shards can accumulate independently and merge their record lists (the payload of the RCCL all_gather) into
+ * bit-identical maps. */
+typedef struct scvod_map scvod_map;
+#define SCVOD_MAP_NO_GROUND 1       /* leave cloud_out (ground) out                                  */
+#define SCVOD_MAP_NO_REJECTED 2     /* leave cloud_eva_static (range/FOV rejects) out                 */
+#define SCVOD_MAP_IGNORE_DYNAMIC 4  /* raw map: keep the points scvod_batch_track marked dynamic too  */
+int scvod_map_create(int device, int64_t capacity_cells, float leaf, scvod_map** out);
+void scvod_map_destroy(scvod_map* map);
+const char* scvod_map_last_error(const scvod_map* map);
+int64_t scvod_map_capacity(const scvod_map* map);
+int scvod_map_clear(scvod_map* map, void* stream);
+/* pcl::getTransformation(x, y, z, roll, pitch, yaw) as a row-major 3x4 matrix */
+void scvod_pose_matrix(const float pose[6], float T_out[12]);
+/* adds the static points of every scan of ctx's last batch: h_poses [n_scans][6].  Asynchronous on `stream`. */
+int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* map, const float* h_poses, int32_t flags, void* stream);
+/* occupied cells as 16-byte records {uint64 cell key, uint64 packed point} into device memory (NULL: count only);
+ * *n_out = number of cells.  Synchronises `stream`.  Record order is unspecified (sort by key for a canonical order). */
+int scvod_map_export(scvod_map* map, void* d_records, int64_t cap_records, int64_t* n_out, void* stream);
+/* inserts records exported by another shard (a record with key ~0 is padding and skipped).  Asynchronous. */
+int scvod_map_merge(scvod_map* map, const void* d_records, int64_t n, void* stream);
+/* the map as points: d_xyzi [cap][4] floats (cell origin + stored offset, intensity), optionally the records beside them */
+int scvod_map_points(scvod_map* map, void* d_xyzi, void* d_records, int64_t cap, int64_t* n_out, void* stream);
 
 #ifdef __cplusplus
 }

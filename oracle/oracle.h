@@ -57,6 +57,15 @@ int oracle_toy_tracking(const scvod_params* params, const scvod_apri* apri_a, in
                         const float pose_a[6], const float pose_b[6], int32_t car, int32_t tree, int32_t* states, int32_t* n_states,
                         int32_t* next_labels, int32_t* n_next_vox, int32_t* dynamic_num, int32_t* n_next_clusters);
 
+/* one pair, successor freshly segmented (first-order decision of ssc.cpp:1323-1397); see tracking_oracle.cpp */
+int oracle_track_decide(const scvod_params* params, const scvod_apri* apri_a, int32_t n_a, const int32_t* cl_a, const int32_t* ty_a,
+                        const scvod_apri* apri_b, int32_t n_b, const int32_t* cl_b, const int32_t* ty_b, const float T[12], int32_t car,
+                        int32_t* out_clusters, int32_t* n_clusters, int32_t* pair_begin, int32_t* pairs);
+/* SSC::segDF's tracking loop over a segmented sequence: chain = 1 the reference's sequential re-labelling, 0 first-order */
+int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
+                             const int32_t* pt_cluster, const int32_t* pt_type, const float* poses, int32_t car, int32_t chain,
+                             uint8_t* pt_dyn, int32_t* dynamic_clusters);
+
 /* brute-force nearest neighbour / radius test (src/evaluate.cpp:79-145 analogue) */
 int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz, int32_t n_query, float radius,
                      int32_t* nn_idx, float* nn_sqdist, uint8_t* within);

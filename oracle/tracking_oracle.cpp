@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -204,6 +205,79 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
     return dynamic_num;
 }
 
+
+// frame with an explicit segmentation: pt_cluster = name per apri point, pt_type = Cluster::type or -1 for points whose
+// cluster refineClusterByBoundingBox erased (ssc.cpp:437-467: erased clusters leave cluster_set, their voxels get label -1).
+// Voxel::label = cluster of the voxel's points (clusterAndCreateFrame, ssc.cpp:388-392); occupy_voxels = sampleVec of the
+// members' voxel_idx (ssc.cpp:382-384).  A voxel whose points sit in different clusters (possible only through index
+// aliasing of the -1 bins) takes the label of its first point here; the reference's own choice depends on unordered_map
+// iteration order.
+void build_frame_seg(const scvod_params& P, const scvod_apri* apri, int n, const int32_t* pt_cluster, const int32_t* pt_type, FrameT& f) {
+    build_frame(P, apri, n, f);
+    f.cluster_set.clear();
+    int max_name = 4;
+    for (auto& kv : f.hash_cloud) {
+        const int first = kv.second.ptIdx.front();
+        kv.second.label = pt_type[first] == -1 ? -1 : pt_cluster[first];
+    }
+    for (int i = 0; i < n; ++i) {
+        if (pt_type[i] == -1) continue;
+        ClusterT& c = f.cluster_set[pt_cluster[i]];
+        if (c.name == -1) {
+            c.name = pt_cluster[i];
+            c.type = pt_type[i];
+            if (c.name > max_name) max_name = c.name;
+        }
+        c.occupy_pts.push_back(i);
+        c.occupy_voxels.push_back(apri[i].voxel_idx);
+        c.cloud.push_back(f.cloud_use[i]);
+    }
+    for (auto& kv : f.cluster_set) sampleVec(kv.second.occupy_voxels);
+    f.max_name = max_name + 1;
+}
+
+void dyn_of_frame(const FrameT& f, int n, const int32_t* pt_type, uint8_t* dyn) {
+    for (int i = 0; i < n; ++i) dyn[i] = pt_type[i] == -1 ? 2 : 0;  // 2: in no cluster
+    for (auto& kv : f.cluster_set)
+        if (kv.second.state == 1)  // saveSegCloud, ssc.cpp:479-481: dynamic_pt = occupy_pts of the clusters with state == 1
+            for (int p : kv.second.occupy_pts) dyn[p] = 1;
+}
+
+// ssc.cpp:1274-1397 for ONE cluster against an untouched successor: remap_name (ordered map: only the iteration order of
+// the output differs from the reference's unordered_map) and the state the reference would assign; nothing is mutated.
+int decide_independent(const scvod_params& P, int R, int S, const ClusterT& c, FrameT& fb, const float T[12], int car,
+                       std::map<int, std::vector<int>>& remap_name) {
+    for (const P3& in : c.cloud) {
+        P3 pt;
+        pt.x = T[0] * in.x + T[1] * in.y + T[2] * in.z + T[3];  // transformCloud, utility.h:400-405
+        pt.y = T[4] * in.x + T[5] * in.y + T[6] * in.z + T[7];
+        pt.z = T[8] * in.x + T[9] * in.y + T[10] * in.z + T[11];
+        float dis = pointDistance2d(pt);
+        float angle = getPolarAngle(pt);
+        float azimuth = getAzimuth(pt);
+        int range_idx = std::ceil((dis - P.min_dis) / P.range_res) - 1;
+        int sector_idx = std::ceil((angle - P.min_angle) / P.sector_res) - 1;
+        int azimuth_idx = std::ceil((azimuth - P.min_azimuth) / P.azimuth_res) - 1;
+        int voxel_idx = azimuth_idx * R * S + range_idx * S + sector_idx;
+        auto it_find = fb.hash_cloud.find(voxel_idx);
+        if (it_find != fb.hash_cloud.end() && it_find->second.label != -1) remap_name[it_find->second.label].emplace_back(it_find->first);
+    }
+    for (auto& re : remap_name) sampleVec(re.second);
+    int state = -1;
+    if (remap_name.size() == 0) {
+        state = 1;
+    } else if (remap_name.size() == 1) {
+        auto it = remap_name.begin();
+        float ratio = (float)it->second.size() / (float)fb.cluster_set[it->first].occupy_voxels.size();
+        if (ratio < P.occupancy)
+            state = (fb.cluster_set[it->first].type == car) ? 1 : 0;
+        else if (fb.cluster_set[it->first].type == car)
+            state = 0;
+    } else {
+        state = 0;
+    }
+    return state;
+}
 }  // namespace
 
 extern "C" {
@@ -242,6 +316,88 @@ int oracle_toy_tracking(const scvod_params* params, const scvod_apri* apri_a, in
     *n_next_vox = (int)keys.size();
     *dynamic_num = dyn;
     *n_next_clusters = (int)fb.cluster_set.size();
+    return 0;
+}
+
+
+// SSC::tracking of ONE pair with the successor in its freshly segmented state (first-order decision: what the device's
+// scvod_batch_track computes).  Per `car` cluster of frame a in ascending name: out_clusters[k] = {name, state, unique
+// labelled voxels hit, remap_name.size()}; pairs: for cluster k, pair_begin[k] .. pair_begin[k+1]: {label, |hits|} in
+// ascending label.  No re-labelling is applied to b (the decisions of ssc.cpp:1323-1397 are read off, the bookkeeping of
+// :1354-1372 / :1399-1419 is skipped).
+int oracle_track_decide(const scvod_params* params, const scvod_apri* apri_a, int32_t n_a, const int32_t* cl_a, const int32_t* ty_a,
+                        const scvod_apri* apri_b, int32_t n_b, const int32_t* cl_b, const int32_t* ty_b, const float T[12], int32_t car,
+                        int32_t* out_clusters, int32_t* n_clusters, int32_t* pair_begin, int32_t* pairs) {
+    const scvod_params& P = *params;
+    FrameT fa, fb;
+    build_frame_seg(P, apri_a, n_a, cl_a, ty_a, fa);
+    build_frame_seg(P, apri_b, n_b, cl_b, ty_b, fb);
+    int32_t R, S, A, bins;
+    oracle_grid_dims(&P, &R, &S, &A, &bins);
+    std::vector<int> names;
+    for (auto& kv : fa.cluster_set)
+        if (kv.second.type == car) names.push_back(kv.first);
+    std::sort(names.begin(), names.end());
+    int k = 0, np = 0;
+    for (int nm : names) {
+        ClusterT& c = fa.cluster_set[nm];
+        std::map<int, std::vector<int>> remap_name;
+        const int state = decide_independent(P, R, S, c, fb, T, car, remap_name);
+        int uniq = 0;
+        for (auto& re : remap_name) uniq += (int)re.second.size();
+        out_clusters[4 * k] = nm;
+        out_clusters[4 * k + 1] = state;
+        out_clusters[4 * k + 2] = uniq;
+        out_clusters[4 * k + 3] = (int)remap_name.size();
+        pair_begin[k] = np;
+        for (auto& re : remap_name) {
+            pairs[2 * np] = re.first;
+            pairs[2 * np + 1] = (int)re.second.size();
+            ++np;
+        }
+        ++k;
+    }
+    pair_begin[k] = np;
+    *n_clusters = k;
+    return 0;
+}
+
+// SSC::segDF's tracking loop (ssc.cpp:1449-1451) over a sequence of segmented frames.  chain == 1: the reference's
+// semantics -- tracking(i, i + 1) re-labels / splits / fuses the clusters of frame i + 1 before tracking(i + 1, i + 2) walks
+// them, cluster_set iterated in the container's order.  chain == 0: every pair against a freshly segmented successor
+// (the clusters of one pair still see each other's re-labelling).  chain == 2: every cluster on its own against the
+// untouched successor (first-order; the device path).  pt_dyn per apri point: 1 = member of a cluster with state == 1 after the loop
+// (saveSegCloud's dynamic_pt, ssc.cpp:479-481), 2 = in no cluster, 0 otherwise.
+int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
+                             const int32_t* pt_cluster, const int32_t* pt_type, const float* poses, int32_t car, int32_t chain,
+                             uint8_t* pt_dyn, int32_t* dynamic_clusters) {
+    const scvod_params& P = *params;
+    std::vector<FrameT> frames(n_scans);
+    for (int s = 0; s < n_scans; ++s)
+        build_frame_seg(P, apri + offs[s], offs[s + 1] - offs[s], pt_cluster + offs[s], pt_type + offs[s], frames[s]);
+    int name = 0, dyn = 0;
+    for (int i = 0; i + 1 < n_scans; ++i) {
+        if (chain == 2) {  // every cluster on its own against the untouched successor (what the device computes)
+            int32_t R, S, A, bins;
+            oracle_grid_dims(&P, &R, &S, &A, &bins);
+            float T[12];
+            oracle_pose_delta(poses + 6 * i, poses + 6 * (i + 1), T);
+            for (auto& kv : frames[i].cluster_set) {
+                if (kv.second.type != car) continue;
+                std::map<int, std::vector<int>> remap_name;
+                kv.second.state = decide_independent(P, R, S, kv.second, frames[i + 1], T, car, remap_name);
+                dyn += kv.second.state == 1;
+            }
+        } else if (chain) {
+            dyn += tracking(P, frames[i], frames[i + 1], poses + 6 * i, poses + 6 * (i + 1), car, name);
+        } else {
+            FrameT fresh;
+            build_frame_seg(P, apri + offs[i + 1], offs[i + 2] - offs[i + 1], pt_cluster + offs[i + 1], pt_type + offs[i + 1], fresh);
+            dyn += tracking(P, frames[i], fresh, poses + 6 * i, poses + 6 * (i + 1), car, name);
+        }
+    }
+    for (int s = 0; s < n_scans; ++s) dyn_of_frame(frames[s], offs[s + 1] - offs[s], pt_type + offs[s], pt_dyn + offs[s]);
+    if (dynamic_clusters) *dynamic_clusters = dyn;
     return 0;
 }
 

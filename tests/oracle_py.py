@@ -170,3 +170,28 @@ class Oracle:
         cs = C.c_int64()
         self.lib.oracle_time_process(C.byref(params), _p(a), _p(o), o.shape[0] - 1, st, C.byref(cs))
         return [st[0], st[1], st[2]], cs.value
+
+    def track_decide(self, params, apri_a, cl_a, ty_a, apri_b, cl_b, ty_b, T, car=2):
+        a, b = np.ascontiguousarray(apri_a), np.ascontiguousarray(apri_b)
+        ca, ta = np.ascontiguousarray(cl_a, np.int32), np.ascontiguousarray(ty_a, np.int32)
+        cb, tb = np.ascontiguousarray(cl_b, np.int32), np.ascontiguousarray(ty_b, np.int32)
+        t = np.ascontiguousarray(T, np.float32)
+        out = np.zeros((max(len(a), 1), 4), np.int32)
+        pb = np.zeros(len(a) + 1, np.int32)
+        pairs = np.zeros((max(len(a), 1), 2), np.int32)
+        n = C.c_int32()
+        self.lib.oracle_track_decide(C.byref(params), _p(a), len(a), _p(ca), _p(ta), _p(b), len(b), _p(cb), _p(tb), _p(t), car,
+                                     _p(out), C.byref(n), _p(pb), _p(pairs))
+        k = n.value
+        return dict(clusters=out[:k], pair_begin=pb[:k + 1], pairs=pairs[:pb[k]])
+
+    def sequence_tracking(self, params, apri, offs, pt_cluster, pt_type, poses, car=2, chain=1):
+        a = np.ascontiguousarray(apri)
+        o = np.ascontiguousarray(offs, np.int32)
+        cl, ty = np.ascontiguousarray(pt_cluster, np.int32), np.ascontiguousarray(pt_type, np.int32)
+        ps = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        dyn = np.zeros(max(len(a), 1), np.uint8)
+        nd = C.c_int32()
+        self.lib.oracle_sequence_tracking(C.byref(params), _p(a), _p(o), len(o) - 1, _p(cl), _p(ty), _p(ps), car, int(chain),
+                                          _p(dyn), C.byref(nd))
+        return dyn[:len(a)], nd.value

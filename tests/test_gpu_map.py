@@ -1,0 +1,161 @@
+"""World-frame static map (scvod_map_*, csrc/scvod_map.hip): the device hash grid against a numpy restatement of its
+definition, and the property the multi-GPU reduce relies on: shards that accumulate independently and merge their
+record lists give the bit-identical map of a single shard."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracked_batch(scvod, P, kind, seq, first, count):
+    import synth
+    pts, offs, poses, _ = synth.make_batch(seq, first, count, kind)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    d = pts.cuda()
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    return ctx, d, pts.numpy(), offs, poses
+
+
+def _numpy_map(scvod, ctx, x, offs, poses, leaf, use_dyn=True, ground=True, rejected=True):
+    """definition of the map: per static point the cell key and the packed in-cell offset, per cell the smallest"""
+    keys, vals = [], []
+    inv = np.float32(1.0) / np.float32(leaf)
+    for s in range(len(offs) - 1):
+        r = ctx.batch_fetch(s)
+        t = ctx.batch_fetch_track(s)
+        keep = t["pt_dyn"] != 1 if use_dyn else np.ones(r["n_apri"], bool)
+        src = [r["apri_src"][keep]]
+        if ground:
+            src.append(r["ground_idx"])
+        if rejected:
+            src.append(r["rejected_src"])
+        p = x[offs[s]:offs[s + 1]][np.concatenate(src)]
+        T = scvod.pose_matrix(poses[s])
+        w = [((T[4 * i] * p[:, 0] + T[4 * i + 1] * p[:, 1]) + T[4 * i + 2] * p[:, 2]) + T[4 * i + 3] for i in range(3)]
+        f = [c * inv for c in w]
+        c = [np.floor(v) for v in f]
+        u = [(ci.astype(np.int64) + (1 << 20)).astype(np.uint64) for ci in c]
+        key = (u[0] << np.uint64(42)) | (u[1] << np.uint64(21)) | u[2]
+        q = [np.clip(((fi - ci) * np.float32(65536.0)).astype(np.int64), 0, 65535).astype(np.uint64) for fi, ci in zip(f, c)]
+        qi = np.clip(p[:, 3] * np.float32(256.0), 0, 65535).astype(np.int64).astype(np.uint64)
+        keys.append(key)
+        vals.append((q[0] << np.uint64(48)) | (q[1] << np.uint64(32)) | (q[2] << np.uint64(16)) | qi)
+    key, val = np.concatenate(keys), np.concatenate(vals)
+    order = np.lexsort((val, key))
+    key, val = key[order], val[order]
+    first = np.ones(len(key), bool)
+    first[1:] = key[1:] != key[:-1]
+    return key[first], val[first]
+
+
+def _sorted_records(m):
+    rec = m.export().cpu().numpy().view(np.uint64)
+    o = np.argsort(rec[:, 0])
+    return rec[o, 0], rec[o, 1]
+
+
+@pytest.mark.parametrize("kind,preset", [("K64", "semantickitti"), ("PARK", "parkinglot")])
+def test_map_matches_its_definition(scvod, kind, preset):
+    P = scvod.make_params(preset)
+    count = 5
+    ctx, d, x, offs, poses = _tracked_batch(scvod, P, kind, 5, 640, count)
+    m = scvod.StaticMap(1 << 21, leaf=0.2)
+    m.accumulate(ctx, poses)
+    k, v = _sorted_records(m)
+    ek, ev = _numpy_map(scvod, ctx, x, offs, poses, 0.2)
+    assert np.array_equal(k, ek) and np.array_equal(v, ev)
+    assert m.count() == len(ek)
+    # the points handed out sit inside their cell, in the record order
+    xyzi, rec = m.points()
+    xyzi, rec = xyzi.cpu().numpy(), rec.cpu().numpy().view(np.uint64)
+    cx = (rec[:, 0] >> np.uint64(42)).astype(np.int64) - (1 << 20)
+    assert (np.floor(xyzi[:, 0] / np.float32(0.2) + 1e-3) >= cx - 1).all() and (np.abs(xyzi[:, 0] - (cx + 0.5) * 0.2) <= 0.1001).all()
+    # accumulating the same batch again changes nothing (idempotent union); the raw map is a superset; flags drop lists
+    m.accumulate(ctx, poses)
+    k2, v2 = _sorted_records(m)
+    assert np.array_equal(k, k2) and np.array_equal(v, v2)
+    raw = scvod.StaticMap(1 << 21, leaf=0.2)
+    raw.accumulate(ctx, poses, flags=scvod.MAP_IGNORE_DYNAMIC)
+    rk, _ = _sorted_records(raw)
+    assert len(rk) >= len(k) and np.isin(k, rk).all()
+    raw.clear()
+    raw.accumulate(ctx, poses, flags=scvod.MAP_NO_GROUND | scvod.MAP_NO_REJECTED)
+    nk, nv = _sorted_records(raw)
+    ek2, ev2 = _numpy_map(scvod, ctx, x, offs, poses, 0.2, ground=False, rejected=False)
+    assert np.array_equal(nk, ek2) and np.array_equal(nv, ev2)
+    raw.close()
+    m.close()
+    ctx.close()
+
+
+def test_shards_merge_into_the_single_shard_map(scvod):
+    """two shards (the second one tracked on its own, its first scan exported to the first as the boundary table)
+    accumulate their scans into their own maps; merging the exported record lists reproduces the unsplit map bit for bit"""
+    import torch
+    P = scvod.make_params("semantickitti")
+    count, cut = 6, 3
+    ctx, d, x, offs, poses = _tracked_batch(scvod, P, "K64", 5, 2000, count)
+    whole = scvod.StaticMap(1 << 21)
+    whole.accumulate(ctx, poses)
+    wk, wv = _sorted_records(whole)
+    ctx.close()
+    T = np.zeros((count, 12), np.float32)
+    oa, ob = np.asarray(offs[:cut + 1], np.int32), (np.asarray(offs[cut:], np.int64) - offs[cut]).astype(np.int32)
+    ca = scvod.Ctx(P, max_points_total=int(oa[-1]) + 64, max_scans=cut)
+    cb = scvod.Ctx(P, max_points_total=int(ob[-1]) + 64, max_scans=count - cut)
+    for s in range(count - 1):
+        T[s] = ca.pose_delta(poses[s], poses[s + 1])
+    da, db = d[:offs[cut]].contiguous(), d[offs[cut]:].contiguous()
+    for c, dd, oo in ((ca, da, oa), (cb, db, ob)):
+        c.batch_process(dd, oo)
+        c.batch_cluster()
+        c.batch_cluster_types()
+    cb.batch_track(T[cut:])
+    msg = torch.zeros((1 << 16, 4), dtype=torch.int32, device="cuda")
+    cb.batch_export_table(0, msg)
+    ca.batch_track(T[:cut], next_scan=np.array([1, 2, -2], np.int32), ext_tables=[msg])
+    ma, mb = scvod.StaticMap(1 << 20), scvod.StaticMap(1 << 20)
+    ma.accumulate(ca, poses[:cut])
+    mb.accumulate(cb, poses[cut:])
+    ra, rb = ma.export(), mb.export()
+    # what the RCCL all_gather moves: equally sized, padded lists (key ~0 = padding)
+    cap = max(ra.shape[0], rb.shape[0]) + 7
+    pad = torch.full((2, cap, 2), -1, dtype=torch.int64, device="cuda")
+    pad[0, :ra.shape[0]] = ra
+    pad[1, :rb.shape[0]] = rb
+    merged = scvod.StaticMap(1 << 21)
+    merged.merge(pad.reshape(-1, 2))
+    mk, mv = _sorted_records(merged)
+    assert np.array_equal(mk, wk) and np.array_equal(mv, wv)
+    # a map that is too small reports it instead of silently dropping cells
+    tiny = scvod.StaticMap(1024)
+    tiny.merge(ra)
+    with pytest.raises(scvod.ScvodError):
+        tiny.count()
+    for o in (ma, mb, merged, whole, tiny):
+        o.close()
+    ca.close()
+    cb.close()
+
+
+def test_map_needs_a_tracked_batch(scvod):
+    import torch
+    P = scvod.make_params("semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=4096, max_scans=1)
+    m = scvod.StaticMap(4096)
+    pose = np.zeros((1, 6), np.float32)
+    import ctypes as C
+    assert m.lib.scvod_batch_map_accumulate(ctx.h, m.h, pose.ctypes.data_as(C.c_void_p), 0, None) == -5
+    d = torch.zeros((100, 4), device="cuda")
+    ctx.batch_process(d, [0, 100])
+    assert m.lib.scvod_batch_map_accumulate(ctx.h, m.h, pose.ctypes.data_as(C.c_void_p), 0, None) == -5   # no tracking result
+    assert m.lib.scvod_batch_map_accumulate(ctx.h, m.h, pose.ctypes.data_as(C.c_void_p), 4, None) == 0    # raw map is fine
+    assert m.count() == 0  # 100 points at the origin: r <= 2.7 m, dropped by Patchwork, in neither cloud
+    m.close()
+    ctx.close()

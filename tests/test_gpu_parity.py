@@ -1,5 +1,7 @@
 """GPU parity tests proper: the HIP path, driven through the C-ABI (libscvod.so), against the
 oracle on the same seeded inputs.  Bit-exact everywhere (integer indices AND descriptor floats)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -304,48 +306,125 @@ def test_track_probe_parity(scvod, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("fine", [False, True])
-def test_batch_track_matches_oracle_per_pair(scvod, oracle, fine):
-    """scvod_batch_track (device-resident sequence shard: points read through apri_src, next scan's keys staged in
-    LDS) must count, per cluster, exactly the unique next-scan voxels the oracle's per-pair probe finds.  `fine`: a grid
-    so fine that a scan has more voxels than the LDS key table holds (global-memory search path)."""
-    import torch
+def _segmented_batch(scvod, P, kind, seq, first, count):
+    """count consecutive scans through process -> cluster -> cluster types on the device; returns ctx + per-scan host copies"""
     import synth
-    P = scvod.make_params("semantickitti", range_res=0.05, sector_res=0.2, azimuth_res=0.25) if fine else _params(scvod, "semantickitti")
-    count = 4
-    pts, offs, poses, _ = synth.make_batch(5, 420, count, "K64")
+    pts, offs, poses, _ = synth.make_batch(seq, first, count, kind)
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
     d = pts.cuda()
     ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
     res = [ctx.batch_fetch(s) for s in range(count)]
-    assert (min(r["n_voxels"] for r in res) > 8192) == fine
-    members, cbegin, pbegin, per_pair = [], [0], [0], []
+    names = [ctx.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(count)]
+    types = [ctx.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(count)]
+    return ctx, d, offs, poses, res, names, types
+
+
+def _assert_track_equal(t, o):
+    assert np.array_equal(t["cluster_root"], o["clusters"][:, 0])
+    assert np.array_equal(t["cluster_state"], o["clusters"][:, 1])
+    assert np.array_equal(t["n_unique"], o["clusters"][:, 2])
+    assert np.array_equal(np.diff(t["pair_begin"]), o["clusters"][:, 3])
+    assert np.array_equal(t["pair_begin"], o["pair_begin"])
+    assert np.array_equal(t["pair_label"], o["pairs"][:, 0])
+    assert np.array_equal(t["pair_count"], o["pairs"][:, 1])
+
+
+@pytest.mark.parametrize("kind,preset,seq,first", [("K64", "semantickitti", 5, 420), ("PARK", "parkinglot", 3, 30),
+                                                   ("OS128", "os128_fine", 5, 700), ("K64", "fine", 5, 1200)])
+def test_batch_track_decision_parity(scvod, oracle, kind, preset, seq, first):
+    """scvod_batch_track (SSC::tracking for every scan against its successor, all on the device: labels and types of the
+    resident clustering, member lists, probe, remap_name, state rule, per-point byte) against the oracle's per-pair
+    restatement of ssc.cpp:1274-1397 on 8 consecutive pairs.  `fine`: more voxels per scan than the LDS sample table holds
+    (two-level look-up)."""
+    if preset == "fine":
+        P = scvod.make_params("semantickitti", range_res=0.05, sector_res=0.2, azimuth_res=0.25)
+    else:
+        P = _params(scvod, preset)
+    count = 9 if kind != "OS128" else 5
+    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, kind, seq, first, count)
+    if preset == "fine":
+        assert min(r["n_voxels"] for r in res) > 8192
+    T = np.zeros((count, 12), np.float32)
     for s in range(count - 1):
-        n_a = res[s]["n_apri"]
-        m = np.arange(s % 3, n_a, 3, dtype=np.int32)      # every third apri point, ragged cluster sizes
-        sizes = [37, 500, 1, 1200, 64]
-        k, i, mine = 0, 0, [0]
-        while k < len(m):
-            sz = min(sizes[i % len(sizes)], len(m) - k)
-            k += sz
-            i += 1
-            mine.append(k)
-            cbegin.append(cbegin[-1] + sz)
-        members.append(m)
-        pbegin.append(len(cbegin) - 1)
-        per_pair.append((m, np.asarray(mine, np.int32)))
-    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)])
-    ctx.batch_track(torch.from_numpy(np.concatenate(members)).cuda(), cbegin, pbegin, T)
-    uq = ctx.batch_track_counts()
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    tr = [ctx.batch_fetch_track(s) for s in range(count)]
+    n_dyn = n_stat = n_multi = 0
     for s in range(count - 1):
-        m, o = per_pair[s]
-        a = res[s]["apri"]
-        xyzi = np.stack([a["x"][m], a["y"][m], a["z"][m], a["intensity"][m]], 1).astype(np.float32)
-        keys = res[s + 1]["vox_key"]
-        _, _, oub = oracle.track_probe(P, xyzi, o, T[s], keys, np.zeros(len(keys), np.int32))
-        assert np.array_equal(uq[pbegin[s]:pbegin[s + 1]], np.diff(oub)), f"pair {s}"
-    assert uq.sum() > 0
+        o = oracle.track_decide(P, res[s]["apri"], names[s], types[s], res[s + 1]["apri"], names[s + 1], types[s + 1], T[s])
+        _assert_track_equal(tr[s], o)
+        assert tr[s]["n_clusters"] == len(o["clusters"]) and tr[s]["n_car_points"] == int((types[s] == 2).sum())
+        n_dyn += int((o["clusters"][:, 1] == 1).sum())
+        n_stat += int((o["clusters"][:, 1] == 0).sum())
+        n_multi += int((o["clusters"][:, 3] > 1).sum())
+        assert tr[s]["n_dynamic_clusters"] == int((o["clusters"][:, 1] == 1).sum())
+    assert n_dyn > 0 and n_stat > 0 and n_multi > 0, "the sample must exercise every branch of the state rule"
+    # the last scan has no successor: nothing is decided
+    assert (tr[-1]["cluster_state"] == -1).all() and not (tr[-1]["pt_dyn"] == 1).any()
+    # per-point bytes against the sequence-level oracle in its per-cluster (first-order) mode
+    apri = np.concatenate([r["apri"] for r in res])
+    ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
+    dyn, _ = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), np.asarray(poses, np.float32), chain=2)
+    assert np.array_equal(np.concatenate([t["pt_dyn"] for t in tr]), dyn)
     ctx.close()
+
+
+def test_batch_track_across_a_shard_boundary(scvod, oracle):
+    """A sequence cut into two shards: the last scan of shard A is tracked against the table shard B exports for its first
+    scan (scvod_batch_export_table -> external table of scvod_batch_track) and must give exactly what the unsplit batch
+    gives; a scan marked -1 (end of a sequence) in the middle of a batch decides nothing."""
+    import torch
+    import synth
+    P = _params(scvod, "semantickitti")
+    count, cut = 7, 4
+    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, "K64", 5, 860, count)
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    whole = [ctx.batch_fetch_track(s) for s in range(count)]
+    ctx.close()
+    # shard B: scans cut .. count-1
+    oa, ob = np.asarray(offs[:cut + 1], np.int32), (np.asarray(offs[cut:], np.int64) - offs[cut]).astype(np.int32)
+    cb = scvod.Ctx(P, max_points_total=int(ob[-1]) + 64, max_scans=count - cut)
+    db = d[offs[cut]:].contiguous()
+    cb.batch_process(db, ob)
+    cb.batch_cluster()
+    cb.batch_cluster_types()
+    cb.batch_track(T[cut:])
+    msg = torch.zeros((res[cut]["n_voxels"] + 1, 4), dtype=torch.int32, device="cuda")
+    cb.batch_export_table(0, msg)
+    torch.cuda.synchronize()
+    h = msg.cpu().numpy()
+    assert h[0, 0] == res[cut]["n_voxels"] and np.array_equal(h[1:, 0], res[cut]["vox_key"])
+    tb = [cb.batch_fetch_track(s) for s in range(count - cut)]
+    # shard A: scans 0 .. cut-1, its last scan against the message; scan 1 declared the end of a sequence
+    ca = scvod.Ctx(P, max_points_total=int(oa[-1]) + 64, max_scans=cut)
+    da = d[:offs[cut]].contiguous()
+    ca.batch_process(da, oa)
+    ca.batch_cluster()
+    ca.batch_cluster_types()
+    nxt = np.array([1, -1, 3, -2], np.int32)
+    ca.batch_track(T[:cut], next_scan=nxt, ext_tables=[msg])
+    ta = [ca.batch_fetch_track(s) for s in range(cut)]
+    for s in (0, 2, 3):
+        for k in ("cluster_root", "cluster_state", "n_unique", "pair_begin", "pair_label", "pair_count", "pt_dyn"):
+            assert np.array_equal(ta[s][k], whole[s][k]), (s, k)
+    assert (ta[1]["cluster_state"] == -1).all()
+    for s in range(count - cut):
+        for k in ("cluster_root", "cluster_state", "n_unique", "pair_label", "pair_count", "pt_dyn"):
+            assert np.array_equal(tb[s][k], whole[cut + s][k]), (s, k)
+    # error conventions: tracking needs the clustering of the same batch; successors must exist
+    ca.batch_process(da, oa)
+    assert ca.lib.scvod_batch_track(ca.h, T.ctypes.data_as(C.c_void_p), None, None, 0, None, 1) == -5
+    ca.batch_cluster()
+    ca.batch_cluster_types()
+    bad = np.array([1, 2, 9, -1], np.int32)
+    assert ca.lib.scvod_batch_track(ca.h, T.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p), None, 0, None, 1) == -1
+    ca.close()
+    cb.close()
 
 
 def test_nn_search_parity(scvod, oracle):

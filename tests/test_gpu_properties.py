@@ -75,25 +75,32 @@ def test_full_size_batches(scvod, kind, preset, count):
     xr = rev_pts.cpu().numpy()
     s = count - 1
     assert _invariants(ctx.batch_fetch(0), xr[rev_offs[0]:rev_offs[1]], grid) == sums[2]
-    # scan-vs-next-scan probe over the batch: every cluster's unique-hit count is bounded by its size and by
-    # the next scan's table, and a scan probed against ITSELF (identity transform) hits every own voxel
+    # scan-vs-next-scan differencing over the batch: per cluster the unique labelled voxels are bounded by its size and by
+    # the successor's table, the pair counts add up to them, dynamic points are car points; a batch tracked against
+    # ITSELF (identity transforms, next_scan[s] = s) finds every labelled own voxel: no cluster comes out dynamic
     ctx.batch_process(pts, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
     cnt = ctx.batch_counts()
-    members, cbegin, pbegin = [], [0], [0]
+    T = np.zeros((count, 12), np.float32)
     for s in range(count - 1):
-        m = np.arange(0, cnt[s, 4], 3, dtype=np.int32)
-        members.append(m)
-        for k in range(0, len(m), 500):
-            cbegin.append(cbegin[-1] + min(500, len(m) - k))
-        pbegin.append(len(cbegin) - 1)
-    mem = torch.from_numpy(np.concatenate(members)).cuda()
-    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)])
-    ctx.batch_track(mem, cbegin, pbegin, T)
-    uq = ctx.batch_track_counts()
-    sizes = np.diff(np.asarray(cbegin))
-    assert (uq <= sizes).all() and (uq >= 0).all() and uq.sum() > 0
-    for s in range(count - 1):
-        assert (uq[pbegin[s]:pbegin[s + 1]] <= cnt[s + 1, 6]).all()
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    seen = 0
+    for s in (0, count // 2, count - 2):
+        t = ctx.batch_fetch_track(s)
+        assert (t["n_unique"] <= t["cluster_size"]).all() and (t["n_unique"] <= cnt[s + 1, 6]).all()
+        sums = np.array([t["pair_count"][t["pair_begin"][k]:t["pair_begin"][k + 1]].sum() for k in range(t["n_clusters"])], np.int64)
+        assert np.array_equal(sums, t["n_unique"])
+        assert t["cluster_size"].sum() == t["n_car_points"] and int((t["pt_dyn"] == 1).sum()) == t["n_dynamic_points"]
+        assert set(np.unique(t["cluster_state"])) <= {-1, 0, 1}
+        seen += t["n_clusters"]
+    assert seen > 0
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (count, 1))
+    ctx.batch_track(ident, next_scan=np.arange(count, dtype=np.int32))
+    for s in (0, count - 1):
+        t = ctx.batch_fetch_track(s)
+        assert t["n_dynamic_clusters"] == 0 and (t["n_unique"] > 0).all()
     ctx.close()
 
 
@@ -126,7 +133,7 @@ def test_repeated_batches_are_bitwise_identical(scvod):
     count = 24
     pts, offs, poses, _ = synth.make_batch(5, 1500, count, "K64", device="cuda")
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
-    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)])
+    T = np.stack([ctx.pose_delta(poses[s], poses[s + 1]) for s in range(count - 1)] + [np.zeros(12, np.float32)])
 
     def digest():
         h = hashlib.sha256()
@@ -140,18 +147,14 @@ def test_repeated_batches_are_bitwise_identical(scvod):
                 h.update(np.ascontiguousarray(r[k]).tobytes())
         ctx.batch_cluster()
         ctx.batch_cluster_types()
-        members, cbegin, pbegin = [], [0], [0]
         for s in range(count):
             h.update(ctx.batch_fetch_clusters(s, int(cnt[s, 4])).tobytes())
-            t = ctx.batch_fetch_cluster_types(s, int(cnt[s, 4]))
-            h.update(t.tobytes())
-            if s < count - 1:
-                m = np.nonzero(t == 2)[0].astype(np.int32)
-                members.append(m)
-                cbegin.append(cbegin[-1] + len(m))
-                pbegin.append(len(cbegin) - 1)
-        ctx.batch_track(torch.from_numpy(np.concatenate(members)).cuda(), cbegin, pbegin, T)
-        h.update(ctx.batch_track_counts().tobytes())
+            h.update(ctx.batch_fetch_cluster_types(s, int(cnt[s, 4])).tobytes())
+        ctx.batch_track(T)
+        for s in (0, 7, count - 1):
+            t = ctx.batch_fetch_track(s)
+            for k in ("cluster_root", "cluster_size", "cluster_state", "n_unique", "pair_begin", "pair_label", "pair_count", "pt_dyn"):
+                h.update(np.ascontiguousarray(t[k]).tobytes())
         return h.hexdigest()
 
     first = digest()
