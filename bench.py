@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- scans/s of the SCV-OD hot path on MI355X (BASELINE.json metric).
+"""bench.py -- scans/s of the SCV-OD dynamic-removal path on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): a SemanticKITTI-seq-05-shaped sequence -- 2761 scans of a
-64-beam sensor, ~110-120 k returns per scan, config/semantickitti.yaml parameters -- synthetic
-(no dataset exists in this environment), resident in HBM before the timed region starts.
-One "step" = one pass of the hot path over the rank's whole sequence shard:
-    Patchwork ground segmentation -> curved-voxel binning -> per-voxel descriptors
-    -> scan-vs-next-scan occupancy probe for every consecutive pair,
-processed in chunks of --chunk scans through the C-ABI (libscvod.so).  With N > 1 GPUs every
-rank owns its own seq-05-shaped sequence (scans are independent: weak scaling, no data-path
-collective); value = scans of all ranks / max-over-ranks time.
+Workload at one GPU (BASELINE.json configs[1]): a SemanticKITTI-seq-05-shaped sequence -- 2761 scans of a 64-beam sensor,
+~118 k returns per scan, config/semantickitti.yaml parameters -- synthetic (no dataset exists in this environment),
+resident in HBM before the timed region starts.  With N GPUs (configs[3]): the scans of seq 05, 00, 02, 08, ... in that
+order, N x 2761 of them, cut into 8 N blocks that are dealt round-robin over the ranks (weak scaling: 2761 scans per rank).
+
+One "step" = one pass of the whole path over the rank's scans, raw points in, per-point dynamic/static labels and the
+static map out, everything on the device through the C-ABI (libscvod.so):
+    Patchwork ground segmentation -> curved-voxel binning -> per-voxel descriptors        scvod_batch_process
+    -> curved-voxel clustering -> bounding boxes + type rules                             scvod_batch_cluster(_types)
+    -> successor tables; boundary tables of the blocks' first scans to the left neighbour scvod_batch_track_tables,
+       (RCCL point-to-point; a local no-op at one GPU)                                    scvod_batch_export_table
+    -> scan-vs-next-scan differencing: probe, remap_name, state rule, per-point byte      scvod_batch_track
+    -> world-frame static map of the rank's scans                                         scvod_batch_map_accumulate
+    -> (N > 1) the ranks' map records gathered on rank 0 over RCCL and merged             scvod_map_export / _merge
+value = scans of all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline      HBM roofline of the dominant kernel, measured live with hipEvents on the launch stream
-  cpu_baseline  the oracle (CPU restatement of the reference, single thread) on a bounded sample
+  roofline      HBM roofline: algorithmic bytes of the path over the measured step time; the dominant kernel
+                with its own hipEvent time and its own PMC traffic
+  cpu_baseline  the oracle (CPU restatement of the reference, one thread) over the same stages on a bounded sample
+  quality       dynamic-removal PR / RR (tool/analysis.py:186-187) of this path and of the oracle chain on that sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,24 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
-# Algorithmic (compulsory) bytes per scan, SURVEY.md 8(d), split by stage so that a kernel is priced
-# against the bytes of ITS stage (DESIGN.md "Roofline accounting"):
-#   patchwork : 16 N (read xyzi)   [the per-point class byte of 8(d) is not materialised per batch any more:
-#               the two index lists carry it; scvod_batch_fetch builds the class array of a scan on request]
-#   binning   : 4 N (voxel_idx) + 1 N (dynamic/static label)           -> emit (fused)
-#   voxels    : 20 V                                                   -> vx_* kernels
-#   tracking  : 16 N_car + 4 N_car + 64                                -> track_* kernels
-STAGE_OF = {"pw_classify": "patchwork", "pw_offsets": "patchwork", "pw_scatter": "patchwork",
-            "pw_sort_wave": "patchwork", "pw_sort_256": "patchwork", "pw_sort_1024": "patchwork", "pw_sort_2048": "patchwork", "pw_sort_4096": "patchwork", "pw_sort_8192": "patchwork", "pw_order": "patchwork", "pw_fit": "patchwork", "pw_fit_large": "patchwork",
-            "pw_arrange": "patchwork", "emit_offsets": "patchwork",
-            "emit": "binning", "vx_count": "voxels", "vx_offsets": "voxels", "vx_order": "voxels", "vx_scatter": "voxels",
-            "vx_bucket_256": "voxels", "vx_bucket_1024": "voxels", "vx_bucket_2048": "voxels", "vx_bucket_4096": "voxels", "vx_bucket_8192": "voxels", "vx_final_offsets": "voxels",
-            "vx_final": "voxels", "track_probe": "tracking", "track_unique": "tracking"}
+# kernels of one step by the label of their hipEvent pair -> stage of SURVEY 8(d)'s byte accounting
+STAGE_OF = {"pw_": "patchwork", "emit": "binning", "vx_": "voxels", "cc_": "clustering", "tk_": "tracking", "map_": "map"}
 
 
 def _cpu_model():
@@ -55,9 +51,19 @@ def _cpu_model():
     return "unknown"
 
 
-def stage_bytes(n_pts, n_vox, n_car, n_scans):
-    return {"patchwork": 16.0 * n_pts, "binning": 5.0 * n_pts, "voxels": 20.0 * n_vox,
-            "tracking": 20.0 * n_car + 64.0 * n_scans}
+def algorithmic_bytes(n_pts, n_vox, n_car):
+    """Compulsory HBM traffic of one scan set, SURVEY.md 8(d): every input read once, every output written once.
+    16 N read xyzi + 1 N ground/non-ground class + 4 N voxel_idx + 1 N dynamic/static label + 20 V voxel records
+    + 20 N_car differencing (read the cluster points, write the hit key)."""
+    return {"patchwork": 17.0 * n_pts, "binning": 4.0 * n_pts, "voxels": 20.0 * n_vox, "tracking": 1.0 * n_pts + 20.0 * n_car}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -66,18 +72,32 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scans", type=int, default=2761, help="scans per rank (seq 05 has 2761)")
-    ap.add_argument("--chunk", type=int, default=0, help="scans per C-ABI batch call (0 = scans / streams)")
-    ap.add_argument("--streams", type=int, default=1, help="independent ctx + HIP stream pairs the chunks rotate over")
     ap.add_argument("--kind", default="K64")
     ap.add_argument("--preset", default="semantickitti")
-    ap.add_argument("--cpu-scans", type=int, default=400, help="bounded sample for the CPU baseline")
+    ap.add_argument("--blocks-per-rank", type=int, default=8)
+    ap.add_argument("--skip", type=int, default=0, help="tracking stride: scan i is differenced against scan i + skip (0: the preset's config skip_, 5 in semantickitti.yaml, 1 in parkinglot.yaml)")
+    ap.add_argument("--table-cap", type=int, default=0, help="records per boundary message (0: from the scans)")
+    ap.add_argument("--map-cells", type=int, default=0, help="capacity of the static map in cells (0: from the points)")
+    ap.add_argument("--map-leaf", type=float, default=0.2)
+    ap.add_argument("--cpu-scans", type=int, default=64, help="bounded sample for the CPU baseline and the PR/RR check")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the multi-threaded CPU context number")
-    ap.add_argument("--pseudo-clusters", action="store_true", help="differencing stage on synthetic index runs instead of GPU car clusters")
-    ap.add_argument("--no-extras", action="store_true", help="skip the separately reported next-row stages (clustering, boxes, VoxelGrid): profiling runs")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
-    ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0")
+    ap.add_argument("--no-quality", action="store_true", help="skip the PR/RR comparison")
+    ap.add_argument("--no-extras", action="store_true", help="skip the separately reported stages (VoxelGrid, ingest): profiling runs")
+    ap.add_argument("--no-map", action="store_true", help="leave the static map out of the step (profiling)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (use --backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--dump-map", default="", help="rank 0 writes the merged static map (records sorted by cell key) and the per-scan dynamic counts to this .npz")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU, RCCL)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,12 +106,13 @@ def main():
         local = 0
     assert torch.cuda.is_available(), "bench.py needs a GPU: the SCV-OD path has no CPU fallback"
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     import scvod_py
@@ -99,76 +120,90 @@ def main():
     import synth
 
     P = scvod_py.make_params(args.preset)
-    seq = 5 + 11 * rank  # every rank scans its own seq-05-shaped sequence
-    dev = torch.device("cuda", local)
+    if args.skip <= 0:
+        args.skip = 1 if args.preset == "parkinglot" else 5
+    plan = shard.plan_job(world, args.scans, synth.SEQ_LEN, blocks_per_rank=args.blocks_per_rank, skip=args.skip)[rank]
+    n_sc = len(plan["scans"])
 
-    if args.chunk <= 0:
-        args.chunk = (args.scans + args.streams - 1) // args.streams
-    # ---- synthetic sequence, resident in HBM ----
+    # ---- the rank's scans, resident in HBM ----
     t0 = time.time()
-    chunks = []
-    for c0 in range(0, args.scans, args.chunk):
-        cnt = min(args.chunk, args.scans - c0)
-        pts, offs, poses, _ = synth.make_batch(seq, c0, cnt, args.kind, device=dev)
-        chunks.append(dict(pts=pts, offs=np.asarray(offs, np.int32), poses=poses, first=c0))
+    parts, labs, offs, poses = [], [], [0], []
+    for (q, i) in plan["scans"]:
+        p, l, pose = synth.make_scan(q, i, args.kind, device=dev)
+        parts.append(p)
+        labs.append(l)
+        offs.append(offs[-1] + p.shape[0])
+        poses.append(pose)
+    pts = torch.cat(parts, 0).contiguous()
+    del parts
+    offs = np.asarray(offs, np.int32)
+    poses = np.asarray(poses, np.float32)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
-    max_pts = max(int(c["offs"][-1]) for c in chunks)
-    total_pts = sum(int(c["offs"][-1]) for c in chunks)
-    n_ctx = max(1, min(args.streams, len(chunks)))
-    ctxs = [scvod_py.Ctx(P, max_points_total=max_pts + 1024, max_scans=args.chunk, device=local) for _ in range(n_ctx)]
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_ctx - 1)]
-    for i, c in enumerate(chunks):
-        c["ctx"] = ctxs[i % n_ctx]
-        c["stream"] = tstreams[i % n_ctx].cuda_stream
-    ctx = ctxs[0]
+    total_pts = int(offs[-1])
+    max_scan = int(np.diff(offs).max())
 
-    # ---- clusters for the differencing stage (built once, outside the timed region): the `car` clusters the
-    # GPU clustering + bounding-box rules find in every scan -- what SSC::tracking walks.
-    # --pseudo-clusters falls back to every 5th apri point in runs of 256. ----
-    tot_vox = 0
-    tot_car = 0
-    for c in chunks:
-        ctx, stream = c["ctx"], c["stream"]
-        ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=True)
-        cnt = ctx.batch_counts()
-        tot_vox += int(cnt[:, 6].sum())
-        n_sc = cnt.shape[0]
-        members, cbegin, pbegin = [], [0], [0]
-        if not args.pseudo_clusters:
-            ctx.batch_cluster(stream=stream, sync=False)
-            ctx.batch_cluster_types(stream=stream, sync=True)
-        for s in range(n_sc - 1):
-            if args.pseudo_clusters:
-                m = np.arange(0, cnt[s, 4], 5, dtype=np.int32)
-                sizes = [min(256, len(m) - k) for k in range(0, len(m), 256)]
-            else:
-                names = ctx.batch_fetch_clusters(s, int(cnt[s, 4]))
-                types = ctx.batch_fetch_cluster_types(s, int(cnt[s, 4]))
-                idx = np.nonzero(types == 2)[0].astype(np.int32)
-                order = np.argsort(names[idx], kind="stable")
-                m = idx[order]
-                nm = names[m]
-                starts = np.nonzero(np.concatenate([[True], nm[1:] != nm[:-1]]))[0] if len(m) else np.zeros(0, np.int64)
-                sizes = np.diff(np.append(starts, len(m))).tolist()
-            members.append(m)
-            for sz in sizes:
-                cbegin.append(cbegin[-1] + int(sz))
-            pbegin.append(len(cbegin) - 1)
-        mem = np.concatenate(members) if members else np.zeros(0, np.int32)
-        tot_car += len(mem)
-        T = np.stack([ctx.pose_delta(c["poses"][s], c["poses"][s + 1]) for s in range(n_sc - 1)]) if n_sc > 1 else np.zeros((0, 12), np.float32)
-        c["members"] = torch.from_numpy(mem if len(mem) else np.zeros(1, np.int32)).to(dev)
-        c["cbegin"] = np.asarray(cbegin, np.int32)
-        c["pbegin"] = np.asarray(pbegin, np.int32)
-        c["T"] = T.astype(np.float32)
-        c["n_sc"] = n_sc
+    ctx = scvod_py.Ctx(P, max_points_total=total_pts + 1024, max_scans=n_sc, device=local)
+    stream = torch.cuda.current_stream().cuda_stream  # torch.distributed orders its work against this stream
+    nxt = plan["next_scan"]
+    T = np.zeros((n_sc, 12), np.float32)
+    for s in range(n_sc):
+        if nxt[s] >= 0:
+            T[s] = ctx.pose_delta(poses[s], poses[nxt[s]])
+        elif nxt[s] <= -2:  # the successor lives on the right neighbour: its pose is a function of (seq, idx) like everything else
+            q, i = plan["scans"][s]
+            T[s] = ctx.pose_delta(poses[s], np.asarray(synth.pose_of(i + args.skip), np.float32))
+    table_cap = args.table_cap or (1 << max(12, int(np.ceil(np.log2(max_scan * 0.6 + 2)))))
+    send_buf = torch.zeros((len(plan["send_scans"]), table_cap, 4), dtype=torch.int32, device=dev)
+    recv_buf = torch.zeros((plan["n_recv"], table_cap, 4), dtype=torch.int32, device=dev)
+    ext = [recv_buf[e] for e in range(plan["n_recv"])]
+    smap = None
+    if not args.no_map:
+        cells = args.map_cells or (1 << int(np.ceil(np.log2(max(total_pts * 0.12, 1 << 20) * (world if rank == 0 else 1)))))
+        smap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local)
+    kt = {}
+    info = {}
 
-    def step():
-        for c in chunks:
-            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
-            if c["n_sc"] > 1:
-                c["ctx"].batch_track(c["members"], c["cbegin"], c["pbegin"], c["T"], stream=c["stream"], sync=False)
+    def collect():
+        for name, ms in ctx.timings():
+            a = kt.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+
+    def step(timed=False):
+        def after():
+            if timed:
+                collect()
+        ctx.batch_process(pts, offs, stream=stream, sync=False)
+        after()
+        ctx.batch_cluster(stream=stream, sync=False)
+        after()
+        ctx.batch_cluster_types(stream=stream, sync=False)
+        after()
+        ctx.batch_track_tables(stream=stream)
+        after()
+        for m, s in enumerate(plan["send_scans"]):
+            ctx.batch_export_table(s, send_buf[m], stream=stream)
+        shard.exchange_tables(dist, send_buf, recv_buf)
+        ctx.batch_track(T, next_scan=nxt, ext_tables=ext, stream=stream, sync=False)
+        after()
+        if smap is not None:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            smap.clear(stream=stream)
+            smap.accumulate(ctx, poses, stream=stream)
+            if timed:
+                e1.record()
+                e1.synchronize()
+                a = kt.setdefault("map_accumulate", [0.0, 0])
+                a[0] += e0.elapsed_time(e1)
+                a[1] += 1
+            if world > 1:
+                rec = smap.export(stream=stream)
+                for other in shard.gather_map_records(dist, rec, root=0):
+                    smap.merge(other, stream=stream)
+                info["map_records_sent"] = int(rec.shape[0])
 
     def barrier():
         torch.cuda.synchronize()
@@ -178,175 +213,169 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # per-kernel hipEvent timing on the launch stream for the timed steps
-    kt = {}
-
-    def timed_step():
-        for c in chunks:
-            ctx, stream = c["ctx"], c["stream"]
-            ctx.batch_process(c["pts"], c["offs"], stream=stream, sync=False)
-            for name, ms in ctx.timings():
-                a = kt.setdefault(name, [0.0, 0])
-                a[0] += ms
-                a[1] += 1
-            if c["n_sc"] > 1:
-                ctx.batch_track(c["members"], c["cbegin"], c["pbegin"], c["T"], stream=stream, sync=False)
-                for name, ms in ctx.timings():
-                    a = kt.setdefault(name, [0.0, 0])
-                    a[0] += ms
-                    a[1] += 1
-
-    # timed region 1 (the number reported): no per-kernel events, async launches
-    for x in ctxs:
-        x.set_timing(False)
+    # timed region (the number reported): no per-kernel events, asynchronous launches
+    ctx.set_timing(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    # timed region 2: the same steps with hipEvents around every kernel (roofline attribution)
-    for x in ctxs:
-        x.set_timing(True)
+    # the same steps again with hipEvents around every kernel of the ctx (attribution only) and around the map stage
+    ctx.set_timing(True)
     barrier()
     for _ in range(args.steps):
-        timed_step()
+        step(timed=True)
     barrier()
-    for x in ctxs:
-        x.set_timing(False)
+    ctx.set_timing(False)
 
-    # "next" row 8(f)-1, reported separately (not part of `value`): curved-voxel clustering on the resident batch
-    cc_ms = ct_ms = None
-    try:
-        if args.no_extras:
-            raise RuntimeError("skipped")
-        barrier()
-        t1 = time.perf_counter()
-        for c in chunks:
-            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
-        barrier()
-        t_proc = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        for c in chunks:
-            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
-            c["ctx"].batch_cluster(stream=c["stream"], sync=False)
-        barrier()
-        cc_ms = 1e3 * ((time.perf_counter() - t1) - t_proc)
-        t1 = time.perf_counter()
-        for c in chunks:  # 8(f)-2: bounding boxes + type rules on top of the clusters
-            c["ctx"].batch_process(c["pts"], c["offs"], stream=c["stream"], sync=False)
-            c["ctx"].batch_cluster(stream=c["stream"], sync=False)
-            c["ctx"].batch_cluster_types(stream=c["stream"], sync=False)
-        barrier()
-        ct_ms = 1e3 * ((time.perf_counter() - t1) - t_proc) - cc_ms
-    except Exception as e:  # never let the optional stage break the bench line
-        cc_ms = ct_ms = None
-    # "next" row 8(f)-3, reported separately: loader-side VoxelGrid 0.08 m over the resident sequence (into a second buffer)
-    vg_ms = vg_ratio = e2e_ms = None
-    try:
-        if args.no_extras:
-            raise RuntimeError("skipped")
-        c = chunks[0]
-        d_out = torch.empty_like(c["pts"])
-        c["ctx"].batch_voxelgrid(c["pts"], c["offs"], d_out)  # warm-up
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        oo = c["ctx"].batch_voxelgrid(c["pts"], c["offs"], d_out)
-        torch.cuda.synchronize()
-        vg_ms = 1e3 * (time.perf_counter() - t1) * (args.scans / (len(c["offs"]) - 1))
-        vg_ratio = float(oo[-1]) / float(c["offs"][-1])
-        # the reference's real order: loader (filter + VoxelGrid) THEN the hot path on the downsampled scans, all resident
-        c["ctx"].batch_process(d_out, oo, stream=c["stream"], sync=True)
-        t1 = time.perf_counter()
-        oo = c["ctx"].batch_voxelgrid(c["pts"], c["offs"], d_out)
-        c["ctx"].batch_process(d_out, oo, stream=c["stream"], sync=True)
-        e2e_ms = 1e3 * (time.perf_counter() - t1) * (args.scans / (len(c["offs"]) - 1))
-        del d_out
-    except Exception as e:
-        vg_ms = vg_ratio = e2e_ms = None
-    dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, args.scans, total_pts)
+    cnt = ctx.batch_counts()
+    tot_vox = int(cnt[:, 6].sum())
+    tot_apri = int(cnt[:, 4].sum())
+    tk = [ctx.batch_fetch_track(s) for s in range(0, n_sc, max(1, n_sc // 64))]
+    car_frac = sum(t["n_car_points"] for t in tk) / max(1, sum(t["n_apri"] for t in tk))
+    dyn_frac = sum(t["n_dynamic_points"] for t in tk) / max(1, sum(t["n_apri"] for t in tk))
+    tot_car = car_frac * tot_apri
+    map_cells = smap.count() if smap is not None else None
+    if args.dump_map:
+        dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(n_sc)], np.int64)
+        gathered = [None] * world
+        if dist is not None:
+            dist.all_gather_object(gathered, (rank, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist()))
+        else:
+            gathered = [(0, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist())]
+        if rank == 0:
+            rec = smap.export().cpu().numpy().view(np.uint64)
+            order = np.argsort(rec[:, 0])
+            per_scan = sorted((tuple(q), d) for _, qs, ds in gathered for q, d in zip(qs, ds))
+            np.savez(args.dump_map, keys=rec[order, 0], vals=rec[order, 1], scans=np.array([q for q, _ in per_scan], np.int64),
+                     dynamic_points=np.array([d for _, d in per_scan], np.int64))
+
+    dev_labels = None
+    if rank == 0 and world == 1 and not args.no_cpu and not args.no_quality:
+        import quality as qmod
+        sample = list(range(0, n_sc, args.skip))[: args.cpu_scans]  # what the reference loads with skip_: consecutive FRAMES
+        dev_labels = [qmod.device_point_labels(ctx, s, int(offs[s + 1] - offs[s])) for s in sample[:-1]]
+
+    # ---- separately reported stages (not part of `value`; they reuse the arena) ----
+    extras = {}
+    if not args.no_extras and world == 1:
+        try:  # loader-side label filter + VoxelGrid 0.08 m over the resident sequence
+            sub = min(n_sc, 512)
+            o2 = offs[: sub + 1]
+            d_out = torch.empty((int(o2[-1]), 4), dtype=torch.float32, device=dev)
+            ctx.batch_voxelgrid(pts, o2, d_out)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            oo = ctx.batch_voxelgrid(pts, o2, d_out)
+            torch.cuda.synchronize()
+            extras["voxelgrid_ms_per_sequence"] = 1e3 * (time.perf_counter() - t1) * n_sc / sub
+            extras["voxelgrid_kept_fraction"] = float(oo[-1]) / float(o2[-1])
+            del d_out
+        except Exception as e:  # never let an optional stage break the bench line
+            extras["voxelgrid_error"] = str(e)[:200]
+        try:  # PCIe-inclusive ingest: chunked H2D from pinned host memory on a copy stream, overlapped with the path
+            import ingest
+            extras["ingest"] = ingest.measure(scvod_py, P, pts, offs, poses, local)
+        except Exception as e:
+            extras["ingest_error"] = str(e)[:200]
+
+    dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, n_sc, total_pts)
 
     if rank == 0:
         scans_per_s = all_scans * args.steps / dt
-        # dominant kernel and its HBM roofline
-        n_chunks = len(chunks)
-        sb = stage_bytes(total_pts, tot_vox, tot_car, args.scans)  # bytes per step (this rank)
-        dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else None
-        roof = None
+        ms_step = 1e3 * dt / args.steps
+        ab = algorithmic_bytes(total_pts, tot_vox, tot_car)
+        path_bytes = sum(ab.values())
+        tot_ms = sum(v[0] for v in kt.values()) or 1.0
         kernels = {}
-        for name, (ms, cnt) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
-            kernels[name] = {"avg_ms": ms / cnt, "launches": cnt, "share": ms / sum(v[0] for v in kt.values())}
+        traffic = {}
+        try:  # per-kernel HBM bytes per scan from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/)
+            pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
+            if pm:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1]))).get("by_bench_label", {})
+        except Exception:
+            traffic = {}
+        for name, (ms, c) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
+            k = {"avg_ms": ms / c, "launches": c, "share": ms / tot_ms}
+            if name in traffic:  # bytes per scan -> this kernel's OWN traffic over its OWN time
+                k["pmc_MB_per_scan"] = traffic[name] / 1e6
+                k["pmc_GBps"] = traffic[name] * n_sc / (ms / c * 1e-3) / 1e9
+            kernels[name] = k
+        dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else None
+        roof = {"bound": "hbm", "achieved": path_bytes / (ms_step * 1e-3) / 1e9 * (1 if world == 1 else all_scans / n_sc), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "algorithmic_bytes_per_scan": path_bytes / n_sc, "algorithmic_bytes_per_step": path_bytes, "by_stage_bytes_per_scan": {k: v / n_sc for k, v in ab.items()},
+                "basis": "SURVEY 8(d) bytes of the whole path / measured ms_per_step (all kernels of a step)"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        pmc_total = sum(v for k, v in traffic.items() if k in kt) if traffic else None
+        roof["traffic"] = pmc_total * n_sc if pmc_total else None
         if dom:
-            name, (ms, cnt) = dom
-            stage = STAGE_OF.get(name, "patchwork")
-            bytes_per_launch = sb[stage] / n_chunks  # one launch processes one chunk of the sequence
-            avg_s = ms / cnt / 1e3
-            ach = bytes_per_launch / avg_s / 1e9
-            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-            # gfx950 FETCH doubling per MI355X_MICROARCH.md), stored per scan in profiles/*pmc_traffic.json
-            traffic = None
-            try:
-                pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
-                if pm:
-                    per_scan = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["by_bench_label"].get(name)
-                    if per_scan is not None:
-                        traffic = per_scan * (args.scans / n_chunks)
-            except Exception:
-                traffic = None
-            roof = {"bound": "hbm", "kernel": name, "stage": stage, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_ms_per_launch": ms / cnt,
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "path_GBps": (sum(sb.values()) * args.steps / dt) / 1e9}
-        cpu = None
+            name, (ms, c) = dom
+            roof["dominant_kernel"] = {"name": name, "avg_ms_per_launch": ms / c, "share_of_step": ms / tot_ms,
+                                       "pmc_bytes_per_launch": (traffic[name] * n_sc) if name in traffic else None,
+                                       "pmc_GBps": kernels[name].get("pmc_GBps")}
+        cpu = quality = cpu_all = None
         if not args.no_cpu and world == 1:
             import oracle_py
             orc = oracle_py.load()
-            ns = min(args.cpu_scans, int(chunks[0]["n_sc"]))
-            offs = chunks[0]["offs"][: ns + 1]
-            x = chunks[0]["pts"][: int(offs[-1])].cpu().numpy()
+            sample = list(range(0, n_sc, args.skip))[: args.cpu_scans]
+            ns = len(sample)
+            x = torch.cat([pts[int(offs[s]):int(offs[s + 1])] for s in sample]).cpu().numpy()
+            o2 = np.concatenate([[0], np.cumsum([int(offs[s + 1] - offs[s]) for s in sample])]).astype(np.int32)
+            sp = poses[sample]
             t1 = time.perf_counter()
-            stages, _ = orc.time_process(P, x, offs)
+            stages, ref_lab, _ = orc.time_sequence(P, x, o2, sp)
             cpu_dt = time.perf_counter() - t1
-            cpu = {"value": ns / cpu_dt, "unit": "scans/s", "cores": 1, "kind": "port",
-                   "sample": f"first {ns} scans of the same synthetic seq-05 sequence (Patchwork+binning+voxel descriptors, "
-                             f"oracle/liboracle.so, g++ -O3 no -march, 1 thread; {os.cpu_count()} host cores present)",
-                   "host_cpu": _cpu_model(),
-                   "stage_ms_per_scan": {"patchwork": 1e3 * stages[0] / ns, "bin": 1e3 * stages[1] / ns,
-                                         "voxelize": 1e3 * stages[2] / ns}}
-        # context only: the same oracle with one scan per host thread (ctypes releases the GIL), bounded to ~10 s
-        cpu_all = None
-        if cpu is not None and not args.no_cpu_all:
-            try:
-                from concurrent.futures import ThreadPoolExecutor
-                nthr = min(os.cpu_count() or 1, 64)
-                per = max(2, min(8, int(chunks[0]["n_sc"]) // nthr))
-                offs_all = chunks[0]["offs"]
-                xs = chunks[0]["pts"][: int(offs_all[nthr * per])].cpu().numpy()
+            names = ("patchwork", "bin", "voxelize", "cluster", "types", "tracking")
+            cpu = {"value": ns / sum(stages), "unit": "scans/s", "cores": 1, "kind": "port",
+                   "sample": f"{ns} frames (every {args.skip}th scan from the start, the reference's skip_) of the same synthetic sequence through the same stages (Patchwork, binning, voxel descriptors, "
+                             f"clustering, box rules, sequential tracking chain; oracle/liboracle.so, g++ -O3 no -march, 1 thread; "
+                             f"{os.cpu_count()} host cores present); wall {cpu_dt:.1f} s",
+                   "host_cpu": _cpu_model(), "stage_ms_per_scan": {k: 1e3 * v / ns for k, v in zip(names, stages)}}
+            if not args.no_quality:
+                try:
+                    gt = torch.cat([labs[s] for s in sample]).cpu().numpy()
+                    quality = qmod.compare(scvod_py, ctx, x, o2, sp, gt, ref_lab, np.concatenate(dev_labels), voxelsize=0.2)
+                except Exception as e:
+                    quality = {"error": str(e)[:300]}
+            if not args.no_cpu_all:
+                try:  # context only: the same oracle with one chunk of scans per host thread (ctypes releases the GIL)
+                    from concurrent.futures import ThreadPoolExecutor
+                    nthr = min(os.cpu_count() or 1, 64)
+                    per = 2
+                    xs = pts[: int(offs[min(n_sc, nthr * per)])].cpu().numpy()
 
-                def work(t):
-                    o = offs_all[t * per:(t + 1) * per + 1]
-                    orc.time_process(P, xs[int(o[0]):int(o[-1])], (o - o[0]).astype(np.int32))
-                t1 = time.perf_counter()
-                with ThreadPoolExecutor(nthr) as ex:
-                    list(ex.map(work, range(nthr)))
-                cpu_all = {"value": nthr * per / (time.perf_counter() - t1), "unit": "scans/s", "threads": nthr,
-                           "note": "one scan per thread, same oracle; context, not the baseline"}
-            except Exception:
-                cpu_all = None
-        out = {"metric": "scans/sec on SemanticKITTI-seq-05-shaped input (SCV-OD hot path)", "value": scans_per_s,
-               "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    def work(t):
+                        o = offs[t * per:(t + 1) * per + 1]
+                        if len(o) < 2:
+                            return
+                        orc.time_sequence(P, xs[int(o[0]):int(o[-1])], (o - o[0]).astype(np.int32), poses[t * per:(t + 1) * per], want_labels=False)
+                    t1 = time.perf_counter()
+                    with ThreadPoolExecutor(nthr) as ex:
+                        list(ex.map(work, range(min(nthr, n_sc // per))))
+                    cpu_all = {"value": min(nthr, n_sc // per) * per / (time.perf_counter() - t1), "unit": "scans/s", "threads": nthr,
+                               "note": "two scans per thread, same oracle; context, not the baseline"}
+                except Exception:
+                    cpu_all = None
+        extras["cpu_all_threads"] = cpu_all
+        out = {"metric": "scans/sec on SemanticKITTI-seq-05-shaped input (SCV-OD dynamic-removal path, raw scans -> per-point labels + static map)",
+               "value": scans_per_s, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"seq05-shaped {args.kind} sequence, {args.scans} scans/rank, {args.preset}.yaml grid, "
-                                      f"chunks of {args.chunk} scans on {n_ctx} stream(s)", "scans_per_rank": args.scans,
-                          "points_per_scan": total_pts / args.scans, "voxels_per_scan": tot_vox / args.scans,
-                          "car_points_per_scan": tot_car / args.scans, "car_clusters": "pseudo" if args.pseudo_clusters else "gpu clustering + bbox rules", "sharding": f"1 sequence per GPU x{world}"},
+               "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 else
+                                       f"seq 05,00,02,08,...-shaped {args.kind} scans, {int(all_scans)} in total, {args.blocks_per_rank * world} blocks round-robin over {world} ranks, {args.preset}.yaml grid"),
+                          "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
+                          "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
+                          "static_map_cells": map_cells, "boundary_tables_per_step": len(plan["send_scans"]),
+                          "rccl_ranks": world, "tracking_stride": args.skip, "sharding": f"{args.blocks_per_rank} blocks per rank, block k on rank k % {world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
-               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
-               "extras": {"cluster_ms_per_sequence": cc_ms, "cluster_types_ms_per_sequence": ct_ms, "voxelgrid_ms_per_sequence": vg_ms, "voxelgrid_kept_fraction": vg_ratio, "voxelgrid_then_path_ms_per_sequence": e2e_ms, "cpu_all_threads": cpu_all}}
+               "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
+        if world > 1:
+            out["config"]["map_records_gathered_per_rank"] = info.get("map_records_sent")
         print(json.dumps(out))
-    for x in ctxs:
-        x.close()
+    if smap is not None:
+        smap.close()
+    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -56,7 +56,15 @@ struct scvod_ctx {
     std::vector<int32_t> up_next;
     std::vector<const void*> up_ext;
     bool track_valid = false;
+    bool tables_valid = false;   // successor tables (vox_track) built for the current clustering
     std::vector<int32_t> tk_stage;    // host staging of scvod_batch_fetch_track
+    // streaming ingest (scvod_sequence_ingest): two device chunk buffers, a copy stream, pinned offsets
+    hipStream_t copy_stream = nullptr;
+    void* ingest_buf[2] = {nullptr, nullptr};
+    size_t ingest_cap = 0;  // points per buffer
+    hipEvent_t ingest_copied[2] = {nullptr, nullptr}, ingest_done[2] = {nullptr, nullptr};
+    int32_t* ingest_off = nullptr;  // pinned
+    size_t ingest_off_cap = 0;
     std::vector<uint8_t> tk_stage_dyn;
     // last batch
     bool batch_valid = false;
@@ -147,6 +155,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.apri_src = k.take<int32_t>(N);
     A.apri_key = k.take<int32_t>(N);
     A.apri_int = k.take<float>(N);
+    A.apri_idx3 = k.take<int32_t>(N);
     A.rejected_src = k.take<int32_t>(N);
     A.counts = k.take<int32_t>(B * 8);
     A.vb_count = k.take<int32_t>(B * kMaxBuckets);
@@ -172,7 +181,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cc_touched = k.take<uint8_t>(N);
     A.pt_voxel = k.take<int32_t>(N);
     A.pt_cluster = k.take<int32_t>(N);
-    A.cl_bbox = k.take<uint32_t>(6 * N);
+    A.cl_bbox = k.take<uint32_t>(7 * N + 64);
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
     A.vg_par = k.take<int32_t>(B * 16);
@@ -311,7 +320,7 @@ void timer_hook(void* user, const char* name, int begin) {
 }
 
 int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_scans, hipStream_t st,
-              int do_patchwork, int apply_filter, int do_voxels, int sync) {
+              int do_patchwork, int apply_filter, int do_voxels, int sync, bool off_pinned = false) {
     if (!c) return SCVOD_ERR_INVALID;
     if (n_scans <= 0 || !h_off || (!d_xyzi && do_patchwork != 2)) return fail(c, SCVOD_ERR_INVALID, "empty batch");
     if (n_scans > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "n_scans %d > capacity %d", n_scans, c->cap_scans);
@@ -330,7 +339,8 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     if (!st) st = c->stream;
     c->last_stream = st;
     c->h_scan_off.assign(h_off, h_off + n_scans + 1);
-    HIPCHK(c, hipMemcpyAsync(c->d_scan_off, c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
+    // (a caller-pinned offset table is read by the copy engine directly: nothing to wait for on the host)
+    HIPCHK(c, hipMemcpyAsync(c->d_scan_off, off_pinned ? h_off : c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
     c->A.pts = (const float4*)d_xyzi;
     c->A.scan_off = c->d_scan_off;
     c->A.n_scans = n_scans;
@@ -343,6 +353,7 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->clusters_valid = false;
     c->types_valid = false;
     c->track_valid = false;
+    c->tables_valid = false;
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     if (mx == 0) {
@@ -505,7 +516,7 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     c->A.max_scan_pts = mx;
     c->A.total_pts = total;
     c->tim_used = 0;
-    c->batch_valid = c->counts_valid = c->voxels_valid = c->clusters_valid = c->types_valid = c->track_valid = false;  // the arena is reused
+    c->batch_valid = c->counts_valid = c->voxels_valid = c->clusters_valid = c->types_valid = c->track_valid = c->tables_valid = false;  // the arena is reused
     h_out_off[0] = 0;
     if (mx == 0) {
         for (int s = 0; s < n_scans; ++s) h_out_off[s + 1] = 0;
@@ -625,9 +636,6 @@ int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int devi
     if (!params || !out || max_points_total <= 0 || max_scans <= 0) return SCVOD_ERR_INVALID;
     *out = nullptr;
     if (max_points_total > 2147483583ll) return SCVOD_ERR_CAPACITY;  // scan offsets and point indices are int32
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SCVOD_ERR_NO_DEVICE;
-    if (device < 0 || device >= ndev) return SCVOD_ERR_NO_DEVICE;
     scvod_ctx* c = new scvod_ctx();
     c->device = device;
     c->params = *params;
@@ -643,9 +651,17 @@ int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int devi
         }
         np += c->pw.num_rings_each_zone[k] * c->pw.num_sectors_each_zone[k];
     }
-    if (np > kMaxPatches || !(params->range_res > 0) || !(params->sector_res > 0) || !(params->azimuth_res > 0)) {
+    // th_seeds < 0 or a near-zero th_dist could leave a plane iteration without points: the reference then fits with the
+    // stale moments of the previous patch (PCL leaves cov / mean untouched for an empty cloud) -- not modelled, refused
+    if (np > kMaxPatches || !(params->range_res > 0) || !(params->sector_res > 0) || !(params->azimuth_res > 0) ||
+        !(c->pw.th_seeds >= 0.0) || !(c->pw.th_dist >= 0.01) || c->pw.num_iter < 1 || c->pw.num_lpr < 1) {
         delete c;
         return SCVOD_ERR_INVALID;
+    }
+    int ndev = 0;  // (argument errors are reported before the device is looked for)
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        delete c;
+        return SCVOD_ERR_NO_DEVICE;
     }
     c->cap_pts = max_points_total;
     c->cap_scans = max_scans;
@@ -680,6 +696,13 @@ void scvod_destroy(scvod_ctx* c) {
         hipEventDestroy(t.e1);
     }
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ingest_buf[k]) hipFree(c->ingest_buf[k]);
+        if (c->ingest_copied[k]) hipEventDestroy(c->ingest_copied[k]);
+        if (c->ingest_done[k]) hipEventDestroy(c->ingest_done[k]);
+    }
+    if (c->ingest_off) hipHostFree(c->ingest_off);
     if (c->arena_base) hipFree(c->arena_base);
     if (c->stage) hipHostFree(c->stage);
     for (void* b : c->nn_buf)
@@ -840,15 +863,15 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
     c->tim_used = 0;
-    if (c->apri_compact) {  // the clustering kernels read the index triples of the PointAPRI records
-        launch_apri_expand(c->dev, c->A, 0, c->A.n_scans, c->A.max_scan_pts, st);
-        c->apri_compact = false;
-    }
-    launch_cluster(c->dev, c->A, st, timer_hook, c);
+    if (c->dev.bin.range_num > 2040 || c->dev.bin.sector_num > 2040 || c->dev.bin.azimuth_num > 1016)
+        return fail(c, SCVOD_ERR_INVALID, "grid of %d x %d x %d bins is finer than the clustering's packed index triples hold (2040 x 2040 x 1016)",
+                    c->dev.bin.range_num, c->dev.bin.sector_num, c->dev.bin.azimuth_num);
+    launch_cluster(c->dev, c->A, c->batch_mode == 2 ? 1 : 0, st, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     c->clusters_valid = true;
-    c->types_valid = false;  // the link step uses the type array as scratch
+    c->types_valid = false;  // scvod_batch_cluster_types publishes them
     c->track_valid = false;
+    c->tables_valid = false;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
@@ -873,9 +896,10 @@ int scvod_batch_cluster_types(scvod_ctx* c, void* stream, int32_t sync) {
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
     c->tim_used = 0;
-    launch_cluster_types(c->dev, c->A, st, timer_hook, c);
-    HIPCHK(c, hipGetLastError());
+    // the boxes and the type rules are evaluated by the clustering kernel itself (same workgroup, boxes in LDS): nothing to launch
     c->types_valid = true;
+    c->track_valid = false;
+    c->tables_valid = false;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
@@ -936,16 +960,34 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     J.n_ext = n_ext;
     J.T = c->t_T;
     J.occupancy = c->params.occupancy;
-    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, st, timer_hook, c);
+    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, c->tables_valid ? 2 : 3, st, timer_hook, c);
     HIPCHK(c, hipGetLastError());
+    c->tables_valid = true;
     c->track_valid = true;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
 
+int scvod_batch_track_tables(scvod_ctx* c, void* stream) {
+    if (!c) return SCVOD_ERR_INVALID;
+    if (!c->batch_valid || !c->voxels_valid || !c->clusters_valid || !c->types_valid)
+        return fail(c, SCVOD_ERR_STATE, "scvod_batch_track_tables needs scvod_batch_process, scvod_batch_cluster and scvod_batch_cluster_types first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->last_stream = st;
+    c->tim_used = 0;
+    TrackBatch J;
+    memset(&J, 0, sizeof(J));
+    launch_track_batch(c->dev, c->A, J, 0, 1, st, timer_hook, c);
+    HIPCHK(c, hipGetLastError());
+    c->tables_valid = true;
+    c->track_valid = false;
+    return SCVOD_OK;
+}
+
 int scvod_batch_export_table(scvod_ctx* c, int32_t s, void* d_out, int64_t cap_records, void* stream) {
     if (!c || !d_out || cap_records < 1) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
-    if (!c->track_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_export_table needs scvod_batch_track first");
+    if (!c->tables_valid) return fail(c, SCVOD_ERR_STATE, "scvod_batch_export_table needs scvod_batch_track_tables or scvod_batch_track first");
     if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
@@ -1025,6 +1067,88 @@ int scvod_batch_fetch_track(scvod_ctx* c, int32_t s, scvod_track_result* out) {
     return SCVOD_OK;
 }
 
+// Streaming ingest of a sequence that lives in HOST memory (the reference reads one .bin per scan from disk,
+// SSC::getCloud ssc.cpp:1040-1125): chunks of scans are copied host -> device on a copy stream into one of two buffers
+// while the previous chunk is processed on the compute stream; `fn` is called once per chunk, after its
+// scvod_batch_process launches are enqueued, to enqueue the consumers of that chunk's results (clustering, tracking, map
+// accumulation ...) on the same stream -- the arena holds one chunk at a time.
+int scvod_sequence_ingest(scvod_ctx* c, const float* h_xyzi, const int32_t* h_scan_offsets, int32_t n_scans, int32_t chunk_scans,
+                          int32_t flags, scvod_chunk_fn fn, void* user) {
+    if (!c || !h_xyzi || !h_scan_offsets || n_scans <= 0 || chunk_scans <= 0) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
+    if (chunk_scans > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "chunk of %d scans > capacity %d", chunk_scans, c->cap_scans);
+    const int n_chunks = (n_scans + chunk_scans - 1) / chunk_scans;
+    int64_t max_chunk_pts = 0;
+    for (int k = 0; k < n_chunks; ++k) {
+        const int s0 = k * chunk_scans, s1 = s0 + chunk_scans < n_scans ? s0 + chunk_scans : n_scans;
+        const int64_t p = (int64_t)h_scan_offsets[s1] - h_scan_offsets[s0];
+        if (p < 0) return fail(c, SCVOD_ERR_INVALID, "scan_offsets not monotone");
+        if (p > max_chunk_pts) max_chunk_pts = p;
+    }
+    if (max_chunk_pts > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "chunk of %lld points > capacity %lld", (long long)max_chunk_pts, (long long)c->cap_pts);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        if (!c->ingest_copied[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ingest_copied[k], hipEventDisableTiming));
+        if (!c->ingest_done[k]) HIPCHK(c, hipEventCreateWithFlags(&c->ingest_done[k], hipEventDisableTiming));
+    }
+    if ((size_t)max_chunk_pts > c->ingest_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (int k = 0; k < 2; ++k) {
+            if (c->ingest_buf[k]) hipFree(c->ingest_buf[k]);
+            c->ingest_buf[k] = nullptr;
+        }
+        c->ingest_cap = 0;
+        for (int k = 0; k < 2; ++k) HIPCHK(c, hipMalloc(&c->ingest_buf[k], 16 * (size_t)max_chunk_pts));
+        c->ingest_cap = (size_t)max_chunk_pts;
+    }
+    const size_t off_need = (size_t)n_scans + (size_t)n_chunks + 8;
+    if (off_need > c->ingest_off_cap) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->ingest_off) hipHostFree(c->ingest_off);
+        c->ingest_off = nullptr;
+        c->ingest_off_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->ingest_off, sizeof(int32_t) * off_need, hipHostMallocDefault));
+        c->ingest_off_cap = off_need;
+    }
+    const size_t bytes_all = 16 * (size_t)(h_scan_offsets[n_scans] - h_scan_offsets[0]);
+    bool registered = false;
+    if ((flags & SCVOD_INGEST_REGISTER) && bytes_all) {  // pin the caller's buffer for the duration of the call
+        if (hipHostRegister((void*)(h_xyzi + 4 * (size_t)h_scan_offsets[0]), bytes_all, hipHostRegisterDefault) == hipSuccess)
+            registered = true;
+        else
+            (void)hipGetLastError();  // already pinned or not registrable: the copies still work (staged)
+    }
+    hipStream_t st = c->stream;
+    int rc = SCVOD_OK;
+    int32_t* po = c->ingest_off;
+    for (int k = 0; k < n_chunks && rc == SCVOD_OK; ++k) {
+        const int b = k & 1;
+        const int s0 = k * chunk_scans, s1 = s0 + chunk_scans < n_scans ? s0 + chunk_scans : n_scans;
+        const int ns = s1 - s0;
+        for (int j = 0; j <= ns; ++j) po[j] = h_scan_offsets[s0 + j] - h_scan_offsets[s0];
+        const size_t npts = (size_t)po[ns];
+        // the buffer is free once the consumers of the chunk two steps back are done
+        if (k >= 2 && hipStreamWaitEvent(c->copy_stream, c->ingest_done[b], 0) != hipSuccess) rc = fail(c, SCVOD_ERR_HIP, "hipStreamWaitEvent");
+        if (rc == SCVOD_OK && npts &&
+            hipMemcpyAsync(c->ingest_buf[b], h_xyzi + 4 * (size_t)h_scan_offsets[s0], 16 * npts, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess)
+            rc = fail(c, SCVOD_ERR_HIP, "hipMemcpyAsync (ingest)");
+        if (rc == SCVOD_OK && (hipEventRecord(c->ingest_copied[b], c->copy_stream) != hipSuccess ||
+                               hipStreamWaitEvent(st, c->ingest_copied[b], 0) != hipSuccess))
+            rc = fail(c, SCVOD_ERR_HIP, "ingest event");
+        if (rc == SCVOD_OK) rc = run_batch(c, c->ingest_buf[b], po, ns, st, 1, 1, 1, 0, true);
+        if (rc == SCVOD_OK && fn) {
+            const int frc = fn(user, c, s0, ns, (void*)st);
+            if (frc != SCVOD_OK) rc = fail(c, frc, "chunk callback returned %d", frc);
+        }
+        if (rc == SCVOD_OK && hipEventRecord(c->ingest_done[b], st) != hipSuccess) rc = fail(c, SCVOD_ERR_HIP, "hipEventRecord");
+        po += ns + 1;
+    }
+    hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(st);
+    if (registered) hipHostUnregister((void*)(h_xyzi + 4 * (size_t)h_scan_offsets[0]));
+    if (rc == SCVOD_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(c, SCVOD_ERR_HIP, "ingest: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return rc;
+}
+
 int scvod_set_timing(scvod_ctx* c, int32_t enabled) {
     if (!c) return SCVOD_ERR_INVALID;
     c->timing = enabled != 0;
@@ -1085,7 +1209,7 @@ static int nn_reserve(scvod_ctx* c, int slot, size_t bytes, void** out) {
 }
 
 static int nn_run(scvod_ctx* c, const float* d_map, int32_t n_map, const float* d_q, int32_t n_query, float radius,
-                  int32_t* d_idx, float* d_sq, uint8_t* d_w, const float origin[3], hipStream_t st) {
+                  int32_t* d_idx, float* d_sq, uint8_t* d_w, const float origin[3], int bounded, hipStream_t st) {
     // grid: cell edge >= radius (so `within` is decided by the 27-cell probe); the origin only shifts the hash
     const float cell = radius > 0.2f ? radius : 0.2f;
     int32_t buckets = 1024;
@@ -1095,13 +1219,13 @@ static int nn_run(scvod_ctx* c, const float* d_map, int32_t n_map, const float* 
     void* d_work = nullptr;
     int rc = nn_reserve(c, 5, work_ints * sizeof(int), &d_work);
     if (rc) return rc;
-    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, origin, cell, buckets, (int*)d_work, st);
+    launch_nn(d_map, n_map, d_q, n_query, radius, d_idx, d_sq, d_w, origin, cell, buckets, (int*)d_work, bounded, st);
     HIPCHK(c, hipGetLastError());
     return SCVOD_OK;
 }
 
-int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,
-                    float radius, int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within) {
+static int nn_search_host(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query, float radius,
+                          int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within, int bounded) {
     if (!c || n_map < 0 || n_query < 0 || (n_map > 0 && !h_map_xyz) || (n_query > 0 && !h_query_xyz))
         return fail(c, SCVOD_ERR_INVALID, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1119,7 +1243,7 @@ int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const f
     if (n_map) HIPCHK(c, hipMemcpyAsync(d_map, h_map_xyz, (size_t)n_map * 12, hipMemcpyHostToDevice, st));
     if (n_query) HIPCHK(c, hipMemcpyAsync(d_q, h_query_xyz, (size_t)n_query * 12, hipMemcpyHostToDevice, st));
     if ((rc = nn_run(c, (const float*)d_map, n_map, (const float*)d_q, n_query, radius, (int32_t*)d_idx, (float*)d_sq, (uint8_t*)d_w,
-                     origin, st)))
+                     origin, bounded, st)))
         return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     if (n_query) {
@@ -1130,13 +1254,24 @@ int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const f
     return SCVOD_OK;
 }
 
+int scvod_nn_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,
+                    float radius, int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within) {
+    return nn_search_host(c, h_map_xyz, n_map, h_query_xyz, n_query, radius, h_nn_idx, h_nn_sqdist, h_within, 0);
+}
+int scvod_nn_radius_search(scvod_ctx* c, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz, int32_t n_query,
+                           float radius, int32_t* h_nn_idx, float* h_nn_sqdist) {
+    if (!(radius > 0.f)) return fail(c, SCVOD_ERR_INVALID, "radius must be positive");
+    std::vector<uint8_t> w(n_query > 0 ? n_query : 1);
+    return nn_search_host(c, h_map_xyz, n_map, h_query_xyz, n_query, radius, h_nn_idx, h_nn_sqdist, w.data(), 1);
+}
+
 int scvod_nn_search_device(scvod_ctx* c, const float* d_map_xyz, int32_t n_map, const float* d_query_xyz, int32_t n_query,
                            float radius, int32_t* d_nn_idx, float* d_nn_sqdist, uint8_t* d_within, void* stream) {
     if (!c || n_map < 0 || n_query < 0 || (n_map > 0 && !d_map_xyz) || (n_query > 0 && (!d_query_xyz || !d_nn_idx || !d_nn_sqdist || !d_within)))
         return fail(c, SCVOD_ERR_INVALID, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const float origin[3] = {0.f, 0.f, 0.f};
-    return nn_run(c, d_map_xyz, n_map, d_query_xyz, n_query, radius, d_nn_idx, d_nn_sqdist, d_within, origin,
+    return nn_run(c, d_map_xyz, n_map, d_query_xyz, n_query, radius, d_nn_idx, d_nn_sqdist, d_within, origin, 0,
                   stream ? (hipStream_t)stream : c->stream);
 }
 

@@ -75,6 +75,7 @@ struct Arena {
     int32_t* apri_src;        // [N]
     int32_t* apri_key;        // [N] PointAPRI::voxel_idx, compact copy for the voxel stage
     float* apri_int;          // [N] PointAPRI::intensity, compact copy for the voxel stage
+    int32_t* apri_idx3;       // [N] PointAPRI::{range,sector,azimuth}_idx packed 11+11+10 bits (clustering)
     int32_t* rejected_src;    // [N]
     int32_t* counts;          // [B][8]
     // voxel stage
@@ -102,7 +103,7 @@ struct Arena {
     uint8_t* cc_touched;      // [N] per voxel slot: appeared in a neighbourhood
     int32_t* pt_voxel;        // [N] voxel slot of every apri point
     int32_t* pt_cluster;      // [N] canonical cluster name = smallest apri index of the component
-    uint32_t* cl_bbox;        // [6N] per cluster root: min xyz / max xyz in order-preserving uint encoding
+    uint32_t* cl_bbox;        // [7N] clustering scratch: bounding-box records of the scans that do not fit the LDS
     int32_t* cl_count;        // [N] per cluster root: number of points
     uint8_t* pt_type;         // [N] per apri point: 0 erased, 1 other, 2 car
     // sequence differencing on the device (scvod_batch_track, scvod_track.hip)
@@ -180,15 +181,14 @@ void launch_voxelgrid_keys(const Arena& A, const VgJob& J, hipStream_t st);
 void launch_voxelgrid_lut(const Arena& A, hipStream_t st);
 void launch_voxelgrid_gather(const DevParams& P, const Arena& A, const VgJob& J, long long out_capacity, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
-void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
-void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
+void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
-void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, hipStream_t st, TimerHook th,
-                        void* tu);
+void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
+                        TimerHook th, void* tu);
 void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
-               float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work,
+               float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work, int bounded,
                hipStream_t st);
 
 }  // namespace scvod

@@ -10,8 +10,8 @@
 //   SSC::makeHashCloud                             ssc.cpp:253-289             -> k_vx_count, k_vx_offsets, k_vx_scatter, k_vx_order_*,
 //                                                                                  k_vx_bucket<...>, k_vx_final*
 //   SSC::tracking bulk part                        ssc.cpp:1274-1321           -> k_track_probe_pair, k_track_probe, k_track_unique_bits
-//   SSC::clusterAndCreateFrame (next row f-1)      ssc.cpp:299-393             -> k_cc_init/runs/link_starts/link_rest/join/flatten
-//   refineClusterByBoundingBox + recognize rules   ssc.cpp:437-467,849-872     -> k_cc_bbox_init/bbox/type
+//   SSC::clusterAndCreateFrame (next row f-1)      ssc.cpp:299-393             -> k_cc_scan (one workgroup per scan, union-find in LDS)
+//   refineClusterByBoundingBox + recognize rules   ssc.cpp:437-467,849-872     -> k_cc_scan (same workgroup, boxes in LDS)
 //   SSC::getCloud filter + pcl::VoxelGrid (f-3)    ssc.cpp:1063-1076,1103-1106 -> k_vg_minmax/keys/lut/outoff/final, k_vx_bucket<..., 1>
 //   kd-tree look-ups of evaluate.cpp:79-145                                    -> k_nn_count/fill/query, k_nn_brute_list
 //
@@ -197,6 +197,16 @@ __device__ __forceinline__ unsigned long long pack_key(uint32_t key, uint32_t id
 }
 __device__ __forceinline__ uint32_t key_idx(unsigned long long k) { return (uint32_t)k & ((1u << kKeyIdxBits) - 1u); }
 __device__ __forceinline__ uint32_t key_major(unsigned long long k) { return (uint32_t)(k >> kKeyIdxBits); }
+
+// index triple of an apri point, packed by k_emit / k_bin_direct / k_apri_split: 11 + 11 + 10 bits, each index clamped
+// to [-2, limit] and biased by 2 (indices at or beyond -2 / dim + 1 have no in-grid neighbour at all, so clamping them
+// keeps both the run comparison and the neighbourhood exact)
+__device__ __forceinline__ int32_t pack_idx3(int r, int s, int a) {
+    r = min(max(r, -2), 2045) + 2;
+    s = min(max(s, -2), 2045) + 2;
+    a = min(max(a, -2), 1021) + 2;
+    return r | (s << 11) | (a << 22);
+}
 
 __device__ __forceinline__ void cswap_asc(unsigned long long& x, unsigned long long& y) {
     double lo, hi;
@@ -1264,6 +1274,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     A.apri_src[dst0 + ek] = (int32_t)id;
                     A.apri_key[dst0 + ek] = a.voxel_idx;
                     A.apri_int[dst0 + ek] = a.intensity;
+                    A.apri_idx3[dst0 + ek] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
                 } else {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
                 }
@@ -1532,6 +1543,7 @@ __global__ __launch_bounds__(1024) void k_bin_direct(DevParams P, Arena A, int a
                 A.apri_src[dst] = i;
                 A.apri_key[dst] = a.voxel_idx;
                 A.apri_int[dst] = a.intensity;
+                A.apri_idx3[dst] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
             } else {
                 A.rejected_src[(size_t)base + (i - (run + ek))] = i;
             }
@@ -1560,6 +1572,7 @@ __global__ __launch_bounds__(256) void k_apri_split(Arena A) {
         const scvod_apri& a = A.apri[(size_t)base + i];
         A.apri_key[(size_t)base + i] = a.voxel_idx;
         A.apri_int[(size_t)base + i] = a.intensity;
+        A.apri_idx3[(size_t)base + i] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
     }
 }
 
@@ -1799,25 +1812,38 @@ __global__ __launch_bounds__(256) void k_vx_final(DevParams P, Arena A) {
 
 // ------------------------------------------------------------------------------------------
 // Curved-voxel clustering (SSC::clusterAndCreateFrame, src/ssc.cpp:299-352).
-// The reference walks the points in order and merges a point with EVERY point of the occupied voxels
-// in the 3x3x3 neighbourhood of its own (range, sector, azimuth) index, clipped to the grid, no sector
-// wrap-around (findVoxelNeighbors, ssc.cpp:395-411).  The resulting partition is order independent:
-// it is the set of connected components of that relation, computed here with a lock-free union-find
-// (smaller index wins, so the canonical name of a cluster is its smallest apri index).
+// The reference walks the points in order; point i looks its index triple's 3x3x3 neighbourhood up in hash_cloud
+// (findVoxelNeighbors, ssc.cpp:395-411: clipped to the grid, no sector wrap-around) and is merged with EVERY point of the
+// occupied voxels it finds (ssc.cpp:316-345); a point that finds nothing opens a cluster of its own (ssc.cpp:347-353).
+// The resulting partition does not depend on the order: it is the set of connected components of that relation.
+//
+// One workgroup per scan, the whole union-find in LDS.  Nodes are VOXELS, not points: a voxel that appears in anybody's
+// neighbourhood ("touched") has all its points merged, so it is one node, named after its first point; the points of a
+// voxel are walked as RUNS of equal index triples (a run's points share one neighbourhood) and a run that does not start
+// its voxel -- only possible when different triples alias onto one voxel_idx, i.e. next to the -1 bins -- is an extra
+// node.  Per scan: ~10 k voxels x 9 binary searches (the three sector neighbours of one (range, azimuth) pair are
+// adjacent keys) + lock-free unions, all on a 64 KB key table and a 64 KB parent array in LDS; the canonical cluster name
+// is the smallest apri index of the component.  Scans with more than kCcNodes voxels or kCcSlots points run the same
+// code on arena scratch in HBM.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int cc_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr int kCcNodes = 16384;  // voxels + extra run openers per scan held in LDS
+constexpr int kCcSlots = 65536;  // apri points per scan whose run / voxel start bits are held in LDS
+constexpr int kCcThreads = 1024;
+constexpr int kCcBoxes = 1024;   // bounding boxes per scan held in LDS (7 words each: the three bit arrays + touched/found, released)
+static_assert(7 * kCcBoxes <= 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32), "box records must fit the released bit arrays");
+constexpr size_t kCcLdsBytes = (size_t)(2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + 64) * 4;
 
+__device__ __forceinline__ int cc_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int cc_find(int* parent, int x) {
-    int p = cc_load(&parent[x]);
+    int p = cc_ld(&parent[x]);
     while (p != x) {
-        const int gp = cc_load(&parent[p]);
+        const int gp = cc_ld(&parent[p]);
         if (gp != p) atomicMin(&parent[x], gp);  // path halving (only ever moves towards smaller ancestors)
         x = p;
         p = gp;
     }
     return x;
 }
-
 __device__ __forceinline__ void cc_union(int* parent, int a, int b) {
     for (;;) {
         a = cc_find(parent, a);
@@ -1831,8 +1857,7 @@ __device__ __forceinline__ void cc_union(int* parent, int a, int b) {
         if (atomicCAS(&parent[a], a, b) == a) return;  // a was still a root: now hangs under the smaller b
     }
 }
-
-__device__ __forceinline__ int vox_slot_of(const int32_t* keys, int nv, int key) {
+__device__ __forceinline__ int cc_lower_bound(const int* keys, int nv, int key) {
     int lo = 0, hi = nv;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -1841,211 +1866,50 @@ __device__ __forceinline__ int vox_slot_of(const int32_t* keys, int nv, int key)
         else
             hi = mid;
     }
-    return (lo < nv && keys[lo] == key) ? lo : -1;
-}
-
-__global__ __launch_bounds__(256) void k_cc_init(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        A.cc_parent[(size_t)base + i] = i;
-        A.cc_touched[(size_t)base + i] = 0;
-        A.cl_count[(size_t)base + i] = 0;  // runs per voxel (k_cc_runs); cluster sizes only later (k_cc_bbox_init)
-    }
-}
-
-constexpr int kCcLdsKeys = 8192;
-// clusterAndCreateFrame walks the points of a voxel in order and searches the 27-neighbourhood only when the index
-// triple differs from the previous point's (ssc.cpp:306-330); a point with the same triple joins the point that opened
-// the run, if that one found any neighbour.  A thread per VOXEL made every wave as slow as its most populated voxel
-// (walls: hundreds of points), so the work is cut by point slot k of the voxel lists instead:
-//   k_cc_runs         per slot: voxel of the slot, does it open a run (first of its voxel or triple != previous)
-//   k_cc_link_starts  per run opener: the neighbourhood searches + unions, remembers whether it found a neighbour
-//   k_cc_link_rest    per other slot: union with its run's opener when that one found a neighbour
-// Same set of unions as the sequential walk, hence the same partition.
-__device__ __forceinline__ int cc_voxel_of_slot(const int32_t* vbeg, int nv, int k) {
-    int lo = 0, hi = nv;  // vbeg[lo] <= k < vbeg[lo + 1]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (vbeg[mid] <= k)
-            lo = mid;
-        else
-            hi = mid;
-    }
     return lo;
 }
+__device__ __forceinline__ bool cc_bit(const int* bits, int i) { return (cc_ld(&bits[i >> 5]) >> (i & 31)) & 1; }
+__device__ __forceinline__ void cc_set(int* bits, int i) { atomicOr(&bits[i >> 5], 1 << (i & 31)); }
 
-__global__ __launch_bounds__(256) void k_cc_runs(Arena A) {
-    __shared__ int32_t sbeg[kCcLdsKeys + 1];
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    const int nv = A.counts[s * 8 + 6];
-    if ((int)blockIdx.x * 256 >= n) return;
-    const int32_t* gbeg = A.vox_pt_begin + base + s;
-    const bool in_lds = nv <= kCcLdsKeys;
-    if (in_lds)
-        for (int i = threadIdx.x; i <= nv; i += 256) sbeg[i] = gbeg[i];
-    __syncthreads();
-    const int32_t* vbeg = in_lds ? sbeg : gbeg;
-    const int32_t* vpts = A.vox_pts + base;
-    const int lane = threadIdx.x & 63;
-    for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) {
-        const int k = k0 + threadIdx.x;
-        const bool valid = k < n;
-        int v = 0, pt = 0, ri = 0, si = 0, ai = 0;
-        if (valid) {
-            v = cc_voxel_of_slot(vbeg, nv, k);
-            pt = vpts[k];
-            A.pt_voxel[(size_t)base + pt] = v;
-            const scvod_apri& a = A.apri[(size_t)base + pt];
-            ri = a.range_idx;
-            si = a.sector_idx;
-            ai = a.azimuth_idx;
-        }
-        // the previous slot's triple comes from the neighbouring lane; only lane 0 of a wave gathers it
-        int pr = __shfl_up(ri, 1), ps = __shfl_up(si, 1), pa = __shfl_up(ai, 1);
-        if (valid) {
-            int start = 1;
-            if (k > vbeg[v]) {
-                if (lane == 0) {
-                    const scvod_apri& q = A.apri[(size_t)base + vpts[k - 1]];
-                    pr = q.range_idx;
-                    ps = q.sector_idx;
-                    pa = q.azimuth_idx;
-                }
-                start = (ri != pr || si != ps || ai != pa) ? 1 : 0;
-            }
-            A.pt_type[(size_t)base + k] = (uint8_t)start;  // per SLOT: bit 0 opens a run, bit 1 (k_cc_link_starts) found a neighbour
-            if (start) atomicAdd(&A.cl_count[(size_t)base + v], 1);
-        }
-    }
+// two-level table: `lk` holds every 2^shift-th key (all of them when shift == 0) in LDS, the rest stays in `gk` (HBM):
+// one LDS search + at most 2^shift adjacent global reads instead of log2(nv) dependent global round trips
+struct CcKeys {
+    const int* lk;
+    const int* gk;
+    int ns, nv, shift;
+};
+__device__ __forceinline__ int cc_lower_bound2(const CcKeys& K, int key) {
+    const int lo = cc_lower_bound(K.lk, K.ns, key);  // first sample >= key
+    if (K.shift == 0 || lo == 0) return lo << K.shift;
+    int u = ((lo - 1) << K.shift) + 1;
+    const int end = min(lo << K.shift, K.nv);
+    while (u < end && K.gk[u] < key) ++u;
+    return u;
 }
 
-// EXTRA = false: one thread per voxel handles the run its first slot opens (dense: every voxel has one).
-// EXTRA = true : one thread per slot handles the openers inside a voxel (index aliasing only: almost none).
-template <bool EXTRA>
-__global__ __launch_bounds__(256) void k_cc_link_starts(DevParams P, Arena A) {
-    // the scan's sorted key table in LDS when it fits (27 binary searches per run)
-    __shared__ int32_t skeys[kCcLdsKeys];
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    const int nv = A.counts[s * 8 + 6];
-    const int n_items = EXTRA ? n : nv;
-    if ((int)blockIdx.x * 256 >= n_items) return;
-    const int32_t* vbeg = A.vox_pt_begin + base + s;
-    const int32_t* vpts = A.vox_pts + base;
-    if (EXTRA) {  // nothing to do for this block unless one of its slots opens a run inside a voxel
-        const int k = blockIdx.x * 256 + threadIdx.x;
-        bool mine = false;
-        if (k < n && (A.pt_type[(size_t)base + k] & 1)) mine = (k != vbeg[A.pt_voxel[(size_t)base + vpts[k]]]);
-        if (!__syncthreads_or(mine)) return;
-    }
-    const int32_t* gkeys = A.vox_key + base;
-    const bool in_lds = nv <= kCcLdsKeys;
-    if (in_lds)
-        for (int i = threadIdx.x; i < nv; i += 256) skeys[i] = gkeys[i];
-    __syncthreads();
-    const int32_t* keys = in_lds ? skeys : gkeys;
-    int* parent = A.cc_parent + base;
-    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= n_items) return;
-    int k;
-    if (EXTRA) {
-        k = item;
-        if (!(A.pt_type[(size_t)base + k] & 1)) return;
-        if (k == vbeg[A.pt_voxel[(size_t)base + vpts[k]]]) return;  // handled by the per-voxel launch
-    } else {
-        k = vbeg[item];
-    }
-    const int pt = vpts[k];
-    const scvod_apri& a = A.apri[(size_t)base + pt];
-    const int ri = a.range_idx, si = a.sector_idx, ai = a.azimuth_idx;
+// neighbourhood of triple t for node `me`: unions with every occupied voxel found, marks them touched
+__device__ __forceinline__ bool cc_search(const CcKeys& K, int* parent, int* touched, int me, int32_t t, int R, int S, int Az) {
+    const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+    const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
     bool found = false;
-    for (int x = ri - 1; x <= ri + 1; ++x) {
-        if (x > R - 1 || x < 0) continue;
-        for (int y = si - 1; y <= si + 1; ++y) {
-            if (y > S - 1 || y < 0) continue;
-            for (int z = ai - 1; z <= ai + 1; ++z) {
-                if (z > Az - 1 || z < 0) continue;
-                const int u = vox_slot_of(keys, nv, x * S + y + z * R * S);
-                if (u < 0) continue;
-                A.cc_touched[(size_t)base + u] = 1;  // every point of u joins (ssc.cpp:316)
-                cc_union(parent, pt, vpts[vbeg[u]]);
+    if (ylo > yhi) return false;
+    for (int z = ai - 1; z <= ai + 1; ++z) {
+        if (z > Az - 1 || z < 0) continue;
+        for (int x = ri - 1; x <= ri + 1; ++x) {
+            if (x > R - 1 || x < 0) continue;
+            const int k0 = x * S + ylo + z * R * S, k1 = k0 + (yhi - ylo);
+            for (int u = cc_lower_bound2(K, k0); u < K.nv && K.gk[u] <= k1; ++u) {
+                cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
+                cc_union(parent, me, u);
                 found = true;
             }
         }
     }
-    if (found) A.pt_type[(size_t)base + k] = 3;
+    return found;
 }
 
-__global__ __launch_bounds__(256) void k_cc_link_rest(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    const int32_t* vbeg = A.vox_pt_begin + base + s;
-    const int32_t* vpts = A.vox_pts + base;
-    int* parent = A.cc_parent + base;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
-        if (A.pt_type[(size_t)base + k] & 1) continue;
-        const int pt = vpts[k];
-        const int v = A.pt_voxel[(size_t)base + pt];
-        int o = vbeg[v];  // a voxel with a single run (almost all of them): its opener is the voxel's first slot
-        if (A.cl_count[(size_t)base + v] > 1) {
-            o = k - 1;
-            while (!(A.pt_type[(size_t)base + o] & 1)) --o;  // slot vbeg[v] always opens a run
-        }
-        // plain store, no atomics: pt is still its own root (only run openers are ever the target of a union before this
-        // kernel) and the opener precedes it in the voxel's ascending point list, so parent < child holds
-        if (A.pt_type[(size_t)base + o] & 2) parent[pt] = vpts[o];
-    }
-}
-
-// every point of a voxel that appeared in somebody's neighbourhood is merged with that voxel's first point
-__global__ __launch_bounds__(256) void k_cc_join(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    const int32_t* vbeg = A.vox_pt_begin + base + s;
-    const int32_t* vpts = A.vox_pts + base;
-    int* parent = A.cc_parent + base;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int v = A.pt_voxel[(size_t)base + i];
-        if (A.cc_touched[(size_t)base + v]) cc_union(parent, i, vpts[vbeg[v]]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cc_flatten(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    int* parent = A.cc_parent + base;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        int r = i;
-        for (int p = parent[r]; p != r; p = parent[r]) r = p;  // read-only walk: roots are final after k_cc_join
-        A.pt_cluster[(size_t)base + i] = r;
-    }
-}
-
-// ---- bounding boxes + type of every cluster (refineClusterByBoundingBox ssc.cpp:437-467, recognize ssc.cpp:849-872)
 __device__ __forceinline__ uint32_t f2ord(float f) { return float_sort_key(f); }
 __device__ __forceinline__ float ord2f(uint32_t u) { return u2f((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
-
-__global__ __launch_bounds__(256) void k_cc_bbox_init(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + i);
-        bb[0] = bb[1] = bb[2] = 0xffffffffu;  // running minima (order-preserving encoding)
-        bb[3] = bb[4] = bb[5] = 0u;           // running maxima
-        A.cl_count[(size_t)base + i] = 0;
-    }
-}
-
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
@@ -2057,64 +1921,229 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-// Neighbouring apri points mostly belong to the same cluster, so the wave first reduces box and member count per
-// distinct cluster it holds and only one lane per cluster touches the global record (a 20 000-point cluster would
-// otherwise serialise 140 000 atomics on seven words).
-__global__ __launch_bounds__(256) void k_cc_bbox(Arena A) {
-    const int s = blockIdx.y;
+__global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, int from_apri) {
+    extern __shared__ int cc_smem[];
+    __shared__ int wsum[17];
+    __shared__ int n_extra_s;
+    const int s = blockIdx.x;
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
-    const int lane = threadIdx.x & 63;
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        const bool valid = i < n;
-        int r = -1;
-        uint32_t ox = 0, oy = 0, oz = 0;
-        if (valid) {
-            const scvod_apri& a = A.apri[(size_t)base + i];
-            r = A.pt_cluster[(size_t)base + i];
-            ox = f2ord(a.x);
-            oy = f2ord(a.y);
-            oz = f2ord(a.z);
-        }
-        bool todo = valid;
-        while (__any(todo)) {
-            const int first = __ffsll((long long)__ballot(todo)) - 1;
-            const int r0 = __shfl(r, first);
-            const bool mine = todo && (r == r0);
-            const int cnt = __popcll(__ballot(mine));
-            const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mny = wave_min_u32(mine ? oy : 0xffffffffu),
-                           mnz = wave_min_u32(mine ? oz : 0xffffffffu);
-            const uint32_t mxx = wave_max_u32(mine ? ox : 0u), mxy = wave_max_u32(mine ? oy : 0u),
-                           mxz = wave_max_u32(mine ? oz : 0u);
-            if (lane == first) {
-                uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + r0);
-                if (mnx < bb[0]) atomicMin(&bb[0], mnx);  // a stale read only costs a redundant atomic
-                if (mny < bb[1]) atomicMin(&bb[1], mny);
-                if (mnz < bb[2]) atomicMin(&bb[2], mnz);
-                if (mxx > bb[3]) atomicMax(&bb[3], mxx);
-                if (mxy > bb[4]) atomicMax(&bb[4], mxy);
-                if (mxz > bb[5]) atomicMax(&bb[5], mxz);
-                atomicAdd(&A.cl_count[(size_t)base + r0], cnt);
-            }
-            if (mine) todo = false;
+    const int nv = A.counts[s * 8 + 6];
+    if (n <= 0) return;
+    const int tid = threadIdx.x;
+    const int32_t* vbeg = A.vox_pt_begin + base + s;
+    const int32_t* vpts = A.vox_pts + base;
+    const int32_t* idx3 = A.apri_idx3 + base;
+    const int nw = (n + 31) >> 5;             // words of the per-slot bit arrays
+    // storage: LDS when the scan fits, the arena's per-point scratch otherwise (none of it is live during clustering)
+    const bool slots_lds = n <= kCcSlots;
+    int* vstart = slots_lds ? cc_smem + 2 * kCcNodes : A.pt_voxel + base;
+    int* rstart = slots_lds ? vstart + kCcSlots / 32 : A.tk_members + base;
+    int* prefix = slots_lds ? rstart + kCcSlots / 32 : A.tk_clusters + base;
+    int* extras = A.tk_uniq + base;            // slots of the extra run openers (rare: global scratch in both modes)
+    int* extra_of_slot = A.tk_mbegin + base;   // slot -> index in extras
+    if (tid == 0) n_extra_s = 0;
+    for (int w = tid; w < nw; w += kCcThreads) {
+        vstart[w] = 0;
+        rstart[w] = 0;
+    }
+    __syncthreads();
+    for (int v = tid; v < nv; v += kCcThreads) {
+        const int k = vbeg[v];
+        cc_set(vstart, k);
+        cc_set(rstart, k);
+    }
+    __syncthreads();
+    // runs inside a voxel: a slot whose triple differs from the previous slot's opens one (ssc.cpp:306-330 walks the
+    // voxel's points with their own triples; equal triples have equal neighbourhoods)
+    for (int k = tid; k < n; k += kCcThreads) {
+        if (cc_bit(vstart, k)) continue;
+        if (idx3[vpts[k]] != idx3[vpts[k - 1]]) {
+            const int e = atomicAdd(&n_extra_s, 1);
+            extras[e] = k;
+            extra_of_slot[k] = e;
+            cc_set(rstart, k);
         }
     }
-}
-
-// per point: 0 erased, 1 other, 2 car (labels are mapped by the fetch call)
-__global__ __launch_bounds__(256) void k_cc_type(DevParams P, Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int r = A.pt_cluster[(size_t)base + i];
-        const uint32_t* bb = A.cl_bbox + 6 * ((size_t)base + r);
-        const float mnx = ord2f(bb[0]), mny = ord2f(bb[1]), mnz = ord2f(bb[2]);
-        const float mxx = ord2f(bb[3]), mxy = ord2f(bb[4]), mxz = ord2f(bb[5]);
-        const int cnt = A.cl_count[(size_t)base + r];
+    // prefix[w] = voxel starts in the words before w: voxel of slot k = prefix[k >> 5] + popc(vstart word up to k) - 1
+    {
+        int run = 0;
+        for (int w0 = 0; w0 < nw; w0 += kCcThreads) {
+            const int w = w0 + tid;
+            const int c = (w < nw) ? __popc((unsigned)vstart[w]) : 0;
+            int total;
+            const int ex = block_excl_scan<kCcThreads>(c, total, wsum);
+            if (w < nw) prefix[w] = run + ex;
+            run += total;
+        }
+    }
+    __syncthreads();
+    const int n_extra = n_extra_s;
+    const int nn = nv + n_extra;
+    const bool nodes_lds = nn <= kCcNodes;
+    int* lkeys = cc_smem;
+    int* parent = nodes_lds ? cc_smem + kCcNodes : A.cc_parent + base;
+    int* touched = nodes_lds ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) : A.tk_npairs + base;
+    int* found = nodes_lds ? touched + kCcNodes / 32 : A.tk_hit + base;
+    CcKeys K;
+    K.nv = nv;
+    K.shift = 0;
+    while (((nv + (1 << K.shift) - 1) >> K.shift) > kCcNodes) ++K.shift;
+    K.ns = (nv + (1 << K.shift) - 1) >> K.shift;
+    K.lk = lkeys;
+    K.gk = (K.shift == 0) ? lkeys : A.vox_key + base;
+    for (int v = tid; v < K.ns; v += kCcThreads) lkeys[v] = A.vox_key[(size_t)base + ((size_t)v << K.shift)];
+    for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;
+    for (int w = tid; w < ((nn + 31) >> 5); w += kCcThreads) {
+        touched[w] = 0;
+        found[w] = 0;
+    }
+    __syncthreads();
+    auto voxel_of_slot = [&](int k) -> int {
+        const unsigned m = (unsigned)vstart[k >> 5] & (0xffffffffu >> (31 - (k & 31)));
+        return prefix[k >> 5] + __popc(m) - 1;
+    };
+    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
+    // the run that starts a voxel is node v, an extra run is node nv + e
+    for (int j = tid; j < nn; j += kCcThreads) {
+        const int k = (j < nv) ? vbeg[j] : extras[j - nv];
+        if (cc_search(K, parent, touched, j, idx3[vpts[k]], R, S, Az)) cc_set(found, j);
+    }
+    __syncthreads();
+    // every point of a touched voxel is merged with the voxel (ssc.cpp:316-345): the extra runs inside one join it
+    for (int e = tid; e < n_extra; e += kCcThreads) {
+        const int v = voxel_of_slot(extras[e]);
+        if (cc_bit(touched, v)) cc_union(parent, nv + e, v);
+    }
+    __syncthreads();
+    // canonical name of a component: the smallest apri index among the openers of its nodes (every other member of a
+    // node sits behind its opener in an ascending point list)
+    int* minpt = nodes_lds ? lkeys : A.cl_count + base;  // the key table is not needed any more
+    for (int j = tid; j < nn; j += kCcThreads) minpt[j] = 0x7fffffff;
+    __syncthreads();
+    for (int j = tid; j < nn; j += kCcThreads) {
+        const int k = (j < nv) ? vbeg[j] : extras[j - nv];
+        const int r = cc_find(parent, j);
+        atomicMin(&minpt[r], vpts[k]);
+    }
+    __syncthreads();
+    // flatten, then number the components 0 .. ncl-1 in node order: parent[j] becomes the compact id of j's component
+    int* flat = A.tk_cursor + base;                 // [nn] root of every node (arena scratch, nn <= n)
+    for (int j = tid; j < nn; j += kCcThreads) {
+        int r = j;
+        for (int q = parent[r]; q != r; q = parent[r]) r = q;  // read-only walk: the roots are final
+        flat[j] = r;
+    }
+    __syncthreads();
+    int* slot_cid = (int*)(A.tk_pairs + base);      // [n] compact id of the slot's point, -1 = a cluster of its own
+    int* rootcid = slot_cid + n;                    // [nn]
+    int* names = A.tk_nuniq + base;                 // [ncl] canonical name per compact id
+    int ncl = 0;
+    for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
+        const int j = j0 + tid;
+        const bool isroot = (j < nn) && flat[j] == j;
+        int total;
+        const int ex = block_excl_scan<kCcThreads>(isroot ? 1 : 0, total, wsum);
+        if (isroot) {
+            rootcid[j] = ncl + ex;
+            names[ncl + ex] = minpt[j];
+        }
+        ncl += total;
+    }
+    __syncthreads();
+    for (int j = tid; j < nn; j += kCcThreads) parent[j] = rootcid[flat[j]];
+    __syncthreads();
+    for (int k = tid; k < n; k += kCcThreads) {
+        const int p = vpts[k];
+        const int v = voxel_of_slot(k);
+        int cid;
+        if (cc_bit(touched, v)) {
+            cid = parent[v];
+        } else {
+            int o = k;  // opener of this slot's run: the closest run start at or before k (a voxel start is one)
+            {
+                int w = o >> 5;
+                unsigned m = (unsigned)rstart[w] & (0xffffffffu >> (31 - (o & 31)));
+                while (!m) m = (unsigned)rstart[--w];
+                o = (w << 5) + 31 - __clz(m);
+            }
+            const int node = (o == vbeg[v]) ? v : nv + extra_of_slot[o];
+            // a point that found nothing is a cluster of its own (ssc.cpp:347-353); the members of a run that found
+            // something joined what the opener joined
+            cid = cc_bit(found, node) ? parent[node] : -1;
+        }
+        slot_cid[k] = cid;
+        A.pt_cluster[(size_t)base + p] = cid >= 0 ? names[cid] : p;
+    }
+    __syncthreads();
+    // ---- bounding boxes + type of every cluster (refineClusterByBoundingBox ssc.cpp:437-467, recognize ssc.cpp:849-872)
+    // in the LDS the bit arrays just released; components beyond kCcBoxes take arena scratch with global atomics
+    uint32_t* bb = slots_lds ? (uint32_t*)(cc_smem + 2 * kCcNodes) : (uint32_t*)(A.cl_bbox + 7 * (size_t)base);
+    uint32_t* ov = (uint32_t*)(A.cl_bbox + 7 * (size_t)base) + (slots_lds ? 0 : 7 * kCcBoxes);  // overflow records, 7 words each
+    const int nbox = min(ncl, kCcBoxes);
+    for (int c = tid; c < ncl; c += kCcThreads) {
+        uint32_t* r = c < kCcBoxes ? bb + 7 * c : ov + 7 * (size_t)(c - kCcBoxes);
+        r[0] = r[1] = r[2] = 0xffffffffu;  // running minima (order-preserving encoding)
+        r[3] = r[4] = r[5] = 0u;           // running maxima
+        r[6] = 0u;                         // members
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63;
+        for (int k0 = 0; k0 < n; k0 += kCcThreads) {
+            const int k = k0 + tid;
+            int cid = -1;
+            uint32_t ox = 0, oy = 0, oz = 0;
+            if (k < n) {
+                cid = slot_cid[k];
+                const int p = vpts[k];
+                if (cid < 0) {  // one point: z extent 0 < 0.2 m, erased whatever toBeClass is (ssc.cpp:444)
+                    A.pt_type[(size_t)base + p] = 0;
+                    A.cl_count[(size_t)base + p] = 1;
+                } else if (from_apri) {  // apri_vec supplied by the caller: no input cloud on the device
+                    const scvod_apri& a = A.apri[(size_t)base + p];
+                    ox = f2ord(a.x);
+                    oy = f2ord(a.y);
+                    oz = f2ord(a.z);
+                } else {  // cloud_use[p] = input point apri_src[p]
+                    const float4 q = A.pts[base + A.apri_src[(size_t)base + p]];
+                    ox = f2ord(q.x);
+                    oy = f2ord(q.y);
+                    oz = f2ord(q.z);
+                }
+            }
+            // neighbouring slots mostly share the component: one lane per distinct component of the wave updates the box
+            bool todo = cid >= 0;
+            while (__any(todo)) {
+                const int first = __ffsll((long long)__ballot(todo)) - 1;
+                const int c0 = __shfl(cid, first);
+                const bool mine = todo && (cid == c0);
+                const int cnt = __popcll(__ballot(mine));
+                const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mny = wave_min_u32(mine ? oy : 0xffffffffu),
+                               mnz = wave_min_u32(mine ? oz : 0xffffffffu);
+                const uint32_t mxx = wave_max_u32(mine ? ox : 0u), mxy = wave_max_u32(mine ? oy : 0u), mxz = wave_max_u32(mine ? oz : 0u);
+                if (lane == first) {
+                    uint32_t* r = c0 < kCcBoxes ? bb + 7 * c0 : ov + 7 * (size_t)(c0 - kCcBoxes);
+                    atomicMin(&r[0], mnx);
+                    atomicMin(&r[1], mny);
+                    atomicMin(&r[2], mnz);
+                    atomicMax(&r[3], mxx);
+                    atomicMax(&r[4], mxy);
+                    atomicMax(&r[5], mxz);
+                    atomicAdd(&r[6], (uint32_t)cnt);
+                }
+                if (mine) todo = false;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < ncl; c += kCcThreads) {
+        uint32_t* r = c < kCcBoxes ? bb + 7 * c : ov + 7 * (size_t)(c - kCcBoxes);
+        const float mnx = ord2f(r[0]), mny = ord2f(r[1]), mnz = ord2f(r[2]);
+        const float mxx = ord2f(r[3]), mxy = ord2f(r[4]), mxz = ord2f(r[5]);
+        const int cnt = (int)r[6];
         const float diff_zf = mxz - mnz;
-        uint8_t t;
+        uint32_t t;
         if (mnz > 0.f || cnt < P.to_be_class || diff_zf < 0.2f) {
             t = 0;
         } else {
@@ -2126,7 +2155,15 @@ __global__ __launch_bounds__(256) void k_cc_type(DevParams P, Arena A) {
             else
                 t = 1;
         }
-        A.pt_type[(size_t)base + i] = t;
+        r[0] = t;
+        A.cl_count[(size_t)base + names[c]] = cnt;  // Cluster::occupy_pts.size(), kept at the cluster's canonical name
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += kCcThreads) {
+        const int cid = slot_cid[k];
+        if (cid < 0) continue;
+        const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+        A.pt_type[(size_t)base + vpts[k]] = (uint8_t)r[0];
     }
 }
 
@@ -2371,7 +2408,7 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute(const float* __restrict
     if (q < n_q) {
         nn_idx[q] = bi;
         nn_sq[q] = best;
-        within[q] = (bi >= 0 && best <= r2) ? 1 : 0;
+        within[q] = (bi >= 0 && best < r2) ? 1 : 0;
     }
 }
 
@@ -2582,38 +2619,13 @@ void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream
     hipLaunchKernelGGL(k_cls_from_lists, dim3((n_points + 2047) / 2048), dim3(256), 0, st, A, s);
 }
 
-void launch_cluster(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
+void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
-    dim3 g((A.max_scan_pts + 2047) / 2048, B);
-    TH_BEGIN("cc_init");
-    hipLaunchKernelGGL(k_cc_init, g, dim3(256), 0, st, A);
-    TH_END("cc_init");
-    TH_BEGIN("cc_link");
-    hipLaunchKernelGGL(k_cc_runs, g, dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_cc_link_starts<false>, dim3((A.max_scan_pts + 255) / 256, B), dim3(256), 0, st, P, A);
-    hipLaunchKernelGGL(k_cc_link_starts<true>, dim3((A.max_scan_pts + 255) / 256, B), dim3(256), 0, st, P, A);
-    hipLaunchKernelGGL(k_cc_link_rest, g, dim3(256), 0, st, A);
-    TH_END("cc_link");
-    TH_BEGIN("cc_join");
-    hipLaunchKernelGGL(k_cc_join, g, dim3(256), 0, st, A);
-    TH_END("cc_join");
-    TH_BEGIN("cc_flatten");
-    hipLaunchKernelGGL(k_cc_flatten, g, dim3(256), 0, st, A);
-    TH_END("cc_flatten");
-}
-
-void launch_cluster_types(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
-    const int B = A.n_scans;
-    if (B <= 0 || A.max_scan_pts <= 0) return;
-    dim3 g((A.max_scan_pts + 2047) / 2048, B);
-    TH_BEGIN("cc_bbox");
-    hipLaunchKernelGGL(k_cc_bbox_init, g, dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_cc_bbox, g, dim3(256), 0, st, A);
-    TH_END("cc_bbox");
-    TH_BEGIN("cc_type");
-    hipLaunchKernelGGL(k_cc_type, g, dim3(256), 0, st, P, A);
-    TH_END("cc_type");
+    hipFuncSetAttribute((const void*)k_cc_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcLdsBytes);
+    TH_BEGIN("cc_scan");
+    hipLaunchKernelGGL(k_cc_scan, dim3(B), dim3(kCcThreads), kCcLdsBytes, st, P, A, from_apri);
+    TH_END("cc_scan");
 }
 
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
@@ -2705,7 +2717,7 @@ __global__ __launch_bounds__(256) void k_nn_fill(NnGrid g, const float* __restri
 
 __global__ __launch_bounds__(256) void k_nn_query(NnGrid g, const float* __restrict__ map_xyz, const float* __restrict__ q_xyz,
                                                   int n_q, float r2, const int* start, const int* count, const int* entries,
-                                                  int32_t* nn_idx, float* nn_sq, uint8_t* within, int* todo, int* n_todo) {
+                                                  int32_t* nn_idx, float* nn_sq, uint8_t* within, int* todo, int* n_todo, int bounded) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n_q) return;
     const float qx = q_xyz[3 * (size_t)q], qy = q_xyz[3 * (size_t)q + 1], qz = q_xyz[3 * (size_t)q + 2];
@@ -2733,7 +2745,14 @@ __global__ __launch_bounds__(256) void k_nn_query(NnGrid g, const float* __restr
     if (bi >= 0 && best <= g.h2) {
         nn_idx[q] = bi;
         nn_sq[q] = best;
-        within[q] = best <= r2 ? 1 : 0;
+        within[q] = best < r2 ? 1 : 0;
+    } else if (bounded) {
+        // radius search (pcl radiusSearch, evaluate.cpp:95,104): the cell edge is >= radius, so a neighbour inside the radius
+        // would have been among the candidates; accepted above whenever it is closer than 0.99 cell edges
+        const bool in = bi >= 0 && best < r2;
+        nn_idx[q] = in ? bi : -1;
+        nn_sq[q] = in ? best : __builtin_huge_valf();
+        within[q] = in ? 1 : 0;
     } else {
         todo[atomicAdd(n_todo, 1)] = q;  // exact answer needs the whole map
     }
@@ -2779,14 +2798,14 @@ __global__ __launch_bounds__(kNnThreads) void k_nn_brute_list(const float* __res
         if (q >= 0) {
             nn_idx[q] = bi;
             nn_sq[q] = best;
-            within[q] = (bi >= 0 && best <= r2) ? 1 : 0;
+            within[q] = (bi >= 0 && best < r2) ? 1 : 0;
         }
     }
 }
 
 // work: ints, size >= 3 * buckets + n_map + n_q + 4 + (buckets / 1024 + 1)
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
-               float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work,
+               float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work, int bounded,
                hipStream_t st) {
     if (n_q <= 0) return;
     if (n_map <= 0 || buckets <= 0) {  // empty map: brute-force kernel writes idx -1
@@ -2819,7 +2838,8 @@ void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t 
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, st, start, block_tot, buckets);
     hipLaunchKernelGGL(k_nn_fill, dim3((n_map + 255) / 256), dim3(256), 0, st, g, map_xyz, n_map, start, cursor, entries);
     hipLaunchKernelGGL(k_nn_query, dim3((n_q + 255) / 256), dim3(256), 0, st, g, map_xyz, q_xyz, n_q, radius * radius, start,
-                       count, entries, nn_idx, nn_sq, within, todo, n_todo);
+                       count, entries, nn_idx, nn_sq, within, todo, n_todo, bounded);
+    if (bounded) return;
     hipLaunchKernelGGL(k_nn_brute_list, dim3(kPersistCUs * 2), dim3(kNnThreads), 0, st, map_xyz, n_map, q_xyz, todo, n_todo,
                        radius * radius, nn_idx, nn_sq, within);
 }

@@ -114,37 +114,81 @@ __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mas
 
 // static points of scan blockIdx.y: cloud_out (ground), cloud_eva_static (range/FOV rejects) and the apri points that are
 // not dynamic, moved to the world frame with explicit fp32 dot products (the arithmetic of Utility::transformCloud,
-// utility.h:400-405)
+// utility.h:400-405).  A tile of kMapTile consecutive list entries (neighbours in a list are neighbours in space: the
+// lists are patch-major / voxel-ordered) is first reduced in an LDS hash table, so that a cell hit by many points of the
+// tile costs ONE probe of the table in HBM instead of one per point (a street scan puts ~4 points into every cell it touches).
+constexpr int kMapTile = 2048, kMapLds = 4096;  // 2 slots per point: linear probing stays short
 __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
                                                         float inv_leaf, int with_ground, int with_rejected, int have_dyn,
                                                         unsigned long long* counters) {
+    __shared__ MapRec lt[kMapLds];
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n_g = with_ground ? A.counts[s * 8 + 1] : 0;
     const int n_r = with_rejected ? A.counts[s * 8 + 5] : 0;
     const int n_a = A.counts[s * 8 + 4];
     const int total = n_g + n_r + n_a;
+    if ((int)blockIdx.x * kMapTile >= total) return;
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = pose[12 * s + i];
     int dropped = 0;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
-        int src;
-        if (t < n_g) {
-            src = A.ground_idx[(size_t)base + t];
-        } else if (t < n_g + n_r) {
-            src = A.rejected_src[(size_t)base + (t - n_g)];
-        } else {
-            const int i = t - n_g - n_r;
-            if (have_dyn && A.pt_dyn[(size_t)base + i] == SCVOD_DYN_DYNAMIC) continue;
-            src = A.apri_src[(size_t)base + i];
+    for (int t0 = blockIdx.x * kMapTile; t0 < total; t0 += gridDim.x * kMapTile) {
+        for (int j = threadIdx.x; j < kMapLds; j += 256) {
+            lt[j].key = kEmpty;
+            lt[j].val = kEmpty;
         }
-        const float4 q = A.pts[base + src];
-        const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
-        const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
-        const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
-        unsigned long long key, val;
-        if (!map_encode(x, y, z, q.w, inv_leaf, key, val) || !map_insert(table, mask, key, val)) ++dropped;
+        __syncthreads();
+        constexpr int PER = kMapTile / 256;
+        int src[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {  // all index loads, then all point gathers, in flight together
+            const int t = t0 + u * 256 + threadIdx.x;
+            int v = -1;
+            if (t < n_g) {
+                v = A.ground_idx[(size_t)base + t];
+            } else if (t < n_g + n_r) {
+                v = A.rejected_src[(size_t)base + (t - n_g)];
+            } else if (t < total) {
+                const int i = t - n_g - n_r;
+                if (!(have_dyn && A.pt_dyn[(size_t)base + i] == SCVOD_DYN_DYNAMIC)) v = A.apri_src[(size_t)base + i];
+            }
+            src[u] = v;
+        }
+        float4 q[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) q[u] = A.pts[base + max(src[u], 0)];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (src[u] < 0) continue;
+            const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
+            const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
+            const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
+            unsigned long long key, val;
+            if (!map_encode(x, y, z, q[u].w, inv_leaf, key, val)) {
+                ++dropped;
+                continue;
+            }
+            unsigned h = (unsigned)map_mix(key) & (kMapLds - 1);
+            for (;;) {  // at most kMapTile keys in kMapLds slots: a free slot always exists
+                unsigned long long k = __hip_atomic_load(&lt[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (k == kEmpty) {
+                    k = atomicCAS(&lt[h].key, kEmpty, key);
+                    if (k == kEmpty) k = key;
+                }
+                if (k == key) {
+                    atomicMin(&lt[h].val, val);
+                    break;
+                }
+                h = (h + 1) & (kMapLds - 1);
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kMapLds; j += 256) {
+            const MapRec r = lt[j];
+            if (r.key != kEmpty && !map_insert(table, mask, r.key, r.val)) ++dropped;
+        }
+        __syncthreads();
     }
     if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
 }
@@ -291,7 +335,7 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
         MHIP(m, hipMemcpyAsync(m->d_pose, m->up_pose.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice, st));
     }
     if (max_pts > 0) {
-        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + kMapTile - 1) / kMapTile, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
                            (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, m->counters);
         MHIP(m, hipGetLastError());

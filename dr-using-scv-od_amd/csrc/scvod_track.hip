@@ -21,7 +21,6 @@
 namespace scvod {
 
 constexpr int kTkSamples = 8192;     // sampled successor keys staged in LDS (32 KB)
-constexpr int kTkBitWords = 16384;   // bitset over the successor's voxel table: 2^19 slots = SCVOD_MAX_SCAN_POINTS
 
 // lanes of a wave that hold the same key (neighbouring apri points / voxels mostly do): leader lane, rank inside the group
 // and group size, so that ONE lane per distinct key issues the atomic.  key < 0 = idle lane.
@@ -219,44 +218,46 @@ __global__ __launch_bounds__(256) void k_tk_probe(DevParams P, Arena A, TrackBat
     }
 }
 
-__device__ __forceinline__ int block_min_128(int v, int* red) {  // 128 threads; red: LDS int[2]
+__device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return min(red[0], red[1]);
+    return v;
 }
-__device__ __forceinline__ int block_sum_128(int v, int* red) {
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1];
+    return v;
 }
 
-// One workgroup per car cluster (persistent over the clusters of its scan): bitset of the hit slots -> sorted unique
-// list (sampleVec without a sort), grouped by label -> remap_name, then the state rule.
-__global__ __launch_bounds__(128) void k_tk_decide(Arena A, TrackBatch J) {
-    __shared__ uint32_t bits[kTkBitWords];
-    __shared__ int wsum[3];
-    __shared__ int red[2];
+// One WAVE per car cluster (persistent over the clusters of its scan), no workgroup barriers: a private bitset over the
+// successor's table in LDS turns the cluster's hits into the sorted unique list (sampleVec without a sort), the list is
+// grouped by label -> remap_name, then the state rule.  `words` = LDS words per wave (covers the largest table).
+template <int kTkWaves>
+__global__ __launch_bounds__(64 * kTkWaves) void k_tk_decide(Arena A, TrackBatch J, int words) {
+    extern __shared__ uint32_t tk_bits[];
     const int s = blockIdx.y;
     const int ncl = A.tk_scan[s * 4 + 0];
-    if ((int)blockIdx.x >= ncl) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int first = blockIdx.x * kTkWaves + wave, stride = gridDim.x * kTkWaves;
+    if (first >= ncl) return;
     const NextTable N = next_table_of(A, J, s);
-    if (N.nv < 0) return;  // last scan of a sequence: no tracking call, states stay -1
+    if (N.nv < 0) return;  // last scans of a sequence: no tracking call, states stay -1
     const int base = A.scan_off[s];
-    const int nw = min((N.nv + 31) >> 5, kTkBitWords);
-    for (int w = threadIdx.x; w < nw; w += 128) bits[w] = 0u;
-    __syncthreads();
-    for (int ord = blockIdx.x; ord < ncl; ord += gridDim.x) {
+    uint32_t* bits = tk_bits + (size_t)wave * words;
+    const int nw = min((N.nv + 31) >> 5, words);
+    for (int w = lane; w < nw; w += 64) bits[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int ord = first; ord < ncl; ord += stride) {
         const int root = A.tk_clusters[(size_t)base + ord];
         const int k0 = A.tk_mbegin[(size_t)base + root];
         const int m = A.cl_count[(size_t)base + root];
         int wlo = 0x7fffffff, whi = -1;
-        for (int j = threadIdx.x; j < m; j += 128) {
+        for (int j = lane; j < m; j += 64) {
             const int slot = A.tk_hit[(size_t)base + k0 + j];
             if (slot >= 0 && (slot >> 5) < nw) {
                 atomicOr(&bits[slot >> 5], 1u << (slot & 31));
@@ -264,42 +265,42 @@ __global__ __launch_bounds__(128) void k_tk_decide(Arena A, TrackBatch J) {
                 whi = max(whi, slot >> 5);
             }
         }
-        wlo = block_min_128(wlo, red);
-        whi = -block_min_128(-whi, red);
+        wlo = wave_min_i(wlo);
+        whi = wave_max_i(whi);
         // sorted unique slots of the cluster, only over the words it touched; the words are cleared on the way
-        int run = 0;
-        for (int w0 = wlo; w0 <= whi; w0 += 128) {
-            const int w = w0 + threadIdx.x;
+        int U = 0;
+        for (int w0 = wlo; w0 <= whi; w0 += 64) {
+            const int w = w0 + lane;
             uint32_t word = 0u;
             if (w <= whi) {
                 word = bits[w];
                 bits[w] = 0u;
             }
-            int total;
-            const int ex = block_excl_scan<128>(__popc(word), total, wsum);
-            int o = k0 + run + ex;
+            const int c = __popc(word);
+            const int inc = wave_incl_scan(c);
+            int o = k0 + U + inc - c;
             while (word) {
                 const int b = __ffs(word) - 1;
                 word &= word - 1;
                 A.tk_uniq[(size_t)base + o++] = (w << 5) + b;
             }
-            run += total;
+            U += __shfl(inc, 63);
         }
-        __syncthreads();  // tk_uniq of this cluster is complete (global writes of this block, read back below)
-        const int U = run;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // remap_name: labels in ascending order with the number of unique voxels each
         int npairs = 0, one_count = 0, one_nvox = 1, one_type = 0;
         int cur = -1;
         for (;;) {
             int mn = 0x7fffffff;
-            for (int j = threadIdx.x; j < U; j += 128) {
+            for (int j = lane; j < U; j += 64) {
                 const int lab = N.tab[A.tk_uniq[(size_t)base + k0 + j]].y;
                 if (lab > cur) mn = min(mn, lab);
             }
-            mn = block_min_128(mn, red);
+            mn = wave_min_i(mn);
             if (mn == 0x7fffffff) break;
             int cnt = 0, nvx = 0, typ = 0;
-            for (int j = threadIdx.x; j < U; j += 128) {
+            for (int j = lane; j < U; j += 64) {
                 const int4 rec = N.tab[A.tk_uniq[(size_t)base + k0 + j]];
                 if (rec.y == mn) {
                     ++cnt;
@@ -307,18 +308,19 @@ __global__ __launch_bounds__(128) void k_tk_decide(Arena A, TrackBatch J) {
                     typ = rec.w;
                 }
             }
-            const int any_nvx = -block_min_128(-nvx, red), any_typ = -block_min_128(-typ, red);
-            cnt = block_sum_128(cnt, red);
-            if (threadIdx.x == 0) A.tk_pairs[(size_t)base + k0 + npairs] = make_int2(mn, cnt);
+            nvx = wave_max_i(nvx);
+            typ = wave_max_i(typ);
+            cnt = wave_sum_i(cnt);
+            if (lane == 0) A.tk_pairs[(size_t)base + k0 + npairs] = make_int2(mn, cnt);
             if (npairs == 0) {
                 one_count = cnt;
-                one_nvox = any_nvx;
-                one_type = any_typ;
+                one_nvox = nvx;
+                one_type = typ;
             }
             ++npairs;
             cur = mn;
         }
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             int state;
             if (npairs == 0) {
                 state = 1;  // nothing of the successor under the transformed cluster (ssc.cpp:1323-1326)
@@ -339,7 +341,6 @@ __global__ __launch_bounds__(128) void k_tk_decide(Arena A, TrackBatch J) {
                 atomicAdd(&A.tk_scan[s * 4 + 3], m);
             }
         }
-        __syncthreads();
     }
 }
 
@@ -374,16 +375,21 @@ __global__ __launch_bounds__(256) void k_tk_export(Arena A, int s, int4* out, lo
 #define TH_END(name) \
     if (th) th(tu, name, 0)
 
-void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, hipStream_t st, TimerHook th,
-                        void* tu) {
+// phases: 1 = successor tables only (labels, cluster sizes: what scvod_batch_export_table hands to another shard),
+// 2 = member lists, probe, decision, per-point bytes (needs phase 1 of the same clustering), 3 = both
+void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
+                        TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
-    TH_BEGIN("tk_labels");
-    hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_tk_voxlabel, g, dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_tk_voxfill, g, dim3(256), 0, st, A);
-    TH_END("tk_labels");
+    if (phases & 1) {
+        TH_BEGIN("tk_labels");
+        hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A);
+        hipLaunchKernelGGL(k_tk_voxlabel, g, dim3(256), 0, st, A);
+        hipLaunchKernelGGL(k_tk_voxfill, g, dim3(256), 0, st, A);
+        TH_END("tk_labels");
+    }
+    if (!(phases & 2)) return;
     TH_BEGIN("tk_members");
     hipLaunchKernelGGL(k_tk_members, dim3(B), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_tk_scatter, g, dim3(256), 0, st, A);
@@ -391,8 +397,20 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     TH_BEGIN("tk_probe");
     hipLaunchKernelGGL(k_tk_probe, dim3((A.max_scan_pts + 4095) / 4096, B), dim3(256), 0, st, P, A, J, from_apri);
     TH_END("tk_probe");
+    // LDS words of a wave's bitset: a table holds at most max_scan_pts voxels
+    const int words = (A.max_scan_pts + 31) / 32 + 1;  // SCVOD_MAX_SCAN_POINTS = 2^19 slots = 64 KB: one wave always fits
+    const size_t per_wave = (size_t)words * 4;
     TH_BEGIN("tk_decide");
-    hipLaunchKernelGGL(k_tk_decide, dim3(32, B), dim3(128), 0, st, A, J);
+    if (4 * per_wave <= 64 * 1024) {  // two workgroups per CU
+        hipFuncSetAttribute((const void*)k_tk_decide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * per_wave));
+        hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * per_wave, st, A, J, words);
+    } else if (2 * per_wave <= 150 * 1024) {
+        hipFuncSetAttribute((const void*)k_tk_decide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * per_wave));
+        hipLaunchKernelGGL(k_tk_decide<2>, dim3(16, B), dim3(128), 2 * per_wave, st, A, J, words);
+    } else {
+        hipFuncSetAttribute((const void*)k_tk_decide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave);
+        hipLaunchKernelGGL(k_tk_decide<1>, dim3(32, B), dim3(64), per_wave, st, A, J, words);
+    }
     TH_END("tk_decide");
     TH_BEGIN("tk_dyn");
     hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A);

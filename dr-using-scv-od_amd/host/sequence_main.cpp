@@ -1,61 +1,83 @@
-// sequence_main.cpp -- SSC::segDF-shaped driver (src/ssc.cpp:1428-1452) on the facade: for every scan
-// process() -> segmentGpu() -> keep the Frame; then tracking(frame[i], frame[i+1]) along the chain.
-// Writes, per scan, the points of the clusters that ended up dynamic (state == 1).
-//   usage: scvod_sequence <config.yaml> <dir with 0.f32 1.f32 ... and poses.txt> <n_scans> <out_dir>
+// sequence_main.cpp -- the reference's node main (src/main.cpp:3-14: construct SSC, call segDF) on the facade, for a
+// KITTI-layout sequence named by the YAML file's session/ keys (data_path_, label_path_, pose_path_, start_, end_) and
+// common/skip_.  Writes, per loaded frame, the points of the clusters that ended up dynamic (state == 1).
+//   usage: scvod_sequence <config.yaml> <out_dir> [--data DIR] [--labels DIR] [--poses FILE] [--start S] [--end E] [--skip K]
+//          scvod_sequence --poses-only <config.yaml> [--poses FILE] [--start S] [--end E] [--skip K]   (no GPU needed)
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 
 #include "ssc.h"
 
-static pcl::PointCloud<pcl::PointXYZI>::Ptr load(const std::string& path) {
-    std::ifstream in(path, std::ios::binary);
-    in.seekg(0, std::ios::end);
-    size_t n = (size_t)in.tellg() / 16;
-    in.seekg(0);
-    std::vector<float> v(n * 4);
-    in.read((char*)v.data(), n * 16);
-    pcl::PointCloud<pcl::PointXYZI>::Ptr c(new pcl::PointCloud<pcl::PointXYZI>());
-    c->points.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        c->points[i].x = v[4 * i];
-        c->points[i].y = v[4 * i + 1];
-        c->points[i].z = v[4 * i + 2];
-        c->points[i].intensity = v[4 * i + 3];
+struct PoseOnly : public Utility {  // getPose without a device: the pose maths live in Utility
+    std::vector<Pose> pose_vec;
+    void run() {
+        std::ifstream pose_file(pose_path);
+        if (!pose_file) throw std::runtime_error("cannot open " + pose_path);
+        std::string line;
+        int count = 0;
+        while (std::getline(pose_file, line)) {
+            if (count < start || (count - start) % skip != 0) {
+                count++;
+                continue;
+            }
+            if (count >= end) break;
+            float pose_v[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            std::istringstream is(line);
+            std::string tok;
+            int l = 0;
+            while (l < 12 && is >> tok) pose_v[l++] = (float)std::atof(tok.c_str());
+            Pose pose;
+            float v2c[4][4];
+            if (!kittiPose(pose_v, pose, v2c)) throw std::runtime_error("ssc/tr_ is singular");
+            count++;
+            pose_vec.emplace_back(pose);
+        }
     }
-    return c;
+};
+
+static void overrides(Utility& u, int argc, char** argv, int from) {
+    for (int a = from; a + 1 < argc; a += 2) {
+        const std::string k = argv[a], v = argv[a + 1];
+        if (k == "--data") u.data_path = v;
+        else if (k == "--labels") u.label_path = v;
+        else if (k == "--poses") u.pose_path = v;
+        else if (k == "--start") u.start = std::atoi(v.c_str());
+        else if (k == "--end") u.end = std::atoi(v.c_str());
+        else if (k == "--skip") u.skip = std::atoi(v.c_str());
+        else throw std::invalid_argument("unknown option " + k);
+    }
 }
 
 int main(int argc, char** argv) {
-    if (argc < 5) {
-        std::cerr << "usage: scvod_sequence <config.yaml> <dir> <n_scans> <out_dir>\n";
-        return 2;
-    }
     try {
-        const std::string dir = argv[2], out = argv[4];
-        const int n_scans = std::atoi(argv[3]);
+        if (argc >= 3 && std::strcmp(argv[1], "--poses-only") == 0) {
+            PoseOnly p;
+            if (!p.loadYaml(argv[2])) throw std::invalid_argument(std::string("cannot read ") + argv[2]);
+            overrides(p, argc, argv, 3);
+            p.run();
+            std::cout.precision(9);
+            for (auto& q : p.pose_vec) std::cout << q.x << " " << q.y << " " << q.z << " " << q.roll << " " << q.pitch << " " << q.yaw << "\n";
+            return 0;
+        }
+        if (argc < 3) {
+            std::cerr << "usage: scvod_sequence <config.yaml> <out_dir> [--data DIR] [--labels DIR] [--poses FILE] [--start S] [--end E] [--skip K]\n";
+            return 2;
+        }
+        const std::string out = argv[2];
         SSC ssc(argv[1]);
-        std::vector<Pose> pose_vec(n_scans);
-        {
-            std::ifstream pf(dir + "/poses.txt");
-            for (int i = 0; i < n_scans; ++i) pf >> pose_vec[i].x >> pose_vec[i].y >> pose_vec[i].z >> pose_vec[i].roll >> pose_vec[i].pitch >> pose_vec[i].yaw;
-        }
-        for (int i = 0; i < n_scans; ++i) {  // hot loop #1 (ssc.cpp:1435-1445)
-            auto cloud = load(dir + "/" + std::to_string(i) + ".f32");
-            ssc.process(cloud);
-            ssc.segmentGpu();
-            ssc.frame_set.emplace_back(ssc.frame_ssc);
-            ssc.reset();
-            SSC::id += ssc.skip;
-        }
+        overrides(ssc, argc, argv, 3);
+        ssc.segDF();
         int dyn_total = 0;
-        for (int i = 0; i + 1 < n_scans; ++i) {  // hot loop #2, a sequential chain (ssc.cpp:1450-1452)
-            ssc.tracking(ssc.frame_set[i], ssc.frame_set[i + 1], pose_vec[i], pose_vec[i + 1]);
-            dyn_total += ssc.dynamic_num_last;
-        }
-        for (int i = 0; i < n_scans; ++i) {
-            std::ofstream o(out + "/" + std::to_string(i) + "_dynamic.f32", std::ios::binary);
+        const int n = (int)ssc.frame_set.size();
+        for (int i = 0; i < n; ++i) {
+            {  // the frame as the path saw it (after the loader's filter + VoxelGrid)
+                std::ofstream oc(out + "/" + std::to_string(ssc.frame_set[i].id) + "_cloud.f32", std::ios::binary);
+                for (auto& p : ssc.cloud_vec[i]->points) oc.write((const char*)&p, 16);
+            }
+            std::ofstream o(out + "/" + std::to_string(ssc.frame_set[i].id) + "_dynamic.f32", std::ios::binary);
             int cars = 0, dyn = 0;
             for (auto& kv : ssc.frame_set[i].cluster_set) {
                 const Cluster& c = kv.second;
@@ -65,9 +87,11 @@ int main(int argc, char** argv) {
                     for (int p : c.occupy_pts) o.write((const char*)&ssc.frame_set[i].cloud_use->points[p], 16);
                 }
             }
-            std::cout << "scan " << i << " clusters " << ssc.frame_set[i].cluster_set.size() << " tracked " << cars << " dynamic " << dyn << "\n";
+            dyn_total += dyn;
+            std::cout << "frame " << ssc.frame_set[i].id << " points " << ssc.cloud_vec[i]->points.size() << " clusters " << ssc.frame_set[i].cluster_set.size()
+                      << " tracked " << cars << " dynamic " << dyn << "\n";
         }
-        std::cout << "dynamic_total " << dyn_total << "\n";
+        std::cout << "frames " << n << " dynamic_total " << dyn_total << "\n";
     } catch (const std::exception& e) {
         std::cerr << "scvod_sequence failed: " << e.what() << "\n";
         return 1;

@@ -4,9 +4,15 @@
 // sequential label bookkeeping of SSC::tracking (src/ssc.cpp:1323-1421) on the host.
 #include "ssc.h"
 
+#include <dirent.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
 #include <stdexcept>
 
 int SSC::id = 0;
@@ -298,4 +304,97 @@ void SSC::tracking(Frame& frame_pre_, Frame& frame_next_, Pose pose_pre_, Pose p
         }
     }
     dynamic_num_last = dynamic_num;
+}
+
+// ---- sequence loaders + driver (KITTI layout: velodyne/*.bin, labels/*.label, poses.txt) -------------------------------
+namespace {
+// fileSort (ssc.cpp:12-22): numeric order of the file stems
+int stem_number(const std::string& path) {
+    const size_t a = path.find_last_of('/') + 1;
+    const std::string file = path.substr(a);
+    return std::atoi(file.substr(0, file.rfind('.')).c_str());
+}
+std::vector<std::string> list_sorted(const std::string& dir) {
+    std::vector<std::string> names;
+    DIR* d = opendir(dir.c_str());
+    if (!d) throw std::runtime_error("cannot open directory " + dir);
+    while (dirent* e = readdir(d)) {
+        const std::string n = e->d_name;
+        if (n == "." || n == "..") continue;
+        names.push_back(dir + (dir.empty() || dir.back() == '/' ? "" : "/") + n);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end(), [](const std::string& x, const std::string& y) { return stem_number(x) < stem_number(y); });
+    return names;
+}
+}  // namespace
+
+// SSC::getPose, KITTI branch (ssc.cpp:930-989): line `count` of poses.txt is used when count >= start, count < end and
+// (count - start) % skip == 0; 12 numbers per line, split at blanks and read with atof
+void SSC::getPose() {
+    if (is_pcd) throw std::runtime_error("getPose: the .pcd pose branch (is_pcd_) needs PCL and is not provided");
+    std::ifstream pose_file(pose_path);
+    if (!pose_file) throw std::runtime_error("cannot open " + pose_path);
+    std::string line;
+    int count = 0;
+    while (std::getline(pose_file, line)) {
+        if (count < start || (count - start) % skip != 0) {
+            count++;
+            continue;
+        }
+        if (count >= end) break;
+        float pose_v[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        std::istringstream is(line);
+        std::string tok;
+        int l = 0;
+        while (l < 12 && is >> tok) pose_v[l++] = (float)std::atof(tok.c_str());
+        Pose pose;
+        float v2c[4][4];
+        if (!kittiPose(pose_v, pose, v2c)) throw std::runtime_error("ssc/tr_ is singular");
+        trans_vec.emplace_back(&v2c[0][0], &v2c[0][0] + 16);
+        count++;
+        pose_vec.emplace_back(pose);
+    }
+}
+
+// SSC::getCloud, KITTI branch (ssc.cpp:1021-1125): scans start, start + skip, ... < end of the sorted .bin / .label lists;
+// label & 0xFFFF in {0, 1} dropped, intensity * max_intensity, VoxelGrid 0.08 m (filterAndDownsample, on the GPU).  The
+// reference's range test `dis >= min_dis || dis <= max_dis` (ssc.cpp:1094) is always true and keeps every point.
+void SSC::getCloud() {
+    if (is_pcd) throw std::runtime_error("getCloud: the .pcd branch (is_pcd_) needs PCL and is not provided");
+    const std::vector<std::string> bin_name = list_sorted(data_path), label_name = list_sorted(label_path);
+    if (bin_name.size() != label_name.size()) throw std::runtime_error("bins or labels load error");
+    const int all = (int)bin_name.size();
+    if (start < 0 || end > all) throw std::runtime_error("the start or end index set error");
+    for (int i = start; i < end; i = i + skip) {
+        std::ifstream in_label(label_name[i], std::ios::binary);
+        if (!in_label.is_open()) throw std::runtime_error("can't open " + label_name[i]);
+        in_label.seekg(0, std::ios::end);
+        const uint32_t num_points = (uint32_t)(in_label.tellg() / sizeof(uint32_t));
+        in_label.seekg(0, std::ios::beg);
+        std::vector<uint32_t> values_label(num_points);
+        in_label.read((char*)values_label.data(), num_points * sizeof(uint32_t));
+        std::ifstream in_cloud(bin_name[i], std::ios::binary);
+        if (!in_cloud.is_open()) throw std::runtime_error("can't open " + bin_name[i]);
+        std::vector<float> values_cloud(4 * (size_t)num_points);
+        in_cloud.read((char*)values_cloud.data(), 4 * (size_t)num_points * sizeof(float));
+        cloud_vec.emplace_back(filterAndDownsample(values_cloud, values_label));
+    }
+}
+
+// SSC::segDF (ssc.cpp:1428-1452): load, per scan process -> segment -> recognize -> keep the frame, then the tracking
+// chain.  segment() / recognize() are the GPU stand-in segmentGpu() here (curved-voxel clustering + box rules); a build
+// that links the reference's PCL host code calls its own segment() / recognize() instead.
+void SSC::segDF() {
+    id = start;
+    getPose();
+    getCloud();
+    for (auto& cloud : cloud_vec) {
+        process(cloud);
+        segmentGpu();
+        frame_set.emplace_back(frame_ssc);
+        reset();
+        id += skip;
+    }
+    for (int i = 0; i + 1 < (int)frame_set.size(); i++) tracking(frame_set[i], frame_set[i + 1], pose_vec[i], pose_vec[i + 1]);
 }

@@ -27,6 +27,9 @@ class SSC : public Utility {
     pcl::PointCloud<pcl::PointXYZI>::Ptr cloud_eva_static;             // ssc.h:45
     int name = 0;                                                      // ssc.h:50
     std::vector<Frame> frame_set;                                      // ssc.h:51
+    std::vector<pcl::PointCloud<pcl::PointXYZI>::Ptr> cloud_vec;       // ssc.h:20 (what getCloud loads)
+    std::vector<Pose> pose_vec;                                        // ssc.h:21
+    std::vector<std::vector<float>> trans_vec;                         // ssc.h:22: velo_to_cam per loaded pose, row-major 4x4
 
     ~SSC();
     // The reference's SSC() reads the ROS parameter server; here the YAML file is named explicitly.
@@ -42,6 +45,11 @@ class SSC : public Utility {
     void makeApriVec(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_);
     void makeHashCloud(const std::vector<PointAPRI>& apriIn_);
     void tracking(Frame& frame_pre_, Frame& frame_next_, Pose pose_pre_, Pose pose_next_);
+    // sequence driver and its loaders (ssc.h:93-97; KITTI branch of ssc.cpp:913-992, 1021-1125, 1428-1452).  The .pcd
+    // branch (is_pcd_) needs PCL's reader and is not provided; the evaluation copies (rgb / ori clouds) are not produced.
+    void getPose();
+    void getCloud();
+    void segDF();
     // GPU stand-in for segment() + recognize() when the reference's PCL host code is not linked: curved-voxel
     // clustering (ssc.cpp:299-393) + bounding-box refine / recognise rules (ssc.cpp:437-467, 849-872);
     // no intensity merge, no region growing (building and tree both become `tree`).

@@ -4,6 +4,7 @@
 // of the ROS parameter server, so the same config/*.yaml files work with or without ROS.
 #ifndef SCVOD_HOST_UTILITY_H_
 #define SCVOD_HOST_UTILITY_H_
+#include <cmath>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -59,6 +60,80 @@ class Utility {
     float intensity_diff = 50, intensity_cov = 20, occupancy = 0.6f;
     int building = 0, tree = 1, car = 2;
     std::vector<float> tr_v;
+    float tr[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};  // velodyne -> camera extrinsic (utility.h:244,316)
+
+    // include/utility.h:488-505 (float arithmetic; the unqualified sqrt / atan2 on floats are the float overloads)
+    static void rotationMatrixToEulerAngles(const float R[3][3], float rpy[3]) {
+        const float sy = std::sqrt(R[0][0] * R[0][0] + R[1][0] * R[1][0]);
+        const bool singular = sy < 1e-6;
+        if (!singular) {
+            rpy[0] = std::atan2(R[2][1], R[2][2]);
+            rpy[1] = std::atan2(-R[2][0], sy);
+            rpy[2] = std::atan2(R[1][0], R[0][0]);
+        } else {
+            rpy[0] = std::atan2(-R[1][2], R[1][1]);
+            rpy[1] = std::atan2(-R[2][0], sy);
+            rpy[2] = 0;
+        }
+    }
+    // A^-1 for the 4x4 of `tr.inverse()` (ssc.cpp:967): adjugate over determinant in float.  Eigen 3.3 picks an SSE
+    // kernel for Matrix4f on x86; its rounding differs in the last bits (parity unpinned, tolerance 1e-5 relative).
+    static bool inverse4(const float m[4][4], float inv[4][4]) {
+        const float* a = &m[0][0];
+        float o[16];
+        o[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+        o[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+        o[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+        o[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+        o[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+        o[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+        o[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+        o[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+        o[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+        o[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+        o[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+        o[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+        o[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+        o[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+        o[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+        o[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+        const float det = a[0] * o[0] + a[1] * o[4] + a[2] * o[8] + a[3] * o[12];
+        if (det == 0.f) return false;
+        const float id = 1.0f / det;
+        for (int i = 0; i < 16; ++i) (&inv[0][0])[i] = o[i] * id;
+        return true;
+    }
+    static void mul4(const float a[4][4], const float b[4][4], float c[4][4]) {
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float acc = a[i][0] * b[0][j];
+                for (int k = 1; k < 4; ++k) acc += a[i][k] * b[k][j];
+                c[i][j] = acc;
+            }
+    }
+    // one line of a KITTI poses.txt (3x4 camera pose, row-major) -> the velodyne-frame Pose of ssc.cpp:962-989:
+    // velo_to_cam = tr^-1 * cam * tr, translation from its last column, roll / pitch / yaw from its rotation
+    bool kittiPose(const float pose_v[12], Pose& pose, float velo_to_cam[4][4]) const {
+        float cam[4][4] = {{pose_v[0], pose_v[1], pose_v[2], pose_v[3]},
+                           {pose_v[4], pose_v[5], pose_v[6], pose_v[7]},
+                           {pose_v[8], pose_v[9], pose_v[10], pose_v[11]},
+                           {0.f, 0.f, 0.f, 1.f}};
+        float ti[4][4], t1[4][4];
+        if (!inverse4(tr, ti)) return false;
+        mul4(ti, cam, t1);
+        mul4(t1, tr, velo_to_cam);
+        pose.x = velo_to_cam[0][3];
+        pose.y = velo_to_cam[1][3];
+        pose.z = velo_to_cam[2][3];
+        float R[3][3], rpy[3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i][j] = velo_to_cam[i][j];
+        rotationMatrixToEulerAngles(R, rpy);
+        pose.roll = rpy[0];
+        pose.pitch = rpy[1];
+        pose.yaw = rpy[2];
+        return true;
+    }
 
     virtual ~Utility() {}
     Utility() {}
@@ -108,6 +183,8 @@ class Utility {
         y.param<int>("ssc/tree_", tree, 1);
         y.param<int>("ssc/car_", car, 2);
         tr_v = y.floats("ssc/tr_");
+        if (tr_v.size() == 16)  // Eigen::Map<RowMajor 4x4> (utility.h:316)
+            for (int i = 0; i < 16; ++i) tr[i / 4][i % 4] = tr_v[i];
         return true;
     }
     scvod_params toScvodParams() const {

@@ -1,0 +1,61 @@
+"""PCIe-inclusive throughput of the path (bench.py `extras.ingest`): the sequence starts in pinned HOST memory and travels
+to the GPU in chunks through scvod_sequence_ingest (double-buffered H2D on a copy stream, overlapped with the previous
+chunk's kernels); per chunk the consumers of bench.py's step are enqueued from the chunk callback.  Never `value`."""
+import ctypes as C
+import time
+
+import numpy as np
+
+
+def measure(scvod_py, P, d_pts, offs, poses, device, scans=1024, chunk=128):
+    import torch
+    n_sc = min(int(scans), len(offs) - 1)
+    o = np.ascontiguousarray(offs[: n_sc + 1], np.int32)
+    n_pts = int(o[-1])
+    host = torch.empty((n_pts, 4), dtype=torch.float32).pin_memory()
+    host.copy_(d_pts[:n_pts])
+    torch.cuda.synchronize()
+    lib = scvod_py.load_lib()
+    lib.scvod_sequence_ingest.restype = C.c_int
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
+    lib.scvod_sequence_ingest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, CB, C.c_void_p]
+    max_chunk = max(int(o[min(k + chunk, n_sc)] - o[k]) for k in range(0, n_sc, chunk))
+    ctx = scvod_py.Ctx(P, max_points_total=max_chunk + 1024, max_scans=chunk, device=device)
+    T = np.zeros((chunk, 12), np.float32)
+    Tall = np.zeros((n_sc, 12), np.float32)
+    for s in range(n_sc - 1):
+        Tall[s] = ctx.pose_delta(poses[s], poses[s + 1])
+
+    def consumers(user, h, first, n, stream):
+        # clustering -> box rules -> differencing inside the chunk (a chunk's last scan has its successor in the next chunk:
+        # a resident job hands that table over, see bench.py; here it is left undecided)
+        if lib.scvod_batch_cluster(h, stream, 0) or lib.scvod_batch_cluster_types(h, stream, 0):
+            return -3
+        T[:n] = Tall[first:first + n]
+        T[n - 1] = 0
+        return lib.scvod_batch_track(h, T.ctypes.data_as(C.c_void_p), None, None, 0, stream, 0)
+
+    out = {}
+    for name, cb in (("process_only", CB(lambda *a: 0)), ("full_chain", CB(consumers))):
+        times = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            rc = lib.scvod_sequence_ingest(ctx.h, C.c_void_p(host.data_ptr()), o.ctypes.data_as(C.c_void_p), n_sc, chunk, 0, cb, None)
+            times.append(time.perf_counter() - t0)
+            if rc != 0:
+                raise RuntimeError(f"scvod_sequence_ingest: status {rc}: {lib.scvod_last_error(ctx.h).decode()}")
+        out[name + "_scans_per_s"] = n_sc / min(times[1:])
+    # the PCIe ceiling on this box: the same bytes, pinned host -> device, nothing else
+    dst = torch.empty_like(d_pts[:n_pts])
+    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter()
+        dst.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    gbs = n_pts * 16 / best / 1e9
+    out.update({"scans": n_sc, "chunk_scans": chunk, "bytes_per_scan": n_pts * 16 / n_sc, "h2d_GBps": gbs, "h2d_bound_scans_per_s": n_sc / best,
+                "fraction_of_h2d_bound": out["full_chain_scans_per_s"] / (n_sc / best)})
+    ctx.close()
+    return out

@@ -21,7 +21,7 @@ def preservation_rejection(gt_xyz, gt_label, est_xyz, est_label, nn_fn, voxelsiz
     idx, sqd, _ = nn_fn(np.asarray(est_xyz, np.float32), np.asarray(gt_xyz, np.float32), voxelsize)
     dist = np.sqrt(sqd.astype(np.float64))
     inl = dist < voxelsize * np.sqrt(3) / 2
-    est_dyn_at = est_dyn[idx]
+    est_dyn_at = est_dyn[np.maximum(idx, 0)]  # idx -1 (a radius-bounded search found nothing) is never an inlier
     num_static_preserved = int(np.count_nonzero(inl & ~gt_dyn & ~est_dyn_at))
     num_dynamic_preserved = int(np.count_nonzero(inl & gt_dyn & est_dyn_at))
     n_static, n_dynamic = int((~gt_dyn).sum()), int(gt_dyn.sum())

@@ -124,6 +124,7 @@ def load_lib():
         "scvod_batch_track": (C.c_int, [vp, vp, vp, vp, i32, vp, i32]),
         "scvod_batch_fetch_track": (C.c_int, [vp, i32, C.POINTER(TrackResult)]),
         "scvod_batch_export_table": (C.c_int, [vp, i32, vp, i64, vp]),
+        "scvod_batch_track_tables": (C.c_int, [vp, vp]),
         "scvod_map_create": (C.c_int, [C.c_int, i64, f32, C.POINTER(vp)]),
         "scvod_map_destroy": (None, [vp]),
         "scvod_map_last_error": (C.c_char_p, [vp]),
@@ -137,6 +138,7 @@ def load_lib():
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
         "scvod_set_timing": (C.c_int, [vp, i32]),
         "scvod_nn_search": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp]),
+        "scvod_nn_radius_search": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp]),
         "scvod_nn_search_device": (C.c_int, [vp, vp, i32, vp, i32, f32, vp, vp, vp, vp]),
         "scvod_batch_voxelgrid": (C.c_int, [vp, vp, vp, vp, i32, vp, f32, vp, i64, vp, vp]),
         "scvod_voxelgrid": (C.c_int, [vp, vp, vp, i32, vp, f32, vp, i32, vp]),
@@ -154,10 +156,10 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_batch_export_table",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_merge", "scvod_map_points",
-                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
+                    "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
 
 
 def make_params(preset=None, **kw):
@@ -378,6 +380,9 @@ class Ctx:
                     n_unique=arr(r.n_unique, ncl, np.int32), pair_begin=pb, pair_label=arr(r.pair_label, npair, np.int32),
                     pair_count=arr(r.pair_count, npair, np.int32), pt_dyn=arr(r.pt_dyn, r.n_apri, np.uint8))
 
+    def batch_track_tables(self, stream=None):
+        self._chk(self.lib.scvod_batch_track_tables(self.h, C.c_void_p(stream or 0)))
+
     def batch_export_table(self, s, d_out, stream=None):
         """d_out: torch int32 device tensor [cap_records, 4]"""
         self._chk(self.lib.scvod_batch_export_table(self.h, int(s), C.c_void_p(d_out.data_ptr()), int(d_out.shape[0]),
@@ -443,6 +448,18 @@ class Ctx:
         self._chk(self.lib.scvod_nn_search(self.h, pm, m.shape[0], pq, nq, float(radius), idx.ctypes.data_as(C.c_void_p),
                                            sq.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)))
         return idx[:nq], sq[:nq], w[:nq]
+
+
+    def nn_radius_search(self, map_xyz, query_xyz, radius):
+        """nearest map point strictly inside `radius` per query: (idx or -1, squared distance or +inf, found)"""
+        m, pm = self._f32(map_xyz)
+        q, pq = self._f32(query_xyz)
+        nq = q.shape[0]
+        idx = np.zeros(max(nq, 1), np.int32)
+        sq = np.zeros(max(nq, 1), np.float32)
+        self._chk(self.lib.scvod_nn_radius_search(self.h, pm, m.shape[0], pq, nq, float(radius), idx.ctypes.data_as(C.c_void_p),
+                                                  sq.ctypes.data_as(C.c_void_p)))
+        return idx[:nq], sq[:nq], (idx[:nq] >= 0).astype(np.uint8)
 
 
 MAP_NO_GROUND, MAP_NO_REJECTED, MAP_IGNORE_DYNAMIC = 1, 2, 4

@@ -72,13 +72,13 @@ def _segment_objects(seq, seg, kind):
     o["fence_hx"] = u(n_f, 4.0, 9.0)
     o["fence_i"] = q(n_f)
     n_b = 12
-    o["clutter_c"] = torch.stack([x0 + u(n_b, 0, 100), side(n_b, 3.2, 12)], 1)
+    o["clutter_c"] = torch.stack([x0 + u(n_b, 0, 100), side(n_b, 5.0, 12)], 1)
     o["clutter_h"] = u(n_b, 0.25, 0.5)
     o["clutter_top"] = u(n_b, 0.6, 1.6)
     o["clutter_i"] = q(n_b)
     # extra trunks; canopies sit on the first n_can of all trunks
     n_t2 = 8
-    t2_c = torch.stack([x0 + u(n_t2, 0, 100), side(n_t2, 3.5, 16)], 1)
+    t2_c = torch.stack([x0 + u(n_t2, 0, 100), side(n_t2, 4.8, 16)], 1)
     o["cyl_c"] = torch.cat([cyl_c, t2_c])
     o["cyl_r"] = torch.cat([cyl_r, u(n_t2, 0.12, 0.3)])
     o["cyl_h"] = torch.cat([cyl_h, u(n_t2, 2.5, 5.0)])
@@ -90,18 +90,20 @@ def _segment_objects(seq, seg, kind):
     o["can_i"] = q(n_can)
     n_bush = 16
     bush_r = u(n_bush, 0.5, 1.4)
-    o["bush_c"] = torch.cat([torch.stack([x0 + u(n_bush, 0, 100), side(n_bush, 4.5, 14)], 1), (0.5 * bush_r)[:, None]], 1)
+    by = side(n_bush, 4.6, 13)  # inner edge: clear of the movers' lanes (+-3.5 m, half width 0.9 m)
+    o["bush_c"] = torch.cat([torch.stack([x0 + u(n_bush, 0, 100), by + torch.sign(by) * bush_r], 1), (0.5 * bush_r)[:, None]], 1)
     o["bush_r"] = bush_r
     o["bush_i"] = q(n_bush)
     # hedgerows / tree rows: long porous boxes on both sides of the road, what fills the curved voxels of a real street
     n_h = 28
-    o["hedge_c"] = torch.stack([x0 + u(n_h, 0, 100), torch.cat([side(n_h // 2, 4.8, 10.0), side(n_h // 2, 12.0, 22.0)])], 1)
+    hy_in = torch.cat([side(n_h // 2, 4.6, 9.0), side(n_h // 2, 11.0, 20.0)])  # inner edge of the row
     o["hedge_hx"] = u(n_h, 3.0, 9.0)
     o["hedge_hy"] = torch.cat([u(n_h // 2, 0.8, 2.0), u(n_h // 2, 1.5, 4.0)])
+    o["hedge_c"] = torch.stack([x0 + u(n_h, 0, 100), hy_in + torch.sign(hy_in) * o["hedge_hy"]], 1)
     o["hedge_top"] = torch.cat([u(n_h // 2, 1.8, 4.5), u(n_h // 2, 3.0, 7.0)])
     o["hedge_i"] = q(n_h)
     # parked cars stand clear of the driving lanes of the movers (+-3.5 m)
-    o["cars_c"] = torch.stack([cars_c[:, 0], cars_c[:, 1] + 2.2 * torch.sign(cars_c[:, 1])], 1)
+    o["cars_c"] = torch.stack([cars_c[:, 0], cars_c[:, 1] + (1.3 + car_dy) * torch.sign(cars_c[:, 1])], 1)
     if scene == "canyon":
         # tall continuous facades on both sides + decks above the road: the sky-facing beams of a +-22.5 deg sensor return
         n_fc = 10

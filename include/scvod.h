@@ -291,6 +291,11 @@ typedef struct scvod_track_result {
 } scvod_track_result;
 int scvod_batch_fetch_track(scvod_ctx* ctx, int32_t s, scvod_track_result* out);
 
+/* First half of scvod_batch_track on its own: Voxel::label, cluster sizes and types of every scan (the table its
+ * predecessor is tracked against).  A sharded sequence calls this, exports the tables of its blocks' first scans, exchanges
+ * them, and then calls scvod_batch_track (which does not repeat the work).  Asynchronous on `stream`. */
+int scvod_batch_track_tables(scvod_ctx* ctx, void* stream);
+
 /* Boundary message of a sequence shard: writes 1 + n_voxels records of 16 bytes into d_out (device memory, capacity
  * cap_records): record 0 = {records that follow, n_voxels, 0, 0}, then per voxel of scan `s` in ascending key
  * {key, label, |occupy_voxels| of the label's cluster, its type (0 erased, 1 other, 2 car)}.  Asynchronous on `stream`.
@@ -319,6 +324,17 @@ int scvod_batch_fetch_cluster_types(scvod_ctx* ctx, int32_t s, int32_t car_label
 /* one-shot host version on an apri_vec the caller holds (voxelises it first) */
 int scvod_cluster(scvod_ctx* ctx, const scvod_apri* h_apri, int32_t n, int32_t* h_pt_cluster);
 
+/* Streaming ingest of a sequence held in HOST memory (the reference reads one .bin per scan, SSC::getCloud
+ * src/ssc.cpp:1040-1125): chunks of `chunk_scans` scans travel host -> device on a copy stream into one of two device
+ * buffers while the previous chunk runs scvod_batch_process on the ctx's stream; after the launches of a chunk are
+ * enqueued `fn(user, ctx, first_scan, n_scans, stream)` is called to enqueue the consumers of that chunk (clustering,
+ * tracking, map accumulation) on `stream` -- the arena holds one chunk at a time; fn may be NULL.  h_xyzi should be
+ * pinned; SCVOD_INGEST_REGISTER pins it for the duration of the call.  Synchronous: returns when every chunk is done. */
+#define SCVOD_INGEST_REGISTER 1
+typedef int (*scvod_chunk_fn)(void* user, scvod_ctx* ctx, int32_t first_scan, int32_t n_scans, void* stream);
+int scvod_sequence_ingest(scvod_ctx* ctx, const float* h_xyzi, const int32_t* h_scan_offsets, int32_t n_scans,
+                          int32_t chunk_scans, int32_t flags, scvod_chunk_fn fn, void* user);
+
 /* hipEvent timing of the kernels of the last batch call, in launch order:
  * names[i] (static strings), ms[i].  Returns the number of entries (<= cap). */
 int scvod_batch_timings(scvod_ctx* ctx, const char** names, float* ms, int32_t cap);
@@ -330,11 +346,17 @@ int scvod_set_timing(scvod_ctx* ctx, int32_t enabled);
 
 /* For every query point: index of the nearest map point (ties: lowest index) and the
  * squared distance (fp32, ((dx*dx + dy*dy) + dz*dz)); h_within[q] = 1 if any map point
- * lies within `radius` (pcl radiusSearch non-empty, evaluate.cpp:95,104).  h_xyz arrays
+ * lies within `radius` (squared distance < radius^2: pcl radiusSearch non-empty, evaluate.cpp:95,104).  h_xyz arrays
  * are n x 3 floats. */
 int scvod_nn_search(scvod_ctx* ctx, const float* h_map_xyz, int32_t n_map,
                     const float* h_query_xyz, int32_t n_query, float radius,
                     int32_t* h_nn_idx, float* h_nn_sqdist, uint8_t* h_within);
+
+/* pcl::KdTreeFLANN::radiusSearch as src/evaluate.cpp:95,104 uses it (is anything inside the radius?): per query the
+ * nearest map point with squared distance < radius^2 (FLANN keeps dist < r^2), or index -1 / distance +inf.  Unlike
+ * scvod_nn_search it never looks beyond the radius, so queries far from the map cost one 27-cell probe. */
+int scvod_nn_radius_search(scvod_ctx* ctx, const float* h_map_xyz, int32_t n_map, const float* h_query_xyz,
+                           int32_t n_query, float radius, int32_t* h_nn_idx, float* h_nn_sqdist);
 
 /* The same search on arrays already resident in HBM (packed xyz, 12 B per point); asynchronous on `stream`
  * (NULL = the ctx's stream).  For sequence-scale evaluation without host round trips. */

@@ -121,3 +121,70 @@ extern "C" int oracle_voxelgrid(const float* xyzi, const uint32_t* labels, int32
     *n_out = out;
     return 0;
 }
+
+// SSC::getPose, KITTI branch (src/ssc.cpp:960-989) + Utility::rotationMatrixToEulerAngles (include/utility.h:488-505) for
+// one line of poses.txt: velo_to_cam = tr.inverse() * cam * tr in float, pose = {translation, roll, pitch, yaw}.
+// Eigen::Matrix4f::inverse() restated as cofactors from 2x2 sub-determinants over the determinant (Eigen's generic 4x4
+// path; the SSE kernel x86 builds of Eigen 3.3 use rounds differently in the last bits): PARITY UNPINNED, the tests allow
+// 1e-5 relative against a float64 evaluation.
+extern "C" int oracle_kitti_pose(const float tr[16], const float cam12[12], float pose6[6], float velo_to_cam[16]) {
+    auto at = [](const float* m, int r, int c) { return m[4 * r + c]; };
+    const float* a = tr;
+    // 2x2 sub-determinants of the two upper and the two lower rows
+    const float s0 = at(a, 0, 0) * at(a, 1, 1) - at(a, 1, 0) * at(a, 0, 1), s1 = at(a, 0, 0) * at(a, 1, 2) - at(a, 1, 0) * at(a, 0, 2);
+    const float s2 = at(a, 0, 0) * at(a, 1, 3) - at(a, 1, 0) * at(a, 0, 3), s3 = at(a, 0, 1) * at(a, 1, 2) - at(a, 1, 1) * at(a, 0, 2);
+    const float s4 = at(a, 0, 1) * at(a, 1, 3) - at(a, 1, 1) * at(a, 0, 3), s5 = at(a, 0, 2) * at(a, 1, 3) - at(a, 1, 2) * at(a, 0, 3);
+    const float c5 = at(a, 2, 2) * at(a, 3, 3) - at(a, 3, 2) * at(a, 2, 3), c4 = at(a, 2, 1) * at(a, 3, 3) - at(a, 3, 1) * at(a, 2, 3);
+    const float c3 = at(a, 2, 1) * at(a, 3, 2) - at(a, 3, 1) * at(a, 2, 2), c2 = at(a, 2, 0) * at(a, 3, 3) - at(a, 3, 0) * at(a, 2, 3);
+    const float c1 = at(a, 2, 0) * at(a, 3, 2) - at(a, 3, 0) * at(a, 2, 2), c0 = at(a, 2, 0) * at(a, 3, 1) - at(a, 3, 0) * at(a, 2, 1);
+    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    if (det == 0.f) return -1;
+    const float id = 1.0f / det;
+    float inv[16];
+    inv[0] = (at(a, 1, 1) * c5 - at(a, 1, 2) * c4 + at(a, 1, 3) * c3) * id;
+    inv[1] = (-at(a, 0, 1) * c5 + at(a, 0, 2) * c4 - at(a, 0, 3) * c3) * id;
+    inv[2] = (at(a, 3, 1) * s5 - at(a, 3, 2) * s4 + at(a, 3, 3) * s3) * id;
+    inv[3] = (-at(a, 2, 1) * s5 + at(a, 2, 2) * s4 - at(a, 2, 3) * s3) * id;
+    inv[4] = (-at(a, 1, 0) * c5 + at(a, 1, 2) * c2 - at(a, 1, 3) * c1) * id;
+    inv[5] = (at(a, 0, 0) * c5 - at(a, 0, 2) * c2 + at(a, 0, 3) * c1) * id;
+    inv[6] = (-at(a, 3, 0) * s5 + at(a, 3, 2) * s2 - at(a, 3, 3) * s1) * id;
+    inv[7] = (at(a, 2, 0) * s5 - at(a, 2, 2) * s2 + at(a, 2, 3) * s1) * id;
+    inv[8] = (at(a, 1, 0) * c4 - at(a, 1, 1) * c2 + at(a, 1, 3) * c0) * id;
+    inv[9] = (-at(a, 0, 0) * c4 + at(a, 0, 1) * c2 - at(a, 0, 3) * c0) * id;
+    inv[10] = (at(a, 3, 0) * s4 - at(a, 3, 1) * s2 + at(a, 3, 3) * s0) * id;
+    inv[11] = (-at(a, 2, 0) * s4 + at(a, 2, 1) * s2 - at(a, 2, 3) * s0) * id;
+    inv[12] = (-at(a, 1, 0) * c3 + at(a, 1, 1) * c1 - at(a, 1, 2) * c0) * id;
+    inv[13] = (at(a, 0, 0) * c3 - at(a, 0, 1) * c1 + at(a, 0, 2) * c0) * id;
+    inv[14] = (-at(a, 3, 0) * s3 + at(a, 3, 1) * s1 - at(a, 3, 2) * s0) * id;
+    inv[15] = (at(a, 2, 0) * s3 - at(a, 2, 1) * s1 + at(a, 2, 2) * s0) * id;
+    float cam[16];
+    for (int i = 0; i < 12; ++i) cam[i] = cam12[i];
+    cam[12] = cam[13] = cam[14] = 0.f;
+    cam[15] = 1.f;
+    auto mul = [&](const float* x, const float* y, float* z) {
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;
+                for (int k = 0; k < 4; ++k) acc += x[4 * i + k] * y[4 * k + j];
+                z[4 * i + j] = acc;
+            }
+    };
+    float t1[16];
+    mul(inv, cam, t1);
+    mul(t1, tr, velo_to_cam);
+    const float* R = velo_to_cam;
+    pose6[0] = at(R, 0, 3);
+    pose6[1] = at(R, 1, 3);
+    pose6[2] = at(R, 2, 3);
+    const float sy = std::sqrt(at(R, 0, 0) * at(R, 0, 0) + at(R, 1, 0) * at(R, 1, 0));
+    if (!(sy < 1e-6)) {
+        pose6[3] = atan2f(at(R, 2, 1), at(R, 2, 2));
+        pose6[4] = atan2f(-at(R, 2, 0), sy);
+        pose6[5] = atan2f(at(R, 1, 0), at(R, 0, 0));
+    } else {
+        pose6[3] = atan2f(-at(R, 1, 2), at(R, 1, 1));
+        pose6[4] = atan2f(-at(R, 2, 0), sy);
+        pose6[5] = 0;
+    }
+    return 0;
+}

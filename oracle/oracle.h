@@ -20,6 +20,8 @@ void oracle_grid_dims(const scvod_params* p, int32_t* range_num, int32_t* sector
 int oracle_patchwork(const scvod_params* params, const scvod_pw_params* pw, const float* xyzi, int32_t n,
                      int32_t sort_mode, uint8_t* cls, int32_t* ground_idx, int32_t* n_ground, int32_t* nonground_idx,
                      int32_t* n_nonground, scvod_patch_plane* planes, int32_t* n_patches);
+/* number of estimate_plane_ calls that met an empty ground set since the last reset (must stay 0, see patchwork_oracle.cpp) */
+long long oracle_patchwork_empty_sets(int reset);
 void oracle_patch_ids(const scvod_params* params, const float* xyzi, int32_t n, int32_t* pid);
 void oracle_svd3(const float cov_rowmajor[9], float sv[3], float U_rowmajor[9]);
 
@@ -76,6 +78,9 @@ int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz
 int oracle_voxelgrid(const float* xyzi, const uint32_t* labels, int32_t n, float max_intensity, const float leaf[3],
                      int32_t sort_mode, float* out_xyzi, int32_t* n_out);
 
+/* one poses.txt line -> velodyne-frame pose, SSC::getPose KITTI branch (src/ssc.cpp:960-989, utility.h:488-505) */
+int oracle_kitti_pose(const float tr[16], const float cam12[12], float pose6[6], float velo_to_cam[16]);
+
 /* libm probes for tests/test_math_spec.py */
 float oracle_libm_atan2f(float y, float x);
 double oracle_libm_atan2(double y, double x);
@@ -85,6 +90,12 @@ double oracle_libm_atan2(double y, double x);
  * stage_s[3] = {patchwork, bin, voxelize}. */
 int oracle_time_process(const scvod_params* params, const float* xyzi, const int32_t* offsets, int32_t n_scans,
                         double stage_s[3], int64_t* checksum);
+
+/* Timed CPU baseline of the whole path (Patchwork, binning, voxel descriptors, clustering, box rules, the sequential
+ * tracking chain), single thread; stage_s[6]; in_label (optional) per input point: 0 static, 1 dynamic, 2 in no cluster,
+ * 3 dropped by Patchwork. */
+int oracle_time_sequence(const scvod_params* params, const float* xyzi, const int32_t* offsets, int32_t n_scans, const float* poses,
+                         int32_t car, int32_t other, double stage_s[6], uint8_t* in_label, int64_t* checksum);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,11 @@ static void jacobi_svd3(const float cov_colmajor[9], float sv[3], float U_colmaj
     std::memcpy(U_colmajor, U.a, sizeof(U.a));
 }
 
+// how often an estimate_plane_ call met an EMPTY ground set: the one situation in which the reference's plane state leaks
+// from the previous patch (and, through the static object, from the previous scan).  The product does not model the leak;
+// tests/test_oracle_known_answers.py shows the count stays 0 (and DESIGN.md why it must for th_seeds >= 0, th_dist >= 0.01).
+static long long g_empty_ground_sets = 0;
+
 // ---------------------------------------------------------------------------------------
 struct PatchworkState {  // members of class PatchWork that survive between calls
     float d_ = 0.f;
@@ -354,7 +359,9 @@ class PatchworkOracle {
             c[3] = c[1];
             c[6] = c[2];
             c[7] = c[5];
-        }  // n == 0: cov_ / pc_mean_ keep their previous values
+        } else {
+            ++g_empty_ground_sets;  // n == 0: cov_ / pc_mean_ keep their previous values (PCL leaves its outputs untouched)
+        }
     }
 
     void estimate_plane_(const std::vector<Pt>& ground) {  // patchwork.h:216-232
@@ -469,6 +476,12 @@ void oracle_svd3(const float cov_rowmajor[9], float sv[3], float U_rowmajor[9]) 
     jacobi_svd3(cm, sv, Ucm);
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) U_rowmajor[r * 3 + c] = Ucm[c * 3 + r];
+}
+
+long long oracle_patchwork_empty_sets(int reset) {
+    const long long v = g_empty_ground_sets;
+    if (reset) g_empty_ground_sets = 0;
+    return v;
 }
 
 }  // extern "C"

@@ -458,7 +458,7 @@ int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz
         }
         nn_idx[q] = bi;
         nn_sqdist[q] = best;
-        within[q] = (bi >= 0 && best <= r2) ? 1 : 0;
+        within[q] = (bi >= 0 && best < r2) ? 1 : 0;  // FLANN's RadiusResultSet keeps dist < r^2
     }
     return 0;
 }

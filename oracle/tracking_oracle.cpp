@@ -8,6 +8,7 @@
 // recognize, which are out of scope), run this, and compare cluster states and next-frame labels.
 // PARITY UNPINNED against the real binary.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -398,6 +399,99 @@ int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri,
     }
     for (int s = 0; s < n_scans; ++s) dyn_of_frame(frames[s], offs[s + 1] - offs[s], pt_type + offs[s], pt_dyn + offs[s]);
     if (dynamic_clusters) *dynamic_clusters = dyn;
+    return 0;
+}
+
+
+// Timed CPU baseline of the WHOLE path bench.py times on the GPU, single-threaded, scan after scan the way SSC::segDF runs
+// (ssc.cpp:1434-1451): Patchwork -> makeApriVec -> makeHashCloud -> clusterAndCreateFrame -> bounding-box refine + type
+// rules -> SSC::tracking of every consecutive pair (the reference's sequential chain).  stage_s[6] = seconds in
+// {patchwork, bin, voxelize, cluster, types, tracking}.  Optionally returns, per INPUT point, a byte: 0 static (ground,
+// range/FOV reject or member of a cluster that is not dynamic), 1 dynamic, 2 in no cluster, 3 dropped by Patchwork.
+int oracle_time_sequence(const scvod_params* params, const float* xyzi, const int32_t* offsets, int32_t n_scans, const float* poses,
+                         int32_t car, int32_t other, double stage_s[6], uint8_t* in_label, int64_t* checksum) {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    for (int k = 0; k < 6; ++k) stage_s[k] = 0.0;
+    const scvod_params& P = *params;
+    std::vector<FrameT> frames(n_scans);
+    std::vector<std::vector<int32_t>> src(n_scans), types(n_scans);
+    int64_t cs = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        const float* pts = xyzi + 4 * (size_t)offsets[s];
+        const int n = offsets[s + 1] - offsets[s];
+        std::vector<uint8_t> cls(n ? n : 1);
+        std::vector<int32_t> g(n ? n : 1), ng(n ? n : 1);
+        std::vector<scvod_patch_plane> planes(SCVOD_MAX_PATCHES);
+        int32_t n_g = 0, n_ng = 0, n_p = 0;
+        auto t0 = clk::now();
+        oracle_patchwork(params, nullptr, pts, n, 0, cls.data(), g.data(), &n_g, ng.data(), &n_ng, planes.data(), &n_p);
+        auto t1 = clk::now();
+        std::vector<float> ngc(4 * (size_t)(n_ng ? n_ng : 1));
+        for (int k = 0; k < n_ng; ++k) std::memcpy(&ngc[4 * (size_t)k], pts + 4 * (size_t)ng[k], 16);
+        std::vector<scvod_apri> apri(n_ng ? n_ng : 1);
+        std::vector<int32_t> asrc(n_ng ? n_ng : 1), rej(n_ng ? n_ng : 1);
+        int32_t n_a = 0, n_r = 0;
+        oracle_bin(params, ngc.data(), n_ng, 1, apri.data(), asrc.data(), &n_a, rej.data(), &n_r);
+        auto t2 = clk::now();
+        FrameT& f = frames[s];
+        build_frame(P, apri.data(), n_a, f);  // makeHashCloud
+        auto t3 = clk::now();
+        std::vector<int32_t> cl(n_a ? n_a : 1), ty(n_a ? n_a : 1);
+        int32_t mx = 0;
+        oracle_cluster(params, apri.data(), n_a, cl.data(), &mx);
+        auto t4 = clk::now();
+        oracle_cluster_types(params, apri.data(), n_a, cl.data(), car, other, ty.data());
+        // Frame as recognize leaves it: labels, occupy lists, types (the voxel table of build_frame is reused)
+        f.cluster_set.clear();
+        int max_name = 4;
+        for (auto& kv : f.hash_cloud) {
+            const int first = kv.second.ptIdx.front();
+            kv.second.label = ty[first] == -1 ? -1 : cl[first];
+        }
+        for (int i = 0; i < n_a; ++i) {
+            if (ty[i] == -1) continue;
+            ClusterT& c = f.cluster_set[cl[i]];
+            if (c.name == -1) {
+                c.name = cl[i];
+                c.type = ty[i];
+                if (c.name > max_name) max_name = c.name;
+            }
+            c.occupy_pts.push_back(i);
+            c.occupy_voxels.push_back(apri[i].voxel_idx);
+            c.cloud.push_back(f.cloud_use[i]);
+        }
+        for (auto& kv : f.cluster_set) sampleVec(kv.second.occupy_voxels);
+        f.max_name = max_name + 1;
+        auto t5 = clk::now();
+        stage_s[0] += secs(t0, t1);
+        stage_s[1] += secs(t1, t2);
+        stage_s[2] += secs(t2, t3);
+        stage_s[3] += secs(t3, t4);
+        stage_s[4] += secs(t4, t5);
+        cs += n_g + 3 * (int64_t)n_ng + 7 * (int64_t)n_a + 11 * (int64_t)f.hash_cloud.size() + 13 * (int64_t)f.cluster_set.size();
+        if (in_label) {
+            uint8_t* L = in_label + offsets[s];
+            for (int i = 0; i < n; ++i) L[i] = cls[i] == SCVOD_CLS_DROPPED ? 3 : 0;
+            src[s].resize(n_a);
+            for (int i = 0; i < n_a; ++i) src[s][i] = ng[asrc[i]];
+            types[s] = ty;
+        }
+    }
+    auto t6 = clk::now();
+    int name = 0, dyn = 0;
+    for (int i = 0; i + 1 < n_scans; ++i) dyn += tracking(P, frames[i], frames[i + 1], poses + 6 * i, poses + 6 * (i + 1), car, name);
+    stage_s[5] = secs(t6, clk::now());
+    cs += 17 * (int64_t)dyn;
+    if (in_label) {
+        for (int s = 0; s < n_scans; ++s) {
+            const int n_a = (int)src[s].size();
+            std::vector<uint8_t> d(n_a ? n_a : 1);
+            dyn_of_frame(frames[s], n_a, types[s].data(), d.data());
+            for (int i = 0; i < n_a; ++i) in_label[offsets[s] + src[s][i]] = d[i];
+        }
+    }
+    if (checksum) *checksum = cs;
     return 0;
 }
 

@@ -195,3 +195,14 @@ class Oracle:
         self.lib.oracle_sequence_tracking(C.byref(params), _p(a), _p(o), len(o) - 1, _p(cl), _p(ty), _p(ps), car, int(chain),
                                           _p(dyn), C.byref(nd))
         return dyn[:len(a)], nd.value
+
+    def time_sequence(self, params, xyzi, offsets, poses, car=2, other=1, want_labels=True):
+        a = np.ascontiguousarray(xyzi, np.float32)
+        o = np.ascontiguousarray(offsets, np.int32)
+        ps = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        st = (C.c_double * 6)()
+        cs = C.c_int64()
+        lab = np.zeros(max(len(a), 1), np.uint8) if want_labels else None
+        self.lib.oracle_time_sequence(C.byref(params), _p(a), _p(o), len(o) - 1, _p(ps), car, other, st,
+                                      _p(lab) if want_labels else None, C.byref(cs))
+        return list(st), (lab[:len(a)] if want_labels else None), cs.value

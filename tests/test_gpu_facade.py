@@ -137,13 +137,47 @@ def test_voxelize_entry_point(scvod, oracle):
 
 
 def test_sequence_driver_end_to_end(scvod):
-    """segDF-shaped chain on the facade (process -> GPU clustering + bbox rules -> tracking) on a labelled
-    synthetic parking-lot sequence: static structure is preserved, some movers are rejected."""
+    """SSC::segDF on the facade (KITTI-layout loaders -> process -> GPU clustering + bbox rules -> tracking chain) on a
+    labelled synthetic parking-lot sequence: static structure is preserved, the chain runs over every frame."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("sequence_demo", os.path.join(ROOT, "tools", "sequence_demo.py"))
     demo = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(demo)
     r = demo.run(seq=3, first=0, count=6, kind="PARK", preset="parkinglot", verbose=False)
-    assert r["PR"] > 99.0
-    assert r["n_dynamic"] > 0 and r["RR"] > 10.0
+    assert r["PR"] > 98.0
+    assert r["n_dynamic"] > 0
     assert "dynamic_total" in r["log"]
+
+
+@pytest.mark.parametrize("kind,preset,skip,count", [("PARK", "parkinglot", 1, 50), ("K64", "semantickitti", 5, 50)])
+def test_dynamic_removal_quality_matches_the_reference_chain(scvod, oracle, kind, preset, skip, count):
+    """BASELINE.json: dynamic-removal precision / recall within +-0.5 pt of the reference.  The device path (first-order
+    decision per cluster, scvod_batch_track) and the oracle's restatement of the reference's sequential chain
+    (oracle_time_sequence: clusterAndCreateFrame, box rules, SSC::tracking with its re-labelling) on the same 50 labelled
+    frames (every skip-th scan, the reference's skip_): PR and RR as tool/analysis.py:186-187 defines them."""
+    import quality
+    import synth
+    P = scvod.make_params(preset)
+    idx = [k * skip for k in range(count)]
+    scans = [synth.make_scan(5, 300 + i, kind) for i in idx]
+    x = np.concatenate([s[0].numpy() for s in scans])
+    gt = np.concatenate([s[1].numpy() for s in scans])
+    offs = np.concatenate([[0], np.cumsum([len(s[0]) for s in scans])]).astype(np.int32)
+    poses = np.asarray([s[2] for s in scans], np.float32)
+    import torch
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    d = torch.from_numpy(x).cuda()
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    stages, ref_lab, _ = oracle.time_sequence(P, x, offs, poses)
+    q = quality.compare(scvod, ctx, x, offs, poses, gt, ref_lab, voxelsize=0.2)
+    assert q["num_gt_dynamic"] > 1000
+    assert abs(q["delta_PR"]) <= 0.5 and abs(q["delta_RR"]) <= 0.5, q
+    assert q["device"]["PR"] > 95.0
+    assert q["labels_equal_fraction"] > 0.99
+    ctx.close()

@@ -116,9 +116,10 @@ def test_shards_merge_into_the_single_shard_map(scvod):
         c.batch_process(dd, oo)
         c.batch_cluster()
         c.batch_cluster_types()
-    cb.batch_track(T[cut:])
+    cb.batch_track_tables()       # the order of a sharded step: tables -> export -> exchange -> track
     msg = torch.zeros((1 << 16, 4), dtype=torch.int32, device="cuda")
     cb.batch_export_table(0, msg)
+    cb.batch_track(T[cut:])
     ca.batch_track(T[:cut], next_scan=np.array([1, 2, -2], np.int32), ext_tables=[msg])
     ma, mb = scvod.StaticMap(1 << 20), scvod.StaticMap(1 << 20)
     ma.accumulate(ca, poses[:cut])

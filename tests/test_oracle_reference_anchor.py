@@ -1,0 +1,103 @@
+"""The hot-path oracle against the only Patchwork artefacts the reference holds: doc/fig2/509_g.pcd and
+509_seg.pcd, the ground and segmented non-ground clouds its own binary wrote for scan 509 (fixture: tests/golden/
+fig2_509.npz, made by tests/golden/make_fig2_golden.py; data only).  The input scan itself is not shipped, so the anchor is
+a re-segmentation: the union of the two clouds goes through the oracle's Patchwork and must come apart the way the
+reference took it apart.  Also here: the empty-ground-set case, the one place where the reference's plane state leaks
+between patches, is shown not to occur."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fig2_509.npz")
+
+
+def _union():
+    d = np.load(GOLD)
+    g, s = d["ground"], d["seg"]
+    x = np.concatenate([np.concatenate([g, s]), np.zeros((len(g) + len(s), 1), np.float32)], 1)
+    return x, len(g)
+
+
+def test_fig2_clouds_are_consistent_with_the_reference_constants(oracle, scvod):
+    """what the files themselves pin: the -1.8 h cut (patchwork.h:302-310, h = 1.73) and the (2.7, 80] range gate
+    (patchwork.h:436) on the ground cloud, the ssc range window on the segmented cloud"""
+    d = np.load(GOLD)
+    g, s = d["ground"], d["seg"]
+    assert len(g) == 40346 and len(s) == 29940
+    r = np.hypot(g[:, 0].astype(np.float64), g[:, 1].astype(np.float64))
+    assert g[:, 2].min() >= -1.8 * 1.73 and r.min() > 2.7 and r.max() <= 80.0
+    rs = np.hypot(s[:, 0].astype(np.float64), s[:, 1].astype(np.float64))
+    assert rs.max() <= 50.0 + 1e-3  # max_dis_ of the run that wrote it (the YAML comment "01 -> 50 on the highway")
+
+
+def test_resegmenting_fig2_recovers_the_reference_split(oracle, scvod):
+    x, ng = _union()
+    P = scvod.make_params("semantickitti")
+    for sort_mode in (0, 1):
+        o = oracle.patchwork(P, x, sort_mode)
+        cls = o["cls"]
+        g_ground = float((cls[:ng] == 0).mean())
+        s_nonground = float((cls[ng:] == 1).mean())
+        # >= 95 % of the reference's ground cloud must come back as ground (the rest lost its neighbours: the
+        # union lacks everything the reference's range / FOV filter and clustering removed after Patchwork)
+        assert g_ground >= 0.95, g_ground
+        assert s_nonground >= 0.95, s_nonground
+        assert float((cls == 2).mean()) < 0.005
+
+
+def test_empty_ground_sets_do_not_occur(oracle, scvod):
+    """estimate_plane_ on an empty set would leave the reference's cov_ / pc_mean_ at the previous patch's values
+    (patchwork_oracle.cpp: mean_and_covariance); the kernels start every patch from a clean state instead.  For
+    th_seeds >= 0 the seed set holds at least the lowest considered point, and a point of a set lies at most rounding
+    error (< 1e-4 m) above the set's own fitted plane while the gate is th_dist = 0.1 m above it, so no iteration can come
+    out empty -- counted here on street, parking-lot and adversarial scans, and on the reference's own clouds."""
+    import synth
+    P = scvod.make_params("semantickitti")
+    lib = oracle.lib
+    lib.oracle_patchwork_empty_sets.restype = C.c_longlong
+    lib.oracle_patchwork_empty_sets(1)
+    rng = np.random.default_rng(5)
+    scans = [synth.make_scan(5, 1500, "K64")[0].numpy(), synth.make_scan(3, 77, "PARK")[0].numpy(), _union()[0]]
+    # adversarial: duplicated points, a patch of identical z, points far below / above the sensor, heavy outliers
+    a = rng.uniform(-60, 60, (30000, 4)).astype(np.float32)
+    a[:, 2] = rng.choice(np.array([-1.73, -1.73, -1.7, 0.5, 2.5, -3.1, -3.2], np.float32), len(a))
+    a[:5000] = a[0]
+    scans.append(a)
+    b = rng.normal(0, 20, (20000, 4)).astype(np.float32)
+    b[:, 2] = rng.normal(-1.7, 3.0, len(b)).astype(np.float32)
+    scans.append(b)
+    for x in scans:
+        for sort_mode in (0, 1):
+            oracle.patchwork(P, x, sort_mode)
+    assert lib.oracle_patchwork_empty_sets(0) == 0
+
+
+def test_parameter_sets_that_could_empty_a_ground_set_are_refused(scvod):
+    """the C-ABI does not model the reference's state leak, so it refuses the parameter region where it could matter"""
+    lib = scvod.load_lib()
+    P = scvod.make_params("semantickitti")
+    for field, bad in (("th_seeds", -0.1), ("th_dist", 0.001)):
+        pw = scvod.PwParams()
+        lib.scvod_pw_params_default(C.byref(pw))
+        setattr(pw, field, bad)
+        h = C.c_void_p()
+        assert lib.scvod_create(C.byref(P), C.byref(pw), 0, 1000, 1, C.byref(h)) == -1
+
+
+@pytest.mark.gpu
+def test_fig2_through_the_hip_path(scvod, oracle):
+    """the reference's own clouds through the kernels: bit-identical to the oracle, same recovered split"""
+    x, ng = _union()
+    P = scvod.make_params("semantickitti")
+    ctx = scvod.Ctx(P, max_points_total=len(x) + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    o = oracle.patchwork(P, x, 1)
+    assert np.array_equal(r["cls"], o["cls"]) and np.array_equal(r["ground_idx"], o["ground_idx"])
+    assert np.array_equal(r["nonground_idx"], o["nonground_idx"])
+    live = o["planes"]["status"] > 0
+    for f in ("normal", "mean", "sv"):
+        assert np.array_equal(r["planes"][f][live].view(np.uint32), o["planes"][f][live].view(np.uint32))
+    assert float((r["cls"][:ng] == 0).mean()) >= 0.95
+    ctx.close()
