@@ -159,7 +159,7 @@ def main():
     ext = [recv_buf[e] for e in range(plan["n_recv"])]
     smap = None
     if not args.no_map:
-        cells = args.map_cells or (1 << int(np.ceil(np.log2(max(total_pts * 0.12, 1 << 20) * (world if rank == 0 else 1)))))
+        cells = args.map_cells or (1 << int(np.ceil(np.log2(max(total_pts * 0.25, 1 << 22) * (world if rank == 0 else 1)))))  # load <= ~0.5 on the street scenes
         smap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local)
     kt = {}
     info = {}

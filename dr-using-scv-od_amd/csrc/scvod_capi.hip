@@ -651,6 +651,18 @@ int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int devi
         }
         np += c->pw.num_rings_each_zone[k] * c->pw.num_sectors_each_zone[k];
     }
+    // the elevation / flatness gates are indexed ring + 2 * zone for the patches of the first num_rings_of_interest
+    // concentric rings (patchwork.h:351-353) and hold four entries (patchwork.h:50-51): a layout that would index past
+    // them reads out of bounds in the reference; refused here
+    {
+        int conc = 0;
+        for (int k = 0; k < 4; ++k)
+            for (int r = 0; r < c->pw.num_rings_each_zone[k]; ++r, ++conc)
+                if (conc < c->pw.num_rings_of_interest && r + 2 * k > 3) {
+                    delete c;
+                    return SCVOD_ERR_INVALID;
+                }
+    }
     // th_seeds < 0 or a near-zero th_dist could leave a plane iteration without points: the reference then fits with the
     // stale moments of the previous patch (PCL leaves cov / mean untouched for an empty cloud) -- not modelled, refused
     if (np > kMaxPatches || !(params->range_res > 0) || !(params->sector_res > 0) || !(params->azimuth_res > 0) ||

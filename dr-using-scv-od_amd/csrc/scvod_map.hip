@@ -44,6 +44,7 @@ struct scvod_map {
 namespace {
 
 constexpr unsigned long long kEmpty = ~0ull;
+constexpr int kMapMaxProbes = 512;  // linear probing: longer runs only appear beyond ~95 % load
 constexpr int kCellBits = 21, kCellBias = 1 << 20;
 
 int mfail(scvod_map* m, int code, const char* fmt, ...) {
@@ -96,7 +97,8 @@ __device__ __forceinline__ bool map_encode(float x, float y, float z, float inte
 
 __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mask, unsigned long long key, unsigned long long val) {
     unsigned long long h = map_mix(key) & mask;
-    for (unsigned long long probes = 0; probes <= mask; ++probes) {
+    // a table that is (nearly) full is an error the caller hears about at export time, not a reason to walk 2^n slots
+    for (int probes = 0; probes < kMapMaxProbes; ++probes) {
         unsigned long long k = __hip_atomic_load(&table[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == kEmpty) {
             k = atomicCAS(&table[h].key, kEmpty, key);

@@ -64,19 +64,23 @@ __device__ __forceinline__ NextTable next_table_of(const Arena& A, const TrackBa
     return t;
 }
 
-// per cluster root: reset the per-cluster words this call accumulates into
-__global__ __launch_bounds__(256) void k_tk_init(Arena A) {
+// per cluster root: reset the per-cluster words a phase accumulates into (phase 1: the successor tables, phase 2: the
+// member lists and decisions -- a second scvod_batch_track on the same tables must start from clean words too)
+__global__ __launch_bounds__(256) void k_tk_init(Arena A, int phase) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
-    if (blockIdx.x == 0 && threadIdx.x < 4) A.tk_scan[s * 4 + threadIdx.x] = 0;
+    if (phase == 2 && blockIdx.x == 0 && threadIdx.x < 4) A.tk_scan[s * 4 + threadIdx.x] = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         if (A.pt_cluster[(size_t)base + i] != i) continue;
-        A.cl_nvox[(size_t)base + i] = 0;
-        A.tk_cursor[(size_t)base + i] = 0;
-        A.cl_state[(size_t)base + i] = -1;
-        A.tk_npairs[(size_t)base + i] = 0;
-        A.tk_nuniq[(size_t)base + i] = 0;
+        if (phase == 1) {
+            A.cl_nvox[(size_t)base + i] = 0;
+        } else {
+            A.tk_cursor[(size_t)base + i] = 0;
+            A.cl_state[(size_t)base + i] = -1;
+            A.tk_npairs[(size_t)base + i] = 0;
+            A.tk_nuniq[(size_t)base + i] = 0;
+        }
     }
 }
 
@@ -384,13 +388,14 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
     if (phases & 1) {
         TH_BEGIN("tk_labels");
-        hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A);
+        hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A, 1);
         hipLaunchKernelGGL(k_tk_voxlabel, g, dim3(256), 0, st, A);
         hipLaunchKernelGGL(k_tk_voxfill, g, dim3(256), 0, st, A);
         TH_END("tk_labels");
     }
     if (!(phases & 2)) return;
     TH_BEGIN("tk_members");
+    hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A, 2);
     hipLaunchKernelGGL(k_tk_members, dim3(B), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_tk_scatter, g, dim3(256), 0, st, A);
     TH_END("tk_members");

@@ -68,7 +68,7 @@ def _pw(scvod, **kw):
 @pytest.mark.parametrize("case", [
     dict(max_range=50.0, min_range=1.0, num_sectors_each_zone=[12, 20, 36, 24], num_rings_each_zone=[3, 3, 5, 2]),
     dict(num_iter=2, num_lpr=10, th_seeds=0.3, th_dist=0.2, num_min_pts=20, uprightness_thr=0.8),
-    dict(max_range=120.0, min_range=0.5, num_rings_of_interest=6, adaptive_seed_selection_margin=-0.9,
+    dict(max_range=120.0, min_range=0.5, num_rings_of_interest=3, adaptive_seed_selection_margin=-0.9,
          elevation_thr=[-1.0, -0.9, -0.8, -0.7], flatness_thr=[1e-4, 1e-4, 2e-4, 3e-4]),
 ])
 def test_custom_patchwork_constants(scvod, oracle, case):

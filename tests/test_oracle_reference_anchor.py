@@ -78,7 +78,8 @@ def test_parameter_sets_that_could_empty_a_ground_set_are_refused(scvod):
     """the C-ABI does not model the reference's state leak, so it refuses the parameter region where it could matter"""
     lib = scvod.load_lib()
     P = scvod.make_params("semantickitti")
-    for field, bad in (("th_seeds", -0.1), ("th_dist", 0.001)):
+    # (num_rings_of_interest = 6 would index the four elevation / flatness gates at ring + 2 * zone = 4, 5: patchwork.h:351-353)
+    for field, bad in (("th_seeds", -0.1), ("th_dist", 0.001), ("num_rings_of_interest", 6)):
         pw = scvod.PwParams()
         lib.scvod_pw_params_default(C.byref(pw))
         setattr(pw, field, bad)
