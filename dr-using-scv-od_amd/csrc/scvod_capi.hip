@@ -216,6 +216,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.tk_clusters = k.take<int32_t>(N);
     A.tk_scan = k.take<int32_t>(B * 4);
     A.pt_dyn = k.take<uint8_t>(N);
+    A.pt_mapcls = k.take<uint8_t>(N);
     c->d_next_scan = k.take<int32_t>(B);
     c->d_ext = k.take<const int4*>(B);
     *total = align_up(k.off, 256);

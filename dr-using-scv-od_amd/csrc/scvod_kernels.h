@@ -14,6 +14,9 @@ namespace scvod {
 constexpr int kMaxPatches = SCVOD_MAX_PATCHES;
 constexpr int kMaxBuckets = 1024;
 constexpr int kVgLutBins = 16384;
+// which of the reference's clouds an input point ended up in (k_emit / k_bin_direct, k_tk_dyn): the static map streams the
+// input in order and keeps cloud_out, cloud_eva_static and the apri points that are not dynamic
+constexpr uint8_t kMapNone = 0, kMapGround = 1, kMapRejected = 2, kMapApri = 3, kMapDynamic = 4;
 
 struct Xyz {
     float x, y, z;
@@ -123,6 +126,7 @@ struct Arena {
     int32_t* tk_clusters;     // [N] per scan: roots of its car clusters, ascending
     int32_t* tk_scan;         // [B][4] per scan: car clusters, car points, dynamic clusters, dynamic points
     uint8_t* pt_dyn;          // [N] per apri point: SCVOD_DYN_*
+    uint8_t* pt_mapcls;       // [N] per INPUT point, for the static map: kMap* (which cloud of the reference holds it)
     // loader-side VoxelGrid
     int32_t* vg_par;          // [B][16] per scan: min_b[3], mul[3], overflow flag, kept points, distinct cells
     int32_t* vg_range;        // [1] largest cell index range of the batch

@@ -1231,6 +1231,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
             for (int e = lane; e < r.n_g; e += 64) {
                 const uint32_t id = seg[e] & 0x7fffffffu;
                 A.ground_idx[(size_t)base + xg + e] = (int32_t)id;
+                A.pt_mapcls[(size_t)base + id] = kMapGround;
             }
         }
         // non-ground stream of this patch: for a rejected patch the ground part (front, ascending) followed
@@ -1275,8 +1276,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     A.apri_key[dst0 + ek] = a.voxel_idx;
                     A.apri_int[dst0 + ek] = a.intensity;
                     A.apri_idx3[dst0 + ek] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
+                    A.pt_mapcls[(size_t)base + id] = kMapApri;
                 } else {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
+                    A.pt_mapcls[(size_t)base + id] = kMapRejected;
                 }
             }
             run_keep += nk;
@@ -1544,8 +1547,10 @@ __global__ __launch_bounds__(1024) void k_bin_direct(DevParams P, Arena A, int a
                 A.apri_key[dst] = a.voxel_idx;
                 A.apri_int[dst] = a.intensity;
                 A.apri_idx3[dst] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
+                A.pt_mapcls[(size_t)base + i] = kMapApri;
             } else {
                 A.rejected_src[(size_t)base + (i - (run + ek))] = i;
+                A.pt_mapcls[(size_t)base + i] = kMapRejected;
             }
         }
         run += tk;
@@ -2439,6 +2444,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
     const int B = A.n_scans;
     if (B <= 0) return;
     if (do_patchwork == 1) {
+        hipMemsetAsync(A.pt_mapcls, kMapNone, (size_t)A.total_pts, st);  // points Patchwork drops stay in no cloud
         hipMemsetAsync(A.patch_count, 0, sizeof(int32_t) * (size_t)B * kMaxPatches, st);
         hipMemsetAsync(A.patch_cursor, 0, sizeof(int32_t) * (size_t)B * kMaxPatches, st);
         dim3 gcls((A.max_scan_pts + kClsThreads * kClsItems - 1) / (kClsThreads * kClsItems), B);

@@ -116,81 +116,52 @@ __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mas
 
 // static points of scan blockIdx.y: cloud_out (ground), cloud_eva_static (range/FOV rejects) and the apri points that are
 // not dynamic, moved to the world frame with explicit fp32 dot products (the arithmetic of Utility::transformCloud,
-// utility.h:400-405).  A tile of kMapTile consecutive list entries (neighbours in a list are neighbours in space: the
-// lists are patch-major / voxel-ordered) is first reduced in an LDS hash table, so that a cell hit by many points of the
-// tile costs ONE probe of the table in HBM instead of one per point (a street scan puts ~4 points into every cell it touches).
-constexpr int kMapTile = 2048, kMapLds = 4096;  // 2 slots per point: linear probing stays short
+// utility.h:400-405).  The scan is streamed IN INPUT ORDER (coalesced 16-byte loads; which cloud a point belongs to comes
+// from the byte k_emit / k_tk_dyn left per input point): a sweep's neighbours in memory are neighbours in space, so runs of
+// consecutive lanes that fall into the same cell are reduced in the wave first (segmented min over the run) and only the
+// head of a run probes the table in HBM.
 __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
                                                         float inv_leaf, int with_ground, int with_rejected, int have_dyn,
                                                         unsigned long long* counters) {
-    __shared__ MapRec lt[kMapLds];
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
-    const int n_g = with_ground ? A.counts[s * 8 + 1] : 0;
-    const int n_r = with_rejected ? A.counts[s * 8 + 5] : 0;
-    const int n_a = A.counts[s * 8 + 4];
-    const int total = n_g + n_r + n_a;
-    if ((int)blockIdx.x * kMapTile >= total) return;
+    const int n = A.scan_off[s + 1] - base;
+    const int lane = threadIdx.x & 63;
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = pose[12 * s + i];
     int dropped = 0;
-    for (int t0 = blockIdx.x * kMapTile; t0 < total; t0 += gridDim.x * kMapTile) {
-        for (int j = threadIdx.x; j < kMapLds; j += 256) {
-            lt[j].key = kEmpty;
-            lt[j].val = kEmpty;
-        }
-        __syncthreads();
-        constexpr int PER = kMapTile / 256;
-        int src[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {  // all index loads, then all point gathers, in flight together
-            const int t = t0 + u * 256 + threadIdx.x;
-            int v = -1;
-            if (t < n_g) {
-                v = A.ground_idx[(size_t)base + t];
-            } else if (t < n_g + n_r) {
-                v = A.rejected_src[(size_t)base + (t - n_g)];
-            } else if (t < total) {
-                const int i = t - n_g - n_r;
-                if (!(have_dyn && A.pt_dyn[(size_t)base + i] == SCVOD_DYN_DYNAMIC)) v = A.apri_src[(size_t)base + i];
-            }
-            src[u] = v;
-        }
-        float4 q[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) q[u] = A.pts[base + max(src[u], 0)];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if (src[u] < 0) continue;
-            const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
-            const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
-            const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
-            unsigned long long key, val;
-            if (!map_encode(x, y, z, q[u].w, inv_leaf, key, val)) {
-                ++dropped;
-                continue;
-            }
-            unsigned h = (unsigned)map_mix(key) & (kMapLds - 1);
-            for (;;) {  // at most kMapTile keys in kMapLds slots: a free slot always exists
-                unsigned long long k = __hip_atomic_load(&lt[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (k == kEmpty) {
-                    k = atomicCAS(&lt[h].key, kEmpty, key);
-                    if (k == kEmpty) k = key;
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        unsigned long long key = kEmpty, val = kEmpty;
+        if (i < n) {
+            const uint8_t c = A.pt_mapcls[(size_t)base + i];
+            const bool keep = (c == kMapGround && with_ground) || (c == kMapRejected && with_rejected) || c == kMapApri ||
+                              (c == kMapDynamic && !have_dyn);
+            if (keep) {
+                const float4 q = A.pts[base + i];
+                const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
+                const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
+                const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
+                if (!map_encode(x, y, z, q.w, inv_leaf, key, val)) {
+                    ++dropped;
+                    key = kEmpty;
                 }
-                if (k == key) {
-                    atomicMin(&lt[h].val, val);
-                    break;
-                }
-                h = (h + 1) & (kMapLds - 1);
             }
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < kMapLds; j += 256) {
-            const MapRec r = lt[j];
-            if (r.key != kEmpty && !map_insert(table, mask, r.key, r.val)) ++dropped;
+        // runs of equal keys among consecutive lanes: the head of a run takes the smallest value of the run
+        const unsigned long long prev = __shfl_up(key, 1);
+        const bool head = (lane == 0) || (prev != key);
+        const unsigned long long heads = __ballot(head);
+        // end of my run = position of the next head after my lane (exclusive), 64 if none
+        const unsigned long long after = heads & ~((2ull << lane) - 1ull);
+        const int run_end = after ? (__ffsll((long long)after) - 1) : 64;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_down(val, d);
+            if (lane + d < run_end && o < val) val = o;
         }
-        __syncthreads();
+        if (head && key != kEmpty && !map_insert(table, mask, key, val)) ++dropped;
     }
     if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
 }
@@ -314,7 +285,7 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
     Arena A;
     int device = 0, track_valid = 0, batch_valid = 0, n_scans = 0, max_pts = 0;
     scvod__ctx_view(ctx, &A, &device, &track_valid, &batch_valid, &n_scans, &max_pts);
-    if (!batch_valid) return mfail(m, SCVOD_ERR_STATE, "scvod_batch_map_accumulate needs a processed batch");
+    if (!batch_valid || !A.pts) return mfail(m, SCVOD_ERR_STATE, "scvod_batch_map_accumulate needs a processed batch of input clouds");
     const int use_dyn = !(flags & SCVOD_MAP_IGNORE_DYNAMIC);
     if (use_dyn && !track_valid) return mfail(m, SCVOD_ERR_STATE, "no tracking result: run scvod_batch_track or pass SCVOD_MAP_IGNORE_DYNAMIC");
     if (device != m->device) return mfail(m, SCVOD_ERR_INVALID, "map and ctx live on different devices");
@@ -337,7 +308,7 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
         MHIP(m, hipMemcpyAsync(m->d_pose, m->up_pose.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice, st));
     }
     if (max_pts > 0) {
-        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + kMapTile - 1) / kMapTile, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
                            (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, m->counters);
         MHIP(m, hipGetLastError());

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * kTkWaves) void k_tk_decide(Arena A, TrackBatch
 
 // per apri point: dynamic when its cluster was decided dynamic; points of clusters the bounding-box refine erased belong
 // to no cluster (the reference lists them as static, ssc.cpp:450-454)
-__global__ __launch_bounds__(256) void k_tk_dyn(Arena A) {
+__global__ __launch_bounds__(256) void k_tk_dyn(Arena A, int from_apri) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void k_tk_dyn(Arena A) {
         else if (t == 2 && A.cl_state[(size_t)base + A.pt_cluster[(size_t)base + i]] == 1)
             d = SCVOD_DYN_DYNAMIC;
         A.pt_dyn[(size_t)base + i] = d;
+        if (!from_apri) A.pt_mapcls[(size_t)base + A.apri_src[(size_t)base + i]] = (d == SCVOD_DYN_DYNAMIC) ? kMapDynamic : kMapApri;
     }
 }
 
@@ -418,7 +419,7 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     }
     TH_END("tk_decide");
     TH_BEGIN("tk_dyn");
-    hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A, from_apri);
     TH_END("tk_dyn");
 }
 
