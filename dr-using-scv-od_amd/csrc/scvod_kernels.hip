@@ -1961,13 +1961,29 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     __syncthreads();
     // runs inside a voxel: a slot whose triple differs from the previous slot's opens one (ssc.cpp:306-330 walks the
     // voxel's points with their own triples; equal triples have equal neighbourhoods)
-    for (int k = tid; k < n; k += kCcThreads) {
-        if (cc_bit(vstart, k)) continue;
-        if (idx3[vpts[k]] != idx3[vpts[k - 1]]) {
-            const int e = atomicAdd(&n_extra_s, 1);
-            extras[e] = k;
-            extra_of_slot[k] = e;
-            cc_set(rstart, k);
+    for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {
+        int pa[4], pb[4], ta[4], tb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // the two dependent gathers of four slots in flight together
+            const int k = min(k0 + u * kCcThreads + tid, n - 1);
+            pa[u] = vpts[k];
+            pb[u] = vpts[max(k - 1, 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ta[u] = idx3[pa[u]];
+            tb[u] = idx3[pb[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * kCcThreads + tid;
+            if (k >= n || cc_bit(vstart, k)) continue;
+            if (ta[u] != tb[u]) {
+                const int e = atomicAdd(&n_extra_s, 1);
+                extras[e] = k;
+                extra_of_slot[k] = e;
+                cc_set(rstart, k);
+            }
         }
     }
     // prefix[w] = voxel starts in the words before w: voxel of slot k = prefix[k >> 5] + popc(vstart word up to k) - 1
@@ -2040,7 +2056,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         flat[j] = r;
     }
     __syncthreads();
-    int* slot_cid = (int*)(A.tk_pairs + base);      // [n] compact id of the slot's point, -1 = a cluster of its own
+    int* slot_cid = (int*)(A.tk_pairs + base);      // [n] compact id of every apri point's component, -1 = a cluster of its own
     int* rootcid = slot_cid + n;                    // [nn]
     int* names = A.tk_nuniq + base;                 // [ncl] canonical name per compact id
     int ncl = 0;
@@ -2077,7 +2093,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
             // something joined what the opener joined
             cid = cc_bit(found, node) ? parent[node] : -1;
         }
-        slot_cid[k] = cid;
+        slot_cid[p] = cid;  // (indexed by apri point from here on: the passes below stream the points in order)
         A.pt_cluster[(size_t)base + p] = cid >= 0 ? names[cid] : p;
     }
     __syncthreads();
@@ -2095,49 +2111,57 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     __syncthreads();
     {
         const int lane = tid & 63;
-        for (int k0 = 0; k0 < n; k0 += kCcThreads) {
-            const int k = k0 + tid;
-            int cid = -1;
-            uint32_t ox = 0, oy = 0, oz = 0;
-            if (k < n) {
-                cid = slot_cid[k];
-                const int p = vpts[k];
-                if (cid < 0) {  // one point: z extent 0 < 0.2 m, erased whatever toBeClass is (ssc.cpp:444)
-                    A.pt_type[(size_t)base + p] = 0;
-                    A.cl_count[(size_t)base + p] = 1;
-                } else if (from_apri) {  // apri_vec supplied by the caller: no input cloud on the device
-                    const scvod_apri& a = A.apri[(size_t)base + p];
-                    ox = f2ord(a.x);
-                    oy = f2ord(a.y);
-                    oz = f2ord(a.z);
-                } else {  // cloud_use[p] = input point apri_src[p]
-                    const float4 q = A.pts[base + A.apri_src[(size_t)base + p]];
-                    ox = f2ord(q.x);
-                    oy = f2ord(q.y);
-                    oz = f2ord(q.z);
+        constexpr int U = 4;  // four points per thread and step: their index and point loads are in flight together
+        for (int i0 = 0; i0 < n; i0 += kCcThreads * U) {
+            int cidv[U], srcv[U];
+            float4 qv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kCcThreads + tid;
+                cidv[u] = (i < n) ? slot_cid[i] : -2;
+                srcv[u] = (i < n && !from_apri) ? A.apri_src[(size_t)base + i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(i0 + u * kCcThreads + tid, n - 1);
+                if (from_apri) {  // apri_vec supplied by the caller: no input cloud on the device
+                    const scvod_apri& a = A.apri[(size_t)base + i];
+                    qv[u] = make_float4(a.x, a.y, a.z, 0.f);
+                } else {  // cloud_use[i] = input point apri_src[i]
+                    qv[u] = A.pts[base + srcv[u]];
                 }
             }
-            // neighbouring slots mostly share the component: one lane per distinct component of the wave updates the box
-            bool todo = cid >= 0;
-            while (__any(todo)) {
-                const int first = __ffsll((long long)__ballot(todo)) - 1;
-                const int c0 = __shfl(cid, first);
-                const bool mine = todo && (cid == c0);
-                const int cnt = __popcll(__ballot(mine));
-                const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mny = wave_min_u32(mine ? oy : 0xffffffffu),
-                               mnz = wave_min_u32(mine ? oz : 0xffffffffu);
-                const uint32_t mxx = wave_max_u32(mine ? ox : 0u), mxy = wave_max_u32(mine ? oy : 0u), mxz = wave_max_u32(mine ? oz : 0u);
-                if (lane == first) {
-                    uint32_t* r = c0 < kCcBoxes ? bb + 7 * c0 : ov + 7 * (size_t)(c0 - kCcBoxes);
-                    atomicMin(&r[0], mnx);
-                    atomicMin(&r[1], mny);
-                    atomicMin(&r[2], mnz);
-                    atomicMax(&r[3], mxx);
-                    atomicMax(&r[4], mxy);
-                    atomicMax(&r[5], mxz);
-                    atomicAdd(&r[6], (uint32_t)cnt);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * kCcThreads + tid;
+                const int cid = cidv[u];
+                if (cid == -1) {  // one point: z extent 0 < 0.2 m, erased whatever toBeClass is (ssc.cpp:444)
+                    A.pt_type[(size_t)base + i] = 0;
+                    A.cl_count[(size_t)base + i] = 1;
                 }
-                if (mine) todo = false;
+                const uint32_t ox = f2ord(qv[u].x), oy = f2ord(qv[u].y), oz = f2ord(qv[u].z);
+                // neighbouring points mostly share the component: one lane per distinct component of the wave updates the box
+                bool todo = cid >= 0;
+                while (__any(todo)) {
+                    const int first = __ffsll((long long)__ballot(todo)) - 1;
+                    const int c0 = __shfl(cid, first);
+                    const bool mine = todo && (cid == c0);
+                    const int cnt = __popcll(__ballot(mine));
+                    const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mny = wave_min_u32(mine ? oy : 0xffffffffu),
+                                   mnz = wave_min_u32(mine ? oz : 0xffffffffu);
+                    const uint32_t mxx = wave_max_u32(mine ? ox : 0u), mxy = wave_max_u32(mine ? oy : 0u), mxz = wave_max_u32(mine ? oz : 0u);
+                    if (lane == first) {
+                        uint32_t* r = c0 < kCcBoxes ? bb + 7 * c0 : ov + 7 * (size_t)(c0 - kCcBoxes);
+                        atomicMin(&r[0], mnx);
+                        atomicMin(&r[1], mny);
+                        atomicMin(&r[2], mnz);
+                        atomicMax(&r[3], mxx);
+                        atomicMax(&r[4], mxy);
+                        atomicMax(&r[5], mxz);
+                        atomicAdd(&r[6], (uint32_t)cnt);
+                    }
+                    if (mine) todo = false;
+                }
             }
         }
     }
@@ -2164,11 +2188,11 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         A.cl_count[(size_t)base + names[c]] = cnt;  // Cluster::occupy_pts.size(), kept at the cluster's canonical name
     }
     __syncthreads();
-    for (int k = tid; k < n; k += kCcThreads) {
-        const int cid = slot_cid[k];
+    for (int i = tid; i < n; i += kCcThreads) {
+        const int cid = slot_cid[i];
         if (cid < 0) continue;
         const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
-        A.pt_type[(size_t)base + vpts[k]] = (uint8_t)r[0];
+        A.pt_type[(size_t)base + i] = (uint8_t)r[0];
     }
 }
 
