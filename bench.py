@@ -122,7 +122,8 @@ def main():
     P = scvod_py.make_params(args.preset)
     if args.skip <= 0:
         args.skip = 1 if args.preset == "parkinglot" else 5
-    plan = shard.plan_job(world, args.scans, synth.SEQ_LEN, blocks_per_rank=args.blocks_per_rank, skip=args.skip)[rank]
+    bpr = max(1, min(args.blocks_per_rank, args.scans // max(args.skip, 1)))  # a block holds at least one tracking stride
+    plan = shard.plan_job(world, args.scans, synth.SEQ_LEN, blocks_per_rank=bpr, skip=args.skip)[rank]
     n_sc = len(plan["scans"])
 
     # ---- the rank's scans, resident in HBM ----
@@ -363,11 +364,11 @@ def main():
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 else
-                                       f"seq 05,00,02,08,...-shaped {args.kind} scans, {int(all_scans)} in total, {args.blocks_per_rank * world} blocks round-robin over {world} ranks, {args.preset}.yaml grid"),
+                                       f"seq 05,00,02,08,...-shaped {args.kind} scans, {int(all_scans)} in total, {bpr * world} blocks round-robin over {world} ranks, {args.preset}.yaml grid"),
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
                           "static_map_cells": map_cells, "boundary_tables_per_step": len(plan["send_scans"]),
-                          "rccl_ranks": world, "tracking_stride": args.skip, "sharding": f"{args.blocks_per_rank} blocks per rank, block k on rank k % {world}"},
+                          "rccl_ranks": world, "tracking_stride": args.skip, "sharding": f"{bpr} blocks per rank, block k on rank k % {world}"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
         if world > 1:

@@ -347,6 +347,12 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->A.n_scans = n_scans;
     c->A.max_scan_pts = mx;
     c->A.total_pts = total;
+    {   // 32-bit voxel sort keys when a bucket-relative key and a scan-local index fit together (filtered keys never leave the grid)
+        int ib = 1;
+        while ((1 << ib) < mx) ++ib;
+        c->A.vx_idx_bits = ib;
+        c->A.vx_k32 = (do_patchwork != 3 && apply_filter && c->dev.vb_shift + ib <= 32) ? 1 : 0;
+    }
     c->tim_used = 0;
     c->batch_valid = false;
     c->counts_valid = false;
@@ -535,6 +541,7 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     Av.vb_lut_shift = c->A.vg_range + 1;  // second word of the two-int scratch
     Av.vg_labels = d_labels;
     Av.vg_max_intensity = max_intensity;
+    Av.vx_k32 = 0;  // cell indices are not bucket-relative: 64-bit sort keys
     DevParams D = c->dev;
     D.key_off = 0;
     D.vb_shift = 0;
@@ -567,7 +574,9 @@ int upload_if_changed(scvod_ctx* c, std::vector<T>& held, const T* src, size_t n
 
 // internal bridge for scvod_map.hip (not part of the public header)
 extern "C" int scvod__ctx_view(scvod_ctx* c, Arena* arena, int* device, int* track_valid, int* batch_valid, int* n_scans,
-                               int* max_scan_pts) {
+                               int* max_scan_pts, int* batch_mode, int* num_min_pts) {
+    *batch_mode = c->batch_mode;
+    *num_min_pts = c->pw.num_min_pts;
     *arena = c->A;
     *device = c->device;
     *track_valid = c->track_valid ? 1 : 0;

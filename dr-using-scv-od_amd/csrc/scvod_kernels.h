@@ -14,9 +14,10 @@ namespace scvod {
 constexpr int kMaxPatches = SCVOD_MAX_PATCHES;
 constexpr int kMaxBuckets = 1024;
 constexpr int kVgLutBins = 16384;
-// which of the reference's clouds an input point ended up in (k_emit / k_bin_direct, k_tk_dyn): the static map streams the
-// input in order and keeps cloud_out, cloud_eva_static and the apri points that are not dynamic
-constexpr uint8_t kMapNone = 0, kMapGround = 1, kMapRejected = 2, kMapApri = 3, kMapDynamic = 4;
+// marks per INPUT point for the static map, which streams the input in order: whether Patchwork kept a point at all follows
+// from its patch id (pid) and that patch's population; k_tk_dyn marks the members of dynamic clusters; the two list marks are
+// only written when a caller asks for a map without the ground or without the range/FOV rejects
+constexpr uint8_t kMapDynamic = 1, kMapGround = 2, kMapRejected = 4;
 
 struct Xyz {
     float x, y, z;
@@ -91,7 +92,10 @@ struct Arena {
     int32_t* vorder_hist;     // [64]
     int32_t* vorder_cursor;   // [64]
     int32_t* vorder_off;      // [65]
-    uint64_t* vkeys;          // [N] (biased voxel key << 32 | apri idx), bucket-major per scan
+    uint64_t* vkeys;          // [N] (biased voxel key << 32 | apri idx), bucket-major per scan; or 32-bit keys (vx_k32)
+    int32_t vx_k32;           // 1: the voxel stage of this batch sorts 32-bit keys: (key - bucket's first key) << vx_idx_bits | apri idx
+                              //    (range/FOV-filtered keys only: every key lies inside its bucket's range; vb_shift + vx_idx_bits <= 32)
+    int32_t vx_idx_bits;      // bits of an apri index inside one scan of this batch
     int32_t* tmp_vox_key;     // [N] per-bucket voxel records before compaction
     int32_t* tmp_vox_begin;   // [N]
     float* tmp_vox_av;        // [N]
@@ -126,7 +130,7 @@ struct Arena {
     int32_t* tk_clusters;     // [N] per scan: roots of its car clusters, ascending
     int32_t* tk_scan;         // [B][4] per scan: car clusters, car points, dynamic clusters, dynamic points
     uint8_t* pt_dyn;          // [N] per apri point: SCVOD_DYN_*
-    uint8_t* pt_mapcls;       // [N] per INPUT point, for the static map: kMap* (which cloud of the reference holds it)
+    uint8_t* pt_mapcls;       // [N] per INPUT point, for the static map: kMap* bits
     // loader-side VoxelGrid
     int32_t* vg_par;          // [B][16] per scan: min_b[3], mul[3], overflow flag, kept points, distinct cells
     int32_t* vg_range;        // [1] largest cell index range of the batch

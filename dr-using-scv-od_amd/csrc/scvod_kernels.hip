@@ -1231,7 +1231,6 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
             for (int e = lane; e < r.n_g; e += 64) {
                 const uint32_t id = seg[e] & 0x7fffffffu;
                 A.ground_idx[(size_t)base + xg + e] = (int32_t)id;
-                A.pt_mapcls[(size_t)base + id] = kMapGround;
             }
         }
         // non-ground stream of this patch: for a rejected patch the ground part (front, ascending) followed
@@ -1276,10 +1275,8 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     A.apri_key[dst0 + ek] = a.voxel_idx;
                     A.apri_int[dst0 + ek] = a.intensity;
                     A.apri_idx3[dst0 + ek] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
-                    A.pt_mapcls[(size_t)base + id] = kMapApri;
                 } else {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
-                    A.pt_mapcls[(size_t)base + id] = kMapRejected;
                 }
             }
             run_keep += nk;
@@ -1547,10 +1544,8 @@ __global__ __launch_bounds__(1024) void k_bin_direct(DevParams P, Arena A, int a
                 A.apri_key[dst] = a.voxel_idx;
                 A.apri_int[dst] = a.intensity;
                 A.apri_idx3[dst] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
-                A.pt_mapcls[(size_t)base + i] = kMapApri;
             } else {
                 A.rejected_src[(size_t)base + (i - (run + ek))] = i;
-                A.pt_mapcls[(size_t)base + i] = kMapRejected;
             }
         }
         run += tk;
@@ -1661,19 +1656,32 @@ __global__ __launch_bounds__(kVxThreads) void k_vx_scatter(DevParams P, Arena A)
 #pragma unroll
     for (int it = 0; it < kVxItems; ++it) {
         int i = start + it * kVxThreads + threadIdx.x;
-        if (bk[it] >= 0) A.vkeys[(size_t)base + hist[bk[it]] + rank[it]] = pack_key(vx_bias(key[it]), (uint32_t)i);
+        if (bk[it] >= 0) {
+            const size_t at = (size_t)base + hist[bk[it]] + rank[it];
+            if (A.vx_k32)  // key relative to its bucket's first key | apri index: fits 32 bits (see vx_k32 in scvod_kernels.h)
+                ((uint32_t*)A.vkeys)[at] = (uint32_t)((((int64_t)key[it] + P.key_off) & ((1ll << P.vb_shift) - 1)) << A.vx_idx_bits) | (uint32_t)i;
+            else
+                A.vkeys[at] = pack_key(vx_bias(key[it]), (uint32_t)i);
+        }
     }
 }
 
 // MODE 0: SSC::makeHashCloud (intensity mean / variance per voxel).  MODE 1: pcl::VoxelGrid run (keys = cell indices):
 // per cell the CentroidPoint sums of its points in ascending input index, straight from the sorted keys in LDS; no
 // point lists, no intensity statistics; the bucket of the dropped points is skipped.
-template <int CAP, int THREADS, int C_LO, int C_HI, int LGE, int MODE = 0>
+// KT = unsigned long long: (biased voxel key, apri index) under the double-encoded exponent (any key, VoxelGrid cells).
+// KT = uint32_t: hot path of a filtered batch -- (key - first key of the bucket) << idx_bits | apri index; a bucket spans
+// 2^vb_shift keys and a scan 2^idx_bits points, vb_shift + idx_bits <= 32 (checked on the host): half the LDS traffic, and
+// the compare-exchange is a full-rate v_min_u32 + v_max_u32.
+template <int CAP, int THREADS, int C_LO, int C_HI, int LGE, int MODE = 0, typename KT = unsigned long long>
 __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool K32 = sizeof(KT) == 4;
+    constexpr bool PADK = true;  // both key types: unpadded 4-byte keys let the compiler fuse neighbouring LDS accesses into
+                                 // wide ones that fault on the network's unaligned groups (seen on the 8192-key tier)
     constexpr int SLOTS = CAP + CAP / 8;
-    unsigned long long* l_keys = (unsigned long long*)smem;   // padded layout
-    int* l_vbeg = (int*)(smem + (size_t)SLOTS * 8);           // [CAP]
+    KT* l_keys = (KT*)smem;   // padded layout (8-byte keys)
+    int* l_vbeg = (int*)(smem + (size_t)SLOTS * 8);           // [CAP]  (the key area keeps its 8-byte size for both key types)
     float* l_int = (float*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 4);  // [CAP] intensity in sorted order
     int* wsum = (int*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 8);
     int lo, hi;
@@ -1689,26 +1697,30 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         continue;
     }
     const bool in_lds = (m <= CAP);
-    unsigned long long* keys;
+    KT* keys;
     int* vbeg;
     float* ints;
+    KT* gkeys = (KT*)A.vkeys + (size_t)base + off;
+    const KT kpad = K32 ? (KT)0xffffffffu : (KT)kKeyPad;
+    const uint32_t imask = (1u << A.vx_idx_bits) - 1u;
+    auto k_major = [&](KT k) -> uint32_t { return K32 ? (uint32_t)k >> A.vx_idx_bits : key_major((unsigned long long)k); };
+    auto k_idx = [&](KT k) -> uint32_t { return K32 ? (uint32_t)k & imask : key_idx((unsigned long long)k); };
     if (in_lds) {
         int np2 = 1 << LGE;
         while (np2 < m) np2 <<= 1;
-        for (int j = threadIdx.x; j < np2; j += THREADS)
-            l_keys[sort_slot<true>(j)] = (j < m) ? A.vkeys[(size_t)base + off + j] : kKeyPad;
+        for (int j = threadIdx.x; j < np2; j += THREADS) l_keys[sort_slot<PADK>(j)] = (j < m) ? gkeys[j] : kpad;
         __syncthreads();
         keys = l_keys;
         vbeg = l_vbeg;
         ints = l_int;
-        block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
+        block_bitonic_sort_pow2<THREADS, PADK, LGE>(keys, np2);
     } else {
-        keys = (unsigned long long*)(A.vkeys + (size_t)base + off);
+        keys = gkeys;
         vbeg = A.tmp_vox_begin + (size_t)base + off;  // rewritten below with final values
         ints = A.tmp_vox_av + (size_t)base + off;     // m >= nv entries: used as staging, rewritten below
         block_bitonic_sort<THREADS, false>(keys, m);
     }
-#define KX(j) (in_lds ? sort_slot<true>(j) : (j))
+#define KX(j) (in_lds ? sort_slot<PADK>(j) : (j))
     // head flags + compaction of voxel starts; stage the intensities in sorted order
     int run = 0;
     for (int c0 = 0; c0 < m; c0 += THREADS) {
@@ -1716,10 +1728,10 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         int head = 0;
         if (j < m) {
             // never form keys[-1]: with flat addressing that leaves the LDS aperture
-            const uint64_t cur = keys[KX(j)];
-            const uint64_t prev = keys[KX(j > 0 ? j - 1 : 0)];
-            head = (j == 0) || (key_major(cur) != key_major(prev));
-            const uint32_t idx = key_idx(cur);
+            const KT cur = keys[KX(j)];
+            const KT prev = keys[KX(j > 0 ? j - 1 : 0)];
+            head = (j == 0) || (k_major(cur) != k_major(prev));
+            const uint32_t idx = k_idx(cur);
             if (MODE == 0) A.vox_pts[(size_t)base + off + j] = (int32_t)idx;
         }
         int th;
@@ -1738,7 +1750,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
             const int j1 = (v + 1 < nv) ? vbeg[v + 1] : m;
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
             for (int j = j0; j < j1; ++j) {
-                const float4 p = A.pts[base + key_idx(keys[KX(j)])];
+                const float4 p = A.pts[base + k_idx(keys[KX(j)])];
                 sx += p.x;
                 sy += p.y;
                 sz += p.z;
@@ -1752,7 +1764,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         continue;
     }
     if (in_lds) {
-        for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + key_idx(keys[KX(j)])];
+        for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + k_idx(keys[KX(j)])];
         __syncthreads();
     }
     // per voxel: sequential fp32 mean, then population variance accumulated as float += double
@@ -1763,18 +1775,19 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         if (in_lds) {
             for (int j = j0; j < j1; ++j) av += ints[j];
         } else {
-            for (int j = j0; j < j1; ++j) av += A.apri_int[(size_t)base + key_idx(keys[j])];
+            for (int j = j0; j < j1; ++j) av += A.apri_int[(size_t)base + k_idx(keys[j])];
         }
         const float fn = (float)(j1 - j0);
         av = av / fn;
         float cov = 0.f;
         for (int j = j0; j < j1; ++j) {
-            const float in = in_lds ? ints[j] : A.apri_int[(size_t)base + key_idx(keys[j])];
+            const float in = in_lds ? ints[j] : A.apri_int[(size_t)base + k_idx(keys[j])];
             const double d = (double)(in - av);
             cov = (float)((double)cov + d * d);
         }
         cov = cov / fn;
-        A.tmp_vox_key[(size_t)base + off + v] = vx_unbias(key_major(keys[KX(j0)]));
+        A.tmp_vox_key[(size_t)base + off + v] = K32 ? (int32_t)(((int64_t)b << P.vb_shift) + (int64_t)k_major(keys[KX(j0)]) - P.key_off)
+                                                      : vx_unbias(k_major(keys[KX(j0)]));
         A.tmp_vox_cov[(size_t)base + off + v] = cov;
         A.tmp_vox_av[(size_t)base + off + v] = av;
     }
@@ -2468,7 +2481,6 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
     const int B = A.n_scans;
     if (B <= 0) return;
     if (do_patchwork == 1) {
-        hipMemsetAsync(A.pt_mapcls, kMapNone, (size_t)A.total_pts, st);  // points Patchwork drops stay in no cloud
         hipMemsetAsync(A.patch_count, 0, sizeof(int32_t) * (size_t)B * kMaxPatches, st);
         hipMemsetAsync(A.patch_cursor, 0, sizeof(int32_t) * (size_t)B * kMaxPatches, st);
         dim3 gcls((A.max_scan_pts + kClsThreads * kClsItems - 1) / (kClsThreads * kClsItems), B);
@@ -2586,30 +2598,36 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
             hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
             return;
         }
-        hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
-        hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
-        TH_BEGIN("vx_bucket_8192");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv>), dim3(kPersistCUs), dim3(kVoxThreadsL * kTSv),
-                           vox_lds_bytes(kVoxCapL), st, P, A);
-        TH_END("vx_bucket_8192");
-        TH_BEGIN("vx_bucket_4096");
-        hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv>), dim3(kPersistCUs * 2), dim3(256 * kTSv),
-                           vox_lds_bytes(4096), st, P, A);
-        TH_END("vx_bucket_4096");
-        TH_BEGIN("vx_bucket_2048");
-        hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv>), dim3(kPersistCUs * 4), dim3(128 * kTSv),
-                           vox_lds_bytes(2048), st, P, A);
-        TH_END("vx_bucket_2048");
-        TH_BEGIN("vx_bucket_1024");
-        hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS * kTSv, kClassXS, kClassM - 1, kLGEv>), dim3(kPersistCUs * 8),
-                           dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS), st, P, A);
-        TH_END("vx_bucket_1024");
-        TH_BEGIN("vx_bucket_256");
-        hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st,
-                           P, A);
-        TH_END("vx_bucket_256");
+        auto bucket_tiers = [&](auto kt) {
+            using KT = decltype(kt);
+            hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv, 0, KT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
+            hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 0, KT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
+            TH_BEGIN("vx_bucket_8192");
+            hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv, 0, KT>), dim3(kPersistCUs), dim3(kVoxThreadsL * kTSv),
+                               vox_lds_bytes(kVoxCapL), st, P, A);
+            TH_END("vx_bucket_8192");
+            TH_BEGIN("vx_bucket_4096");
+            hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 0, KT>), dim3(kPersistCUs * 2), dim3(256 * kTSv),
+                               vox_lds_bytes(4096), st, P, A);
+            TH_END("vx_bucket_4096");
+            TH_BEGIN("vx_bucket_2048");
+            hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv, 0, KT>), dim3(kPersistCUs * 4), dim3(128 * kTSv),
+                               vox_lds_bytes(2048), st, P, A);
+            TH_END("vx_bucket_2048");
+            TH_BEGIN("vx_bucket_1024");
+            hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS * kTSv, kClassXS, kClassM - 1, kLGEv, 0, KT>), dim3(kPersistCUs * 8),
+                               dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS), st, P, A);
+            TH_END("vx_bucket_1024");
+            TH_BEGIN("vx_bucket_256");
+            hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3, 0, KT>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st, P, A);
+            TH_END("vx_bucket_256");
+        };
+        if (A.vx_k32)
+            bucket_tiers((uint32_t)0);
+        else
+            bucket_tiers((unsigned long long)0);
         TH_BEGIN("vx_final_offsets");
         hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("vx_final_offsets");

@@ -41,6 +41,7 @@ struct scvod_map {
     std::string err;
 };
 
+namespace scvod {
 namespace {
 
 constexpr unsigned long long kEmpty = ~0ull;
@@ -121,8 +122,8 @@ __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mas
 // consecutive lanes that fall into the same cell are reduced in the wave first (segmented min over the run) and only the
 // head of a run probes the table in HBM.
 __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
-                                                        float inv_leaf, int with_ground, int with_rejected, int have_dyn,
-                                                        unsigned long long* counters) {
+                                                        float inv_leaf, int with_ground, int with_rejected, int have_dyn, int have_pid,
+                                                        int min_pts, int marks, unsigned long long* counters) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.scan_off[s + 1] - base;
@@ -135,9 +136,17 @@ __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __
         const int i = i0 + threadIdx.x;
         unsigned long long key = kEmpty, val = kEmpty;
         if (i < n) {
-            const uint8_t c = A.pt_mapcls[(size_t)base + i];
-            const bool keep = (c == kMapGround && with_ground) || (c == kMapRejected && with_rejected) || c == kMapApri ||
-                              (c == kMapDynamic && !have_dyn);
+            // in a cloud at all?  Patchwork drops the points outside its range gate / below the z cut (pid < 0) and whole
+            // patches of at most num_min_pts points (patchwork.h:331); a batch binned without Patchwork keeps every point
+            bool keep = true;
+            if (have_pid) {
+                const int pid = A.pid[(size_t)base + i];
+                keep = pid >= 0 && A.patch_count[s * kMaxPatches + pid] > min_pts;
+            }
+            if (keep && marks) {
+                const uint8_t c = A.pt_mapcls[(size_t)base + i];
+                keep = !((c & kMapDynamic) && have_dyn) && !((c & kMapGround) && !with_ground) && !((c & kMapRejected) && !with_rejected);
+            }
             if (keep) {
                 const float4 q = A.pts[base + i];
                 const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
@@ -164,6 +173,19 @@ __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __
         if (head && key != kEmpty && !map_insert(table, mask, key, val)) ++dropped;
     }
     if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
+}
+
+// only for maps without the ground or without the range/FOV rejects: mark the members of those two lists
+__global__ __launch_bounds__(256) void k_map_mark_lists(Arena A) {
+    const int s = blockIdx.y;
+    const int base = A.scan_off[s];
+    const int n_g = A.counts[s * 8 + 1], n_r = A.counts[s * 8 + 5];
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_g + n_r; t += gridDim.x * 256) {
+        if (t < n_g)
+            A.pt_mapcls[(size_t)base + A.ground_idx[(size_t)base + t]] = kMapGround;
+        else
+            A.pt_mapcls[(size_t)base + A.rejected_src[(size_t)base + (t - n_g)]] = kMapRejected;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_map_merge(const MapRec* __restrict__ recs, long long n, MapRec* table, unsigned long long mask,
@@ -209,11 +231,12 @@ __global__ __launch_bounds__(256) void k_map_export(const MapRec* __restrict__ t
 }
 
 }  // namespace
+}  // namespace scvod
 
 // the one place the map code needs the batch context: its arena, parameters and validity flags
 struct scvod_ctx;
 extern "C" int scvod__ctx_view(scvod_ctx* ctx, Arena* arena, int* device, int* track_valid, int* batch_valid, int* n_scans,
-                               int* max_scan_pts);
+                               int* max_scan_pts, int* batch_mode, int* num_min_pts);
 
 extern "C" {
 
@@ -283,8 +306,8 @@ void scvod_pose_matrix(const float p[6], float t[12]) {
 int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_poses, int32_t flags, void* stream) {
     if (!ctx || !m || !h_poses) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
     Arena A;
-    int device = 0, track_valid = 0, batch_valid = 0, n_scans = 0, max_pts = 0;
-    scvod__ctx_view(ctx, &A, &device, &track_valid, &batch_valid, &n_scans, &max_pts);
+    int device = 0, track_valid = 0, batch_valid = 0, n_scans = 0, max_pts = 0, mode = 0, min_pts = 0;
+    scvod__ctx_view(ctx, &A, &device, &track_valid, &batch_valid, &n_scans, &max_pts, &mode, &min_pts);
     if (!batch_valid || !A.pts) return mfail(m, SCVOD_ERR_STATE, "scvod_batch_map_accumulate needs a processed batch of input clouds");
     const int use_dyn = !(flags & SCVOD_MAP_IGNORE_DYNAMIC);
     if (use_dyn && !track_valid) return mfail(m, SCVOD_ERR_STATE, "no tracking result: run scvod_batch_track or pass SCVOD_MAP_IGNORE_DYNAMIC");
@@ -308,9 +331,14 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
         MHIP(m, hipMemcpyAsync(m->d_pose, m->up_pose.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice, st));
     }
     if (max_pts > 0) {
-        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+        const int need_lists = (flags & (SCVOD_MAP_NO_GROUND | SCVOD_MAP_NO_REJECTED)) ? 1 : 0;
+        if (need_lists) {  // rare: a map without the ground / without the range-FOV rejects needs those two lists marked
+            if (!track_valid) MHIP(m, hipMemsetAsync(A.pt_mapcls, 0, (size_t)A.total_pts, st));  // (tracking clears the marks itself)
+            hipLaunchKernelGGL(k_map_mark_lists, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A);
+        }
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 1023) / 1024, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
-                           (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, m->counters);
+                           (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, mode == 1 ? 1 : 0, min_pts, (use_dyn || need_lists) ? 1 : 0, m->counters);
         MHIP(m, hipGetLastError());
     }
     return SCVOD_OK;

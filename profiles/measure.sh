@@ -1,6 +1,6 @@
 #!/bin/bash
-# Measurement set of one round, run on the MI355X box:  gpurun -- 'bash profiles/measure.sh r1d'
-# then here:  python profiles/refresh.py gpurun_out/r1d r01
+# Measurement set of one round, run on the MI355X box:  gpurun --timeout 2400 -- 'bash profiles/measure.sh r2'
+# then here:  python profiles/refresh.py gpurun_out/r2 r02
 # (PMC passes carry --kernel-trace only through the counter collection itself: no --sys-trace / hip / hsa domains.)
 set -u
 tag=${1:-set}
@@ -8,19 +8,35 @@ R=$(pwd)
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-python bench.py > "$out/bench_full.json" 2> "$out/bench_full.err"
+# 1. the headline line (BASELINE configs[1]) and the two other single-GPU configs, as the driver runs them
+timeout 600 python bench.py > "$out/bench_full.json" 2> "$out/bench_full.err"
+timeout 400 python bench.py --kind PARK --preset parkinglot --scans 2000 > "$out/bench_park.json" 2> "$out/bench_park.err"
+timeout 400 python bench.py --kind OS128 --preset os128_fine --scans 1000 > "$out/bench_os128.json" 2> "$out/bench_os128.err"
 cd /tmp
-rm -rf /tmp/prof_stats /tmp/prof_f /tmp/prof_w
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$R/bench.py" --scans 1024 --steps 2 --no-cpu --no-cpu-all --no-extras \
-    > "$out/bench_under_rocprof.json" 2> "$out/rocprof_stats.err"
-f=$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && cp "$f" "$out/rocprofv3_kernel_stats.csv"
+# 2. rocprofv3 kernel trace + stats of the same command at 1024 scans (the trace of 2761 scans x 3 steps is only bigger)
+for cfg in "k64:--scans 1024" "park:--kind PARK --preset parkinglot --scans 1024" "os128:--kind OS128 --preset os128_fine --scans 512"; do
+    name=${cfg%%:*}; args=${cfg#*:}
+    rm -rf /tmp/prof_stats_$name
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$name -- python "$R/bench.py" $args --steps 2 --no-cpu --no-extras \
+        > "$out/bench_under_rocprof_$name.json" 2> "$out/rocprof_stats_$name.err"
+    f=$(find /tmp/prof_stats_$name -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && cp "$f" "$out/rocprofv3_kernel_stats_$name.csv"
+done
+# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (512 scans, one step, no warm-up: one dispatch per kernel)
 for c in FETCH_SIZE WRITE_SIZE; do
     d=/tmp/prof_$c
     rm -rf $d
-    rocprofv3 --pmc $c --kernel-include-regex scvod --output-format csv -d $d -- python "$R/bench.py" --scans 512 --steps 1 --warmup 0 --no-cpu --no-cpu-all --no-extras \
+    timeout 600 rocprofv3 --pmc $c --kernel-include-regex scvod --output-format csv -d $d -- python "$R/bench.py" --scans 512 --steps 1 --warmup 0 --no-cpu --no-extras \
         > /dev/null 2> "$out/rocprof_$c.err"
     f=$(find $d -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && (head -1 "$f"; grep scvod "$f") > "$out/${c}_counter_collection.csv"
 done
+# 4. SQ counters (what bounds a kernel: issue vs wait, VALU vs LDS share, LDS bank conflicts), 256 scans
+d=/tmp/prof_sq
+rm -rf $d
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+    --kernel-include-regex scvod --output-format csv -d $d -- python "$R/bench.py" --scans 256 --steps 1 --warmup 0 --no-cpu --no-extras \
+    > /dev/null 2> "$out/rocprof_sq.err"
+f=$(find $d -name '*counter_collection.csv' | head -1)
+[ -n "$f" ] && (head -1 "$f"; grep scvod "$f") > "$out/SQ_counter_collection.csv"
 ls -la "$out"

@@ -1,13 +1,12 @@
-"""Turns a gpurun_out/<dir> measurement set into the committed summaries under profiles/.
-usage: python profiles/refresh.py gpurun_out/r1c r01
-expects: bench_full.json, bench_under_rocprof.json, rocprofv3_kernel_stats.csv,
-         FETCH_SIZE_counter_collection.csv, WRITE_SIZE_counter_collection.csv (512-scan PMC runs)"""
+"""Turns a gpurun_out/<dir> measurement set (profiles/measure.sh) into the committed summaries under profiles/.
+usage: python profiles/refresh.py gpurun_out/r2 r02
+expects: bench_full.json, bench_park.json, bench_os128.json, bench_under_rocprof_{k64,park,os128}.json,
+         rocprofv3_kernel_stats_{k64,park,os128}.csv, FETCH_SIZE / WRITE_SIZE / SQ _counter_collection.csv"""
 import collections
 import csv
 import json
 import os
 import re
-import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
@@ -15,78 +14,102 @@ here = os.path.dirname(os.path.abspath(__file__))
 for f in os.listdir(here):
     if f.startswith(tag + "_"):
         os.remove(os.path.join(here, f))
-rows = [r for r in csv.DictReader(open(os.path.join(src, "rocprofv3_kernel_stats.csv"))) if "scvod::" in r["Name"]]
-tot = sum(int(r["TotalDurationNs"]) for r in rows)
-with open(os.path.join(here, f"{tag}_rocprofv3_kernel_stats_scvod.csv"), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "PercentOfScvod", "MinNs", "MaxNs"])
-    for r in sorted(rows, key=lambda r: -int(r["TotalDurationNs"])):
-        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], round(100 * int(r["TotalDurationNs"]) / tot, 2),
-                    r["MinNs"], r["MaxNs"]])
-for name in ("bench_full", "bench_under_rocprof"):
-    json.dump(json.load(open(os.path.join(src, name + ".json"))), open(os.path.join(here, f"{tag}_{name}.json"), "w"), indent=1)
+
+
+def last_json(path):
+    lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+for name in ("k64", "park", "os128"):
+    p = os.path.join(src, f"rocprofv3_kernel_stats_{name}.csv")
+    if not os.path.exists(p):
+        continue
+    rows = [r for r in csv.DictReader(open(p)) if "scvod::" in r["Name"]]
+    tot = sum(int(r["TotalDurationNs"]) for r in rows) or 1
+    with open(os.path.join(here, f"{tag}_rocprofv3_kernel_stats_{name}.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "PercentOfScvod", "MinNs", "MaxNs"])
+        for r in sorted(rows, key=lambda r: -int(r["TotalDurationNs"])):
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], round(100 * int(r["TotalDurationNs"]) / tot, 2), r["MinNs"], r["MaxNs"]])
+for name in ("bench_full", "bench_park", "bench_os128", "bench_under_rocprof_k64", "bench_under_rocprof_park", "bench_under_rocprof_os128"):
+    p = os.path.join(src, name + ".json")
+    d = last_json(p) if os.path.exists(p) else None
+    if d is not None:
+        json.dump(d, open(os.path.join(here, f"{tag}_{name}.json"), "w"), indent=1)
 
 
 def load(path):
-    d = collections.defaultdict(list)
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        d[re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("scvod::", "")].append(float(r["Counter_Value"]))
+        k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("scvod::", "")
+        d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
 
 
+LABELS = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_emit_offsets": "emit_offsets",
+          "k_emit": "emit", "k_vx_count": "vx_count", "k_vx_offsets": "vx_offsets", "k_vx_scatter": "vx_scatter", "k_vx_final_offsets": "vx_final_offsets",
+          "k_vx_final": "vx_final", "k_pw_sort_wave": "pw_sort_wave", "k_cc_scan": "cc_scan", "k_tk_init": "tk_labels", "k_tk_voxlabel": "tk_labels",
+          "k_tk_voxfill": "tk_labels", "k_tk_members": "tk_members", "k_tk_scatter": "tk_members", "k_tk_probe": "tk_probe", "k_tk_dyn": "tk_dyn",
+          "k_map_accumulate": "map_accumulate"}
+
+
 def label(k):
-    m = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_pw_fit_coop": "pw_fit_large",
-         "k_pw_arrange": "pw_arrange", "k_emit_offsets": "emit_offsets", "k_emit": "emit", "k_vx_count": "vx_count",
-         "k_vx_offsets": "vx_offsets", "k_vx_scatter": "vx_scatter", "k_vx_final_offsets": "vx_final_offsets",
-         "k_vx_final": "vx_final", "k_track_probe": "track_probe", "k_track_probe_pair": "track_probe", "k_pw_sort_wave": "pw_sort_wave"}
-    if k in m:
-        return m[k]
-    if k.startswith("k_pw_fit_coop"):
-        return "pw_fit_large"
-    if k.startswith("k_pw_arrange"):
-        return "pw_arrange"
-    if k.startswith("k_cc_link_starts"):
-        return "k_cc_link_starts"
-    if k.startswith("k_track_unique"):
-        return "track_unique"
-    if k.startswith("k_pw_order"):
-        return "pw_order"
-    if k.startswith("k_vx_order"):
-        return "vx_order"
+    if k in LABELS:
+        return LABELS[k]
+    for pre, l in (("k_pw_fit_coop", "pw_fit_large"), ("k_pw_arrange", "pw_arrange"), ("k_pw_order", "pw_order"), ("k_vx_order", "vx_order"), ("k_tk_decide", "tk_decide")):
+        if k.startswith(pre):
+            return l
     for pre, l in (("k_pw_sort", "pw_sort"), ("k_vx_bucket", "vx_bucket")):
         if k.startswith(pre):
-            cap = int(re.search(r"<(\d+)", k).group(1))
-            return l + "_" + str(cap)
+            return l + "_" + str(int(re.search(r"<(\d+)", k).group(1)))
     return k
 
 
-F, W = load(os.path.join(src, "FETCH_SIZE_counter_collection.csv")), load(os.path.join(src, "WRITE_SIZE_counter_collection.csv"))
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    shutil.copy(os.path.join(src, c + "_counter_collection.csv"), os.path.join(here, f"{tag}_pmc_{c}_counter_collection.csv"))
+# k_tk_init runs twice per step (once per phase) and shares its label with two other kernels: sum per label
 scans = 512
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --scans 512 --steps 1 --warmup 0 --no-cpu --no-cpu-all --no-extras; "
-               "raw values are KB per dispatch, bytes = KB*1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide "
-               "coalesced read; uncalibrated for gathers, so read-side numbers of gather-heavy kernels are upper bounds)",
+F, W = load(os.path.join(src, "FETCH_SIZE_counter_collection.csv")), load(os.path.join(src, "WRITE_SIZE_counter_collection.csv"))
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --scans 512 --steps 1 --warmup 0 --no-cpu --no-extras; raw values are "
+               "KB per dispatch, bytes = KB * 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read; uncalibrated for "
+               "gathers, so read-side numbers of gather-heavy kernels are upper bounds); a kernel launched several times per step (k_tk_init) is summed",
        "scans_per_launch": scans, "kernels": {}}
-by, total, extra = collections.defaultdict(float), 0.0, 0.0
+by, total = collections.defaultdict(float), 0.0
+# the profiled command runs its step twice (the timed region and the hipEvent attribution pass): per-step = sum / passes
+passes = max(1, len(F.get("k_pw_classify", {}).get("FETCH_SIZE", [0.0])))
+out["passes_in_the_profiled_run"] = passes
 for k in F:
-    f = sum(F[k]) / len(F[k])
-    w = sum(W.get(k, [0])) / max(1, len(W.get(k, [0])))
+    f = sum(F[k]["FETCH_SIZE"]) / passes
+    w = sum(W.get(k, {}).get("WRITE_SIZE", [0.0])) / passes
     b = (2 * f + w) * 1024
-    out["kernels"][k] = {"launches": len(F[k]), "fetch_KB_raw": f, "write_KB_raw": w, "hbm_bytes_per_launch_corrected": b,
+    out["kernels"][k] = {"launches_per_step": len(F[k]["FETCH_SIZE"]) / passes, "fetch_KB_raw_per_step": f, "write_KB_raw_per_step": w, "hbm_bytes_per_step_corrected": b,
                          "hbm_bytes_per_scan": b / scans}
     by[label(k)] += b / scans
-    if k.startswith("k_cc_") or k in ("k_apri_expand", "k_cls_from_lists"):
-        extra += b / scans  # clustering = "next" row (bench.py: prep + extras only); expansion kernels run on fetch/clustering
-    else:
-        total += b / scans
-out["by_bench_label"], out["total_hbm_bytes_per_scan"], out["extras_hbm_bytes_per_scan"] = dict(by), total, extra
+    total += b / scans
+out["by_bench_label"], out["total_hbm_bytes_per_scan"] = dict(by), total
 json.dump(out, open(os.path.join(here, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-d = json.load(open(os.path.join(src, "bench_full.json")))
-print("scans/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "roofline", {k: d["roofline"][k] for k in ("kernel", "frac", "path_GBps")})
-print("cpu", d["cpu_baseline"]["value"], "extras", d.get("extras"))
-print("total HBM MB/scan", round(total / 1e6, 2))
-for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:10]:
+
+# SQ counters: share of the wave cycles that issued an instruction / a VALU / an LDS instruction, that waited, bank conflicts
+p = os.path.join(src, "SQ_counter_collection.csv")
+if os.path.exists(p):
+    S = load(p)
+    with open(os.path.join(here, f"{tag}_sq_pmc_summary.txt"), "w") as f:
+        f.write("rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT\n"
+                "  --kernel-include-regex scvod -- python bench.py --scans 256 --steps 1 --warmup 0 --no-cpu --no-extras   (sums over the dispatches of a kernel)\n"
+                "shares are of SQ_WAVE_CYCLES: issue = ACTIVE_INST_ANY, valu / lds = ACTIVE_INST_VALU / _LDS, wait = WAIT_ANY (s_waitcnt / barrier), stall = WAIT_INST_ANY;\n"
+                "conflict = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS\n\n")
+        f.write(f"{'kernel':44s} {'waves':>10s} {'issue':>7s} {'valu':>7s} {'lds':>7s} {'wait':>7s} {'stall':>7s} {'conflict':>9s}\n")
+        rows = []
+        for k, c in S.items():
+            g = lambda n: sum(c.get(n, [0.0]))
+            wc = g("SQ_WAVE_CYCLES") or 1.0
+            rows.append((g("SQ_WAVE_CYCLES"), k, g("SQ_WAVES"), g("SQ_ACTIVE_INST_ANY") / wc, g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_LDS") / wc,
+                         g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_LDS_BANK_CONFLICT") / (g("SQ_ACTIVE_INST_LDS") or 1.0)))
+        for r in sorted(rows, reverse=True):
+            f.write(f"{r[1][:44]:44s} {r[2]:10.0f} {r[3]:7.3f} {r[4]:7.3f} {r[5]:7.3f} {r[6]:7.3f} {r[7]:7.3f} {r[8]:9.3f}\n")
+
+d = last_json(os.path.join(src, "bench_full.json"))
+print("scans/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "roofline frac", round(d["roofline"]["frac"], 4))
+print("cpu", d["cpu_baseline"] and d["cpu_baseline"]["value"], "quality", d.get("quality") and {k: d["quality"][k] for k in ("delta_PR", "delta_RR")})
+print("total HBM MB/scan", round(total / 1e6, 2), "algorithmic MB/scan", round(d["roofline"]["algorithmic_bytes_per_scan"] / 1e6, 2))
+for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:12]:
     print(f"  {k:18s} {v / 1e6:6.2f} MB/scan")
-for k, v in list(d["kernels"].items())[:10]:
-    print(f"  {k:18s} {v['avg_ms']:7.3f} ms")
