@@ -14,7 +14,8 @@ static map out, everything on the device through the C-ABI (libscvod.so):
        (RCCL point-to-point; a local no-op at one GPU)                                    scvod_batch_export_table
     -> scan-vs-next-scan differencing: probe, remap_name, state rule, per-point byte      scvod_batch_track
     -> world-frame static map of the rank's scans                                         scvod_batch_map_accumulate
-    -> (N > 1) the ranks' map records gathered on rank 0 over RCCL and merged             scvod_map_export / _merge
+    -> (N > 1) the map reduce-scattered over RCCL: records grouped by owner rank,         scvod_map_export_parts / _merge
+       one all-to-all, every rank merges the cells it owns
 value = scans of all ranks / max-over-ranks time.
 
 The JSON line also carries
@@ -159,9 +160,12 @@ def main():
     recv_buf = torch.zeros((plan["n_recv"], table_cap, 4), dtype=torch.int32, device=dev)
     ext = [recv_buf[e] for e in range(plan["n_recv"])]
     smap = None
+    pmap = None
     if not args.no_map:
-        cells = args.map_cells or (1 << int(np.ceil(np.log2(max(total_pts * 0.25, 1 << 22) * (world if rank == 0 else 1)))))  # load <= ~0.5 on the street scenes
+        cells = args.map_cells or (1 << int(np.ceil(np.log2(max(total_pts * 0.25, 1 << 22)))))  # load <= ~0.5 on the street scenes
         smap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local)
+        # N > 1: the map is reduce-scattered -- every rank ends up owning the cells whose key hashes to it, merged from all ranks
+        pmap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local) if world > 1 else None
     kt = {}
     info = {}
 
@@ -201,10 +205,11 @@ def main():
                 a[0] += e0.elapsed_time(e1)
                 a[1] += 1
             if world > 1:
-                rec = smap.export(stream=stream)
-                for other in shard.gather_map_records(dist, rec, root=0):
-                    smap.merge(other, stream=stream)
-                info["map_records_sent"] = int(rec.shape[0])
+                rec, counts = smap.export_parts(world, stream=stream)
+                pmap.clear(stream=stream)
+                for part in shard.reduce_scatter_map(dist, rec, counts):
+                    pmap.merge(part, stream=stream)
+                info["map_records_sent"] = int(rec.shape[0]) - counts[rank]
 
     def barrier():
         torch.cuda.synchronize()
@@ -238,17 +243,23 @@ def main():
     dyn_frac = sum(t["n_dynamic_points"] for t in tk) / max(1, sum(t["n_apri"] for t in tk))
     tot_car = car_frac * tot_apri
     map_cells = smap.count() if smap is not None else None
+    if smap is not None and world > 1:  # cells of the merged map = sum of the parts the ranks own
+        t_cells = torch.tensor([pmap.count()], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(t_cells)
+        map_cells = int(t_cells.item())
     if args.dump_map:
         dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(n_sc)], np.int64)
         gathered = [None] * world
+        mine = (pmap if world > 1 else smap).export().cpu().numpy().view(np.uint64)
         if dist is not None:
-            dist.all_gather_object(gathered, (rank, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist()))
+            dist.all_gather_object(gathered, (rank, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist(), mine))
         else:
-            gathered = [(0, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist())]
+            gathered = [(0, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist(), mine)]
         if rank == 0:
-            rec = smap.export().cpu().numpy().view(np.uint64)
+            rec = np.concatenate([g[3] for g in gathered])
+            assert len(np.unique(rec[:, 0])) == len(rec), "a cell is owned by exactly one rank"
             order = np.argsort(rec[:, 0])
-            per_scan = sorted((tuple(q), d) for _, qs, ds in gathered for q, d in zip(qs, ds))
+            per_scan = sorted((tuple(q), d) for _, qs, ds, _m in gathered for q, d in zip(qs, ds))
             np.savez(args.dump_map, keys=rec[order, 0], vals=rec[order, 1], scans=np.array([q for q, _ in per_scan], np.int64),
                      dynamic_points=np.array([d for _, d in per_scan], np.int64))
 
@@ -376,6 +387,8 @@ def main():
         print(json.dumps(out))
     if smap is not None:
         smap.close()
+        if pmap is not None:
+            pmap.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

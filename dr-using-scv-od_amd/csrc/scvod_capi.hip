@@ -25,6 +25,13 @@ struct TimingEntry {
 
 }  // namespace
 
+struct UploadSlot {
+    void* pinned = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool used = false;
+};
+
 struct scvod_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -55,6 +62,8 @@ struct scvod_ctx {
     std::vector<float> up_T;          // what the device copies of T / next_scan / ext currently hold (re-uploaded on change only)
     std::vector<int32_t> up_next;
     std::vector<const void*> up_ext;
+    UploadSlot up_ring[4];
+    int up_next_slot = 0;
     bool track_valid = false;
     bool tables_valid = false;   // successor tables (vox_track) built for the current clustering
     std::vector<int32_t> tk_stage;    // host staging of scvod_batch_fetch_track
@@ -558,16 +567,33 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     return SCVOD_OK;
 }
 
-// Re-upload a small host table only when its contents changed since the last call: the staging vector belongs to the ctx
-// and an earlier asynchronous copy may still be reading it, so a change first drains the stream (steady-state sequence
-// loops pass the same tables every step and never synchronise here).
+// Re-upload a small host table only when its contents changed since the last call (steady-state sequence loops pass the
+// same tables every step and upload nothing).
+// A changed table travels through one of four pinned staging slots; a slot is reused only after the copy that read it
+// has completed (its event), so a chunked sequence (scvod_sequence_ingest: new transforms every chunk) never drains the stream.
+int staged_upload(scvod_ctx* c, const void* src, size_t bytes, void* dst, hipStream_t st) {
+    UploadSlot& u = c->up_ring[c->up_next_slot];
+    c->up_next_slot = (c->up_next_slot + 1) % 4;
+    if (!u.ev) HIPCHK(c, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
+    if (u.used) HIPCHK(c, hipEventSynchronize(u.ev));
+    if (bytes > u.cap) {
+        if (u.pinned) hipHostFree(u.pinned);
+        u.pinned = nullptr;
+        u.cap = 0;
+        HIPCHK(c, hipHostMalloc(&u.pinned, bytes + bytes / 2 + 64, hipHostMallocDefault));
+        u.cap = bytes + bytes / 2 + 64;
+    }
+    memcpy(u.pinned, src, bytes);
+    HIPCHK(c, hipMemcpyAsync(dst, u.pinned, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(u.ev, st));
+    u.used = true;
+    return SCVOD_OK;
+}
 template <typename T>
 int upload_if_changed(scvod_ctx* c, std::vector<T>& held, const T* src, size_t n, void* dst, hipStream_t st) {
     if (held.size() == n && (n == 0 || memcmp(held.data(), src, n * sizeof(T)) == 0)) return SCVOD_OK;
-    HIPCHK(c, hipStreamSynchronize(st));
     held.assign(src, src + n);
-    if (n) HIPCHK(c, hipMemcpyAsync(dst, held.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
-    return SCVOD_OK;
+    return n ? staged_upload(c, held.data(), n * sizeof(T), dst, st) : SCVOD_OK;
 }
 
 }  // namespace
@@ -725,6 +751,10 @@ void scvod_destroy(scvod_ctx* c) {
         if (c->ingest_done[k]) hipEventDestroy(c->ingest_done[k]);
     }
     if (c->ingest_off) hipHostFree(c->ingest_off);
+    for (UploadSlot& u : c->up_ring) {
+        if (u.pinned) hipHostFree(u.pinned);
+        if (u.ev) hipEventDestroy(u.ev);
+    }
     if (c->arena_base) hipFree(c->arena_base);
     if (c->stage) hipHostFree(c->stage);
     for (void* b : c->nn_buf)
@@ -1127,6 +1157,10 @@ int scvod_sequence_ingest(scvod_ctx* c, const float* h_xyzi, const int32_t* h_sc
     if (off_need > c->ingest_off_cap) {
         HIPCHK(c, hipDeviceSynchronize());
         if (c->ingest_off) hipHostFree(c->ingest_off);
+    for (UploadSlot& u : c->up_ring) {
+        if (u.pinned) hipHostFree(u.pinned);
+        if (u.ev) hipEventDestroy(u.ev);
+    }
         c->ingest_off = nullptr;
         c->ingest_off_cap = 0;
         HIPCHK(c, hipHostMalloc((void**)&c->ingest_off, sizeof(int32_t) * off_need, hipHostMallocDefault));

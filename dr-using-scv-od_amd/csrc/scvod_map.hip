@@ -34,7 +34,7 @@ struct scvod_map {
     float leaf = 0.2f;
     long long capacity = 0;  // power of two
     MapRec* table = nullptr;
-    unsigned long long* counters = nullptr;  // [0] records exported, [1] insertions dropped (table full / out of range)
+    unsigned long long* counters = nullptr;  // [0] records exported, [1] insertions dropped (table full / out of range), [2..2+64) per-part counts / cursors
     float* d_pose = nullptr;                 // [pose_cap][12]
     long long pose_cap = 0;
     std::vector<float> up_pose;
@@ -230,6 +230,52 @@ __global__ __launch_bounds__(256) void k_map_export(const MapRec* __restrict__ t
     }
 }
 
+// owner of a cell when the map is reduce-scattered over `n_parts` shards (a mix that is independent of the table hash)
+__device__ __forceinline__ int map_part(unsigned long long key, int n_parts) {
+    return (int)((map_mix(key ^ 0x9e3779b97f4a7c15ull) >> 33) % (unsigned long long)n_parts);
+}
+constexpr int kMapMaxParts = 64;
+
+__global__ __launch_bounds__(256) void k_map_count_parts(const MapRec* __restrict__ table, long long capacity, int n_parts, unsigned long long* part_count) {
+    __shared__ int hist[kMapMaxParts];
+    if (threadIdx.x < kMapMaxParts) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < capacity; t += (long long)gridDim.x * 256) {
+        const unsigned long long k = table[t].key;
+        if (k != kEmpty) atomicAdd(&hist[map_part(k, n_parts)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_parts && hist[threadIdx.x]) atomicAdd(&part_count[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// records grouped by owner: a block ranks its occupied slots per part in LDS, reserves one range per part, writes
+__global__ __launch_bounds__(256) void k_map_scatter_parts(const MapRec* __restrict__ table, long long capacity, int n_parts,
+                                                           unsigned long long* part_cursor, MapRec* out, long long cap_out) {
+    __shared__ int hist[kMapMaxParts];
+    __shared__ unsigned long long start[kMapMaxParts];
+    for (long long t0 = blockIdx.x * 256ll; t0 < capacity; t0 += (long long)gridDim.x * 256) {
+        if (threadIdx.x < kMapMaxParts) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const long long t = t0 + threadIdx.x;
+        MapRec r;
+        r.key = kEmpty;
+        if (t < capacity) r = table[t];
+        int part = -1, rank = 0;
+        if (r.key != kEmpty) {
+            part = map_part(r.key, n_parts);
+            rank = atomicAdd(&hist[part], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < n_parts && hist[threadIdx.x]) start[threadIdx.x] = atomicAdd(&part_cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+        __syncthreads();
+        if (part >= 0) {
+            const long long o = (long long)start[part] + rank;
+            if (o < cap_out) out[o] = r;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 }  // namespace scvod
 
@@ -252,8 +298,8 @@ int scvod_map_create(int device, int64_t capacity_cells, float leaf, scvod_map**
     while (cap < capacity_cells) cap <<= 1;
     m->capacity = cap;
     if (hipSetDevice(device) != hipSuccess || hipMalloc(&m->table, sizeof(MapRec) * (size_t)cap) != hipSuccess ||
-        hipMalloc(&m->counters, 16) != hipSuccess || hipMemset(m->table, 0xff, sizeof(MapRec) * (size_t)cap) != hipSuccess ||
-        hipMemset(m->counters, 0, 16) != hipSuccess) {
+        hipMalloc(&m->counters, 8 * (2 + 64)) != hipSuccess || hipMemset(m->table, 0xff, sizeof(MapRec) * (size_t)cap) != hipSuccess ||
+        hipMemset(m->counters, 0, 8 * (2 + 64)) != hipSuccess) {
         if (m->table) hipFree(m->table);
         if (m->counters) hipFree(m->counters);
         delete m;
@@ -366,6 +412,34 @@ int scvod_map_export(scvod_map* m, void* d_records, int64_t cap_records, int64_t
 }
 int scvod_map_points(scvod_map* m, void* d_xyzi, void* d_keys_records, int64_t cap, int64_t* n_out, void* stream) {
     return map_export(m, d_keys_records, d_xyzi, cap, n_out, stream);
+}
+
+int scvod_map_export_parts(scvod_map* m, int32_t n_parts, void* d_records, int64_t cap_records, int64_t* h_counts, void* stream) {
+    if (!m || n_parts < 1 || n_parts > kMapMaxParts || !d_records || !h_counts || cap_records < 0) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
+    MHIP(m, hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pc = m->counters + 2;
+    MHIP(m, hipMemsetAsync(pc, 0, 8 * kMapMaxParts, st));
+    hipLaunchKernelGGL(k_map_count_parts, dim3(256 * 8), dim3(256), 0, st, m->table, m->capacity, (int)n_parts, pc);
+    unsigned long long h[2 + kMapMaxParts];
+    MHIP(m, hipMemcpyAsync(h, m->counters, 8 * (2 + kMapMaxParts), hipMemcpyDeviceToHost, st));
+    MHIP(m, hipStreamSynchronize(st));
+    if (h[1]) return mfail(m, SCVOD_ERR_CAPACITY, "%llu points did not fit the map (table of %lld cells full or coordinates out of range)", h[1], m->capacity);
+    unsigned long long cur[kMapMaxParts], run = 0;
+    for (int p = 0; p < kMapMaxParts; ++p) {
+        cur[p] = run;
+        if (p < n_parts) {
+            h_counts[p] = (int64_t)h[2 + p];
+            run += h[2 + p];
+        }
+    }
+    if ((int64_t)run > cap_records) return mfail(m, SCVOD_ERR_CAPACITY, "output buffer too small (%lld < %llu cells)", (long long)cap_records, run);
+    MHIP(m, hipMemcpyAsync(pc, cur, 8 * kMapMaxParts, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_map_scatter_parts, dim3(256 * 8), dim3(256), 0, st, m->table, m->capacity, (int)n_parts, pc, (MapRec*)d_records,
+                       (long long)cap_records);
+    MHIP(m, hipGetLastError());
+    MHIP(m, hipStreamSynchronize(st));  // `cur` lives on this stack frame
+    return SCVOD_OK;
 }
 
 int scvod_map_merge(scvod_map* m, const void* d_records, int64_t n, void* stream) {

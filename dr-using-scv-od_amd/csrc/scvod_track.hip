@@ -260,7 +260,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 // successor's table in LDS turns the cluster's hits into the sorted unique list (sampleVec without a sort), the list is
 // grouped by label -> remap_name, then the state rule.  `words` = LDS words per wave (covers the largest table).
 template <int kTkWaves>
-__global__ __launch_bounds__(64 * kTkWaves) void k_tk_decide(Arena A, TrackBatch J, int words) {
+__global__ __launch_bounds__(64 * kTkWaves) void k_tk_decide(Arena A, TrackBatch J, int words, int min_words) {
     extern __shared__ uint32_t tk_bits[];
     const int s = blockIdx.y;
     const int ncl = A.tk_scan[s * 4 + 0];
@@ -271,7 +271,9 @@ __global__ __launch_bounds__(64 * kTkWaves) void k_tk_decide(Arena A, TrackBatch
     if (N.nv < 0) return;  // last scans of a sequence: no tracking call, states stay -1
     const int base = A.scan_off[s];
     uint32_t* bits = tk_bits + (size_t)wave * words;
-    const int nw = min((N.nv + 31) >> 5, words);
+    // two launches share the scans: tables of up to `words` bitset words here, larger ones in the launch with more LDS per wave
+    if (((N.nv + 31) >> 5) > words || ((N.nv + 31) >> 5) <= min_words) return;
+    const int nw = (N.nv + 31) >> 5;
     for (int w = lane; w < nw; w += 64) bits[w] = 0u;
     __builtin_amdgcn_wave_barrier();
     for (int ord = first; ord < ncl; ord += stride) {
@@ -422,18 +424,24 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     hipLaunchKernelGGL(k_tk_probe, dim3((A.max_scan_pts + 4095) / 4096, B), dim3(256), 0, st, P, A, J, from_apri);
     TH_END("tk_probe");
     // LDS words of a wave's bitset: a table holds at most max_scan_pts voxels
+    // a wave's bitset covers the successor's voxel table: tables of up to 32 768 voxels (any street scan) take the launch
+    // with 4 KB of LDS per wave (eight workgroups per CU), larger ones the launch sized for the largest scan
+    const int small_words = 1024;
     const int words = (A.max_scan_pts + 31) / 32 + 1;  // SCVOD_MAX_SCAN_POINTS = 2^19 slots = 64 KB: one wave always fits
     const size_t per_wave = (size_t)words * 4;
     TH_BEGIN("tk_decide");
-    if (4 * per_wave <= 64 * 1024) {  // two workgroups per CU
-        hipFuncSetAttribute((const void*)k_tk_decide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * per_wave));
-        hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * per_wave, st, A, J, words);
-    } else if (2 * per_wave <= 150 * 1024) {
-        hipFuncSetAttribute((const void*)k_tk_decide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * per_wave));
-        hipLaunchKernelGGL(k_tk_decide<2>, dim3(16, B), dim3(128), 2 * per_wave, st, A, J, words);
-    } else {
-        hipFuncSetAttribute((const void*)k_tk_decide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave);
-        hipLaunchKernelGGL(k_tk_decide<1>, dim3(32, B), dim3(64), per_wave, st, A, J, words);
+    hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * small_words * 4, st, A, J, small_words, -1);
+    if (words > small_words) {
+        if (4 * per_wave <= 64 * 1024) {  // two workgroups per CU
+            hipFuncSetAttribute((const void*)k_tk_decide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * per_wave));
+            hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * per_wave, st, A, J, words, small_words);
+        } else if (2 * per_wave <= 150 * 1024) {
+            hipFuncSetAttribute((const void*)k_tk_decide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * per_wave));
+            hipLaunchKernelGGL(k_tk_decide<2>, dim3(16, B), dim3(128), 2 * per_wave, st, A, J, words, small_words);
+        } else {
+            hipFuncSetAttribute((const void*)k_tk_decide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave);
+            hipLaunchKernelGGL(k_tk_decide<1>, dim3(32, B), dim3(64), per_wave, st, A, J, words, small_words);
+        }
     }
     TH_END("tk_decide");
     TH_BEGIN("tk_dyn");

@@ -134,6 +134,7 @@ def load_lib():
         "scvod_batch_map_accumulate": (C.c_int, [vp, vp, vp, i32, vp]),
         "scvod_map_export": (C.c_int, [vp, vp, i64, C.POINTER(i64), vp]),
         "scvod_map_merge": (C.c_int, [vp, vp, i64, vp]),
+        "scvod_map_export_parts": (C.c_int, [vp, i32, vp, i64, vp, vp]),
         "scvod_map_points": (C.c_int, [vp, vp, vp, i64, C.POINTER(i64), vp]),
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
         "scvod_set_timing": (C.c_int, [vp, i32]),
@@ -158,7 +159,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
                     "scvod_batch_track", "scvod_batch_fetch_track", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
-                    "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_merge", "scvod_map_points",
+                    "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
 
 
@@ -508,6 +509,15 @@ class StaticMap:
         n = C.c_int64()
         self._chk(self.lib.scvod_map_export(self.h, C.c_void_p(d_records.data_ptr()), int(d_records.shape[0]), C.byref(n), C.c_void_p(stream or 0)))
         return d_records[:int(n.value)]
+
+    def export_parts(self, n_parts, stream=None):
+        """(records [n, 2] int64 grouped by owner shard, counts per shard): the send side of the map's reduce-scatter"""
+        import torch
+        rec = torch.empty((max(self.count(stream), 1), 2), dtype=torch.int64, device=torch.device("cuda", self.device))
+        cnt = (C.c_int64 * int(n_parts))()
+        self._chk(self.lib.scvod_map_export_parts(self.h, int(n_parts), C.c_void_p(rec.data_ptr()), int(rec.shape[0]), cnt, C.c_void_p(stream or 0)))
+        counts = [int(v) for v in cnt]
+        return rec[:sum(counts)], counts
 
     def merge(self, d_records, stream=None):
         self._chk(self.lib.scvod_map_merge(self.h, C.c_void_p(d_records.data_ptr()), int(d_records.shape[0]), C.c_void_p(stream or 0)))

@@ -135,6 +135,44 @@ def gather_map_records(dist, records, root=0):
     return []
 
 
+def reduce_scatter_map(dist, records, counts):
+    """Static-map reduce over xGMI as an all-to-all: `records` [n, 2] int64 grouped by owner rank (scvod_map_export_parts),
+    `counts` the group sizes.  Every rank keeps its own group and receives the groups the other ranks hold for it (sizes
+    first, then one point-to-point pair per peer: 7 links x 1/8 of a rank's map instead of 7 maps converging on rank 0).
+    Returns the list of record tensors this rank owns (its own group first).  Device tensors (RCCL) or, under gloo, staged
+    through the host."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [records]
+    rank, world = dist.get_rank(), dist.get_world_size()
+    home = records.device
+    staged = dist.get_backend() == "gloo" and records.is_cuda
+    rec = records.cpu() if staged else records
+    mine = torch.tensor(counts, dtype=torch.int64, device=rec.device)
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine)                               # allc[j][r] = what rank j holds for rank r
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + int(c))
+    out = [rec[offs[rank]:offs[rank + 1]]]
+    ops, recvs = [], []
+    for j in range(world):
+        if j == rank:
+            continue
+        if counts[j]:
+            ops.append(dist.P2POp(dist.isend, rec[offs[j]:offs[j + 1]].contiguous(), j))
+        n_in = int(allc[j][rank].item())
+        if n_in:
+            buf = torch.empty((n_in, 2), dtype=torch.int64, device=rec.device)
+            recvs.append(buf)
+            ops.append(dist.P2POp(dist.irecv, buf, j))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    out += recvs
+    return [t.to(home) for t in out] if staged else out
+
+
 def aggregate(dist, device, seconds, scans, points):
     """MAX over ranks of the timed seconds, SUM of the processed units.  dist may be None (1 rank)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

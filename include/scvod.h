@@ -387,6 +387,12 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* map, const float* h_po
 /* occupied cells as 16-byte records {uint64 cell key, uint64 packed point} into device memory (NULL: count only);
  * *n_out = number of cells.  Synchronises `stream`.  Record order is unspecified (sort by key for a canonical order). */
 int scvod_map_export(scvod_map* map, void* d_records, int64_t cap_records, int64_t* n_out, void* stream);
+/* The same records grouped by OWNER for a reduce-scatter of the map over n_parts <= 64 shards (owner = a hash of the cell
+ * key modulo n_parts, identical on every shard): h_counts[n_parts] receives the group sizes, group p starts at the sum of
+ * the sizes before it.  Every shard sends group p to shard p (one all-to-all over xGMI: every link carries 1/n of the
+ * map instead of everything converging on one root) and merges what it receives into the map of its own part.
+ * Synchronises `stream`. */
+int scvod_map_export_parts(scvod_map* map, int32_t n_parts, void* d_records, int64_t cap_records, int64_t* h_counts, void* stream);
 /* inserts records exported by another shard (a record with key ~0 is padding and skipped).  Asynchronous. */
 int scvod_map_merge(scvod_map* map, const void* d_records, int64_t n, void* stream);
 /* the map as points: d_xyzi [cap][4] floats (cell origin + stored offset, intensity), optionally the records beside them */

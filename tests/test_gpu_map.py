@@ -134,6 +134,27 @@ def test_shards_merge_into_the_single_shard_map(scvod):
     merged.merge(pad.reshape(-1, 2))
     mk, mv = _sorted_records(merged)
     assert np.array_equal(mk, wk) and np.array_equal(mv, wv)
+    # the reduce-scatter form: records grouped by owner; the groups partition the map and every shard computes the same owner
+    ga, na = ma.export_parts(3)
+    gb, nb = mb.export_parts(3)
+    assert sum(na) == ra.shape[0] and sum(nb) == rb.shape[0]
+    owner = {}
+    for g, c in ((ga, na), (gb, nb)):
+        k = g.cpu().numpy().view(np.uint64)[:, 0]
+        o = np.repeat(np.arange(3), c)
+        for kk, oo in zip(k.tolist(), o.tolist()):
+            assert owner.setdefault(kk, oo) == oo
+    parts = [scvod.StaticMap(1 << 20) for _ in range(3)]
+    oa, ob2 = np.concatenate([[0], np.cumsum(na)]), np.concatenate([[0], np.cumsum(nb)])
+    for p in range(3):
+        parts[p].merge(ga[oa[p]:oa[p + 1]])
+        parts[p].merge(gb[ob2[p]:ob2[p + 1]])
+    allk = np.concatenate([_sorted_records(q)[0] for q in parts])
+    allv = np.concatenate([_sorted_records(q)[1] for q in parts])
+    o = np.argsort(allk)
+    assert np.array_equal(allk[o], wk) and np.array_equal(allv[o], wv)
+    for q in parts:
+        q.close()
     # a map that is too small reports it instead of silently dropping cells
     tiny = scvod.StaticMap(1024)
     tiny.merge(ra)

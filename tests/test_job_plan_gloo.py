@@ -82,6 +82,13 @@ def _worker(rank, world, port, q):
         got = sorted(map(tuple, allrec.tolist()))
     else:
         ok &= others == []
+    # reduce-scatter of the map: rank r holds r + j + 1 records for owner j (tagged r, j); every owner ends up with its own
+    counts = [rank + j + 1 for j in range(world)]
+    rs = torch.cat([torch.stack([torch.full((c,), 1000 * rank + j, dtype=torch.int64), torch.arange(c, dtype=torch.int64)], 1) for j, c in enumerate(counts)])
+    parts = shard.reduce_scatter_map(dist, rs, counts)
+    own = torch.cat(parts)
+    want_own = sorted((1000 * r + rank, k) for r in range(world) for k in range(r + rank + 1))
+    ok &= sorted(map(tuple, own.tolist())) == want_own
     res = [None] * world
     dist.all_gather_object(res, (bool(ok), got, plan["n_recv"]))
     if rank == 0:
