@@ -2087,27 +2087,43 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     __syncthreads();
     for (int j = tid; j < nn; j += kCcThreads) parent[j] = rootcid[flat[j]];
     __syncthreads();
-    for (int k = tid; k < n; k += kCcThreads) {
-        const int p = vpts[k];
-        const int v = voxel_of_slot(k);
-        int cid;
-        if (cc_bit(touched, v)) {
-            cid = parent[v];
-        } else {
-            int o = k;  // opener of this slot's run: the closest run start at or before k (a voxel start is one)
-            {
-                int w = o >> 5;
-                unsigned m = (unsigned)rstart[w] & (0xffffffffu >> (31 - (o & 31)));
-                while (!m) m = (unsigned)rstart[--w];
-                o = (w << 5) + 31 - __clz(m);
+    for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {  // four slots per thread and step: their loads are in flight together
+        int pv[4], cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pv[u] = vpts[min(k0 + u * kCcThreads + tid, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * kCcThreads + tid;
+            int cid = -2;
+            if (k < n) {
+                const int v = voxel_of_slot(k);
+                if (cc_bit(touched, v)) {
+                    cid = parent[v];
+                } else {
+                    int o = k;  // opener of this slot's run: the closest run start at or before k (a voxel start is one)
+                    {
+                        int w = o >> 5;
+                        unsigned m = (unsigned)rstart[w] & (0xffffffffu >> (31 - (o & 31)));
+                        while (!m) m = (unsigned)rstart[--w];
+                        o = (w << 5) + 31 - __clz(m);
+                    }
+                    const int node = (o == vbeg[v]) ? v : nv + extra_of_slot[o];
+                    // a point that found nothing is a cluster of its own (ssc.cpp:347-353); the members of a run that found
+                    // something joined what the opener joined
+                    cid = cc_bit(found, node) ? parent[node] : -1;
+                }
             }
-            const int node = (o == vbeg[v]) ? v : nv + extra_of_slot[o];
-            // a point that found nothing is a cluster of its own (ssc.cpp:347-353); the members of a run that found
-            // something joined what the opener joined
-            cid = cc_bit(found, node) ? parent[node] : -1;
+            cv[u] = cid;
         }
-        slot_cid[p] = cid;  // (indexed by apri point from here on: the passes below stream the points in order)
-        A.pt_cluster[(size_t)base + p] = cid >= 0 ? names[cid] : p;
+        int nm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nm[u] = names[max(cv[u], 0)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (cv[u] == -2) continue;
+            slot_cid[pv[u]] = cv[u];  // (indexed by apri point from here on: the passes below stream the points in order)
+            A.pt_cluster[(size_t)base + pv[u]] = cv[u] >= 0 ? nm[u] : pv[u];
+        }
     }
     __syncthreads();
     // ---- bounding boxes + type of every cluster (refineClusterByBoundingBox ssc.cpp:437-467, recognize ssc.cpp:849-872)
@@ -2201,11 +2217,20 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         A.cl_count[(size_t)base + names[c]] = cnt;  // Cluster::occupy_pts.size(), kept at the cluster's canonical name
     }
     __syncthreads();
-    for (int i = tid; i < n; i += kCcThreads) {
-        const int cid = slot_cid[i];
-        if (cid < 0) continue;
-        const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
-        A.pt_type[(size_t)base + i] = (uint8_t)r[0];
+    for (int i0 = 0; i0 < n; i0 += kCcThreads * 4) {
+        int cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kCcThreads + tid;
+            cv[u] = (i < n) ? slot_cid[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cid = cv[u];
+            if (cid < 0) continue;
+            const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+            A.pt_type[(size_t)base + i0 + u * kCcThreads + tid] = (uint8_t)r[0];
+        }
     }
 }
 
