@@ -1844,14 +1844,19 @@ __global__ __launch_bounds__(256) void k_vx_final(DevParams P, Arena A) {
 // is the smallest apri index of the component.  Scans with more than kCcNodes voxels or kCcSlots points run the same
 // code on arena scratch in HBM.
 // ------------------------------------------------------------------------------------------
-constexpr int kCcNodes = 16384;  // voxels + extra run openers per scan held in LDS
+constexpr int kCcNodes = 14336;  // voxels + extra run openers per scan held in LDS
 constexpr int kCcSlots = 65536;  // apri points per scan whose run / voxel start bits are held in LDS
 constexpr int kCcThreads = 1024;
-constexpr int kCcBoxes = 1024;   // bounding boxes per scan held in LDS (7 words each: the three bit arrays + touched/found, released)
-static_assert(7 * kCcBoxes <= 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32), "box records must fit the released bit arrays");
-constexpr size_t kCcLdsBytes = (size_t)(2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + 64) * 4;
+constexpr int kCcBoxes = 2048;   // bounding boxes per scan held in LDS (7 words each, in the key table once the search is over)
+constexpr int kCcBuckets = 8192; // entries of the key-bucket index (uint16 node numbers)
+static_assert(7 * kCcBoxes <= kCcNodes, "box records must fit the released key table");
+constexpr size_t kCcLdsBytes = (size_t)(2 * kCcNodes + 3 * (kCcSlots / 32) + 3 * (kCcNodes / 32) + kCcBuckets / 2 + 64) * 4;
+constexpr int kCcIter = kCcNodes / kCcThreads;  // nodes per thread when the scan's nodes fit LDS
+static_assert(kCcNodes % kCcThreads == 0, "the register-cached node loop covers kCcNodes exactly");
+static_assert(kCcLdsBytes <= 160 * 1024, "one workgroup per CU: all of its LDS");
 
 __device__ __forceinline__ int cc_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t cc_ldu(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int cc_find(int* parent, int x) {
     int p = cc_ld(&parent[x]);
     while (p != x) {
@@ -1895,8 +1900,22 @@ struct CcKeys {
     const int* lk;
     const int* gk;
     int ns, nv, shift;
+    const uint16_t* tab;  // tab[b] = first node whose key is >= b << bshift (nullptr: no index; keys >= 0 only)
+    int bshift;
 };
 __device__ __forceinline__ int cc_lower_bound2(const CcKeys& K, int key) {
+    if (K.tab) {  // whole key table in LDS + bucket index: the search runs inside one bucket (a handful of keys)
+        const int b = key >> K.bshift;
+        int lo = K.tab[b], hi = K.tab[b + 1];
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (K.lk[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
     const int lo = cc_lower_bound(K.lk, K.ns, key);  // first sample >= key
     if (K.shift == 0 || lo == 0) return lo << K.shift;
     int u = ((lo - 1) << K.shift) + 1;
@@ -1918,8 +1937,52 @@ __device__ __forceinline__ bool cc_search(const CcKeys& K, int* parent, int* tou
             const int k0 = x * S + ylo + z * R * S, k1 = k0 + (yhi - ylo);
             for (int u = cc_lower_bound2(K, k0); u < K.nv && K.gk[u] <= k1; ++u) {
                 cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
-                cc_union(parent, me, u);
+                if (u != me) cc_union(parent, me, u);
                 found = true;
+            }
+        }
+    }
+    return found;
+}
+
+// union that hands back the surviving root (the caller keeps it as its next starting point)
+__device__ __forceinline__ int cc_union_r(int* parent, int a, int b) {
+    for (;;) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return a;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&parent[a], a, b) == a) return b;
+    }
+}
+// cc_search for the all-in-LDS case.  A REGULAR node is a voxel whose opener's triple is in range and encodes to the voxel's
+// own key: it finds itself (so it is touched and found), and two regular voxels find each other, so the pair is joined by
+// the one with the larger index only -- half the unions, and every union starts from the root the previous one returned.
+__device__ __forceinline__ bool cc_search_fast(const CcKeys& K, int* parent, int* touched, const int* regular, int me, bool me_reg,
+                                               int32_t t, int R, int S, int Az) {
+    const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+    const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
+    bool found = false;
+    if (ylo > yhi) return false;
+    int ra = me;
+    for (int z = ai - 1; z <= ai + 1; ++z) {
+        if (z > Az - 1 || z < 0) continue;
+        for (int x = ri - 1; x <= ri + 1; ++x) {
+            if (x > R - 1 || x < 0) continue;
+            const int k0 = x * S + ylo + z * R * S, k1 = k0 + (yhi - ylo);
+            for (int u = cc_lower_bound2(K, k0); u < K.nv && K.lk[u] <= k1; ++u) {
+                found = true;
+                if (u == me) {
+                    cc_set(touched, u);
+                    continue;
+                }
+                if (me_reg && u > me && cc_bit(regular, u)) continue;  // u joins me (and touches me) when its turn comes
+                cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
+                ra = cc_union_r(parent, ra, u);
             }
         }
     }
@@ -1939,7 +2002,25 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+#ifdef SCVOD_CC_PROFILE
+__device__ unsigned long long g_cc_prof[16];
+#define CC_MARK(i)                                                             \
+    do {                                                                       \
+        __syncthreads();                                                       \
+        if (threadIdx.x == 0) {                                                \
+            const unsigned long long t_now = wall_clock64();                   \
+            atomicAdd(&g_cc_prof[i], t_now - t_prev);                          \
+            t_prev = t_now;                                                    \
+        }                                                                      \
+    } while (0)
+#else
+#define CC_MARK(i)
+#endif
+
 __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, int from_apri) {
+#ifdef SCVOD_CC_PROFILE
+    unsigned long long t_prev = wall_clock64();
+#endif
     extern __shared__ int cc_smem[];
     __shared__ int wsum[17];
     __shared__ int n_extra_s;
@@ -1972,6 +2053,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         cc_set(rstart, k);
     }
     __syncthreads();
+    CC_MARK(0);
     // runs inside a voxel: a slot whose triple differs from the previous slot's opens one (ssc.cpp:306-330 walks the
     // voxel's points with their own triples; equal triples have equal neighbourhoods)
     for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {
@@ -1999,6 +2081,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
             }
         }
     }
+    CC_MARK(1);
     // prefix[w] = voxel starts in the words before w: voxel of slot k = prefix[k >> 5] + popc(vstart word up to k) - 1
     {
         int run = 0;
@@ -2033,17 +2116,66 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         found[w] = 0;
     }
     __syncthreads();
+    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
+    // bucket index over the keys a search can ask for (0 .. R*S*Az - 1): a lower bound then costs two table reads and a
+    // search among the few keys of one bucket instead of log2(nv) dependent LDS reads
+    K.tab = nullptr;
+    K.bshift = 0;
+    {
+        const long long span = (long long)R * S * Az;
+        if (K.shift == 0 && span > 0 && span < 0x7fffffffLL) {
+            uint16_t* tab = (uint16_t*)(cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32));
+            while ((((int)span - 1) >> K.bshift) + 2 > kCcBuckets) ++K.bshift;
+            const int nb = (((int)span - 1) >> K.bshift) + 1;
+            for (int b = tid; b <= nb; b += kCcThreads) tab[b] = (uint16_t)cc_lower_bound(lkeys, nv, (int)min((long long)b << K.bshift, 0x7fffffffLL));
+            K.tab = tab;
+            __syncthreads();
+        }
+    }
+    CC_MARK(2);
     auto voxel_of_slot = [&](int k) -> int {
         const unsigned m = (unsigned)vstart[k >> 5] & (0xffffffffu >> (31 - (k & 31)));
         return prefix[k >> 5] + __popc(m) - 1;
     };
-    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
     // the run that starts a voxel is node v, an extra run is node nv + e
-    for (int j = tid; j < nn; j += kCcThreads) {
-        const int k = (j < nv) ? vbeg[j] : extras[j - nv];
-        if (cc_search(K, parent, touched, j, idx3[vpts[k]], R, S, Az)) cc_set(found, j);
+    if (nodes_lds && K.tab) {
+        int* regular = cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2;
+        int tc[kCcIter];  // the opener's triple of this thread's nodes: the three dependent gathers of all of them in flight together
+#pragma unroll
+        for (int it = 0; it < kCcIter; ++it) {
+            const int j = it * kCcThreads + tid;
+            tc[it] = (j < nn) ? ((j < nv) ? vbeg[j] : extras[j - nv]) : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < kCcIter; ++it) tc[it] = vpts[tc[it]];
+#pragma unroll
+        for (int it = 0; it < kCcIter; ++it) tc[it] = idx3[tc[it]];
+        int* triple = A.cc_parent + base;  // [nn] arena scratch (the parents are in LDS): the search loop below stays rolled
+#pragma unroll
+        for (int it = 0; it < kCcIter; ++it) {
+            const int j = it * kCcThreads + tid;
+            const int t = tc[it];
+            const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+            const bool reg = j < nv && ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == lkeys[j]);
+            const unsigned long long b = __ballot(reg);
+            if ((tid & 31) == 0) regular[j >> 5] = (int)(unsigned)((tid & 32) ? (b >> 32) : b);
+            if (j < nn) triple[j] = t;
+        }
+        __syncthreads();
+        int t_next = triple[min(tid, nn - 1)];
+        for (int j = tid; j < nn; j += kCcThreads) {
+            const int t = t_next;
+            t_next = triple[min(j + kCcThreads, nn - 1)];
+            if (cc_search_fast(K, parent, touched, regular, j, j < nv && cc_bit(regular, j), t, R, S, Az)) cc_set(found, j);
+        }
+    } else {
+        for (int j = tid; j < nn; j += kCcThreads) {
+            const int k = (j < nv) ? vbeg[j] : extras[j - nv];
+            if (cc_search(K, parent, touched, j, idx3[vpts[k]], R, S, Az)) cc_set(found, j);
+        }
     }
     __syncthreads();
+    CC_MARK(3);
     // every point of a touched voxel is merged with the voxel (ssc.cpp:316-345): the extra runs inside one join it
     for (int e = tid; e < n_extra; e += kCcThreads) {
         const int v = voxel_of_slot(extras[e]);
@@ -2061,6 +2193,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         atomicMin(&minpt[r], vpts[k]);
     }
     __syncthreads();
+    CC_MARK(4);
     // flatten, then number the components 0 .. ncl-1 in node order: parent[j] becomes the compact id of j's component
     int* flat = A.tk_cursor + base;                 // [nn] root of every node (arena scratch, nn <= n)
     for (int j = tid; j < nn; j += kCcThreads) {
@@ -2087,6 +2220,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     __syncthreads();
     for (int j = tid; j < nn; j += kCcThreads) parent[j] = rootcid[flat[j]];
     __syncthreads();
+    CC_MARK(5);
     for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {  // four slots per thread and step: their loads are in flight together
         int pv[4], cv[4];
 #pragma unroll
@@ -2126,11 +2260,11 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         }
     }
     __syncthreads();
-    // ---- bounding boxes + type of every cluster (refineClusterByBoundingBox ssc.cpp:437-467, recognize ssc.cpp:849-872)
-    // in the LDS the bit arrays just released; components beyond kCcBoxes take arena scratch with global atomics
-    uint32_t* bb = slots_lds ? (uint32_t*)(cc_smem + 2 * kCcNodes) : (uint32_t*)(A.cl_bbox + 7 * (size_t)base);
-    uint32_t* ov = (uint32_t*)(A.cl_bbox + 7 * (size_t)base) + (slots_lds ? 0 : 7 * kCcBoxes);  // overflow records, 7 words each
-    const int nbox = min(ncl, kCcBoxes);
+    CC_MARK(6);
+    // ---- bounding boxes + type of every cluster (refineClusterByBoundingBox ssc.cpp:437-467, recognize ssc.cpp:849-872).
+    // The boxes take the key table's LDS (the search is over); components beyond kCcBoxes take arena scratch.
+    uint32_t* bb = (uint32_t*)cc_smem;
+    uint32_t* ov = (uint32_t*)(A.cl_bbox + 7 * (size_t)base);  // overflow records, 7 words each
     for (int c = tid; c < ncl; c += kCcThreads) {
         uint32_t* r = c < kCcBoxes ? bb + 7 * c : ov + 7 * (size_t)(c - kCcBoxes);
         r[0] = r[1] = r[2] = 0xffffffffu;  // running minima (order-preserving encoding)
@@ -2139,7 +2273,6 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     }
     __syncthreads();
     {
-        const int lane = tid & 63;
         constexpr int U = 4;  // four points per thread and step: their index and point loads are in flight together
         for (int i0 = 0; i0 < n; i0 += kCcThreads * U) {
             int cidv[U], srcv[U];
@@ -2168,32 +2301,22 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
                     A.pt_type[(size_t)base + i] = 0;
                     A.cl_count[(size_t)base + i] = 1;
                 }
+                if (cid < 0) continue;
+                // most points lie inside the box their component has so far: plain reads first, an atomic only to grow it
+                uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
                 const uint32_t ox = f2ord(qv[u].x), oy = f2ord(qv[u].y), oz = f2ord(qv[u].z);
-                // neighbouring points mostly share the component: one lane per distinct component of the wave updates the box
-                bool todo = cid >= 0;
-                while (__any(todo)) {
-                    const int first = __ffsll((long long)__ballot(todo)) - 1;
-                    const int c0 = __shfl(cid, first);
-                    const bool mine = todo && (cid == c0);
-                    const int cnt = __popcll(__ballot(mine));
-                    const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mny = wave_min_u32(mine ? oy : 0xffffffffu),
-                                   mnz = wave_min_u32(mine ? oz : 0xffffffffu);
-                    const uint32_t mxx = wave_max_u32(mine ? ox : 0u), mxy = wave_max_u32(mine ? oy : 0u), mxz = wave_max_u32(mine ? oz : 0u);
-                    if (lane == first) {
-                        uint32_t* r = c0 < kCcBoxes ? bb + 7 * c0 : ov + 7 * (size_t)(c0 - kCcBoxes);
-                        atomicMin(&r[0], mnx);
-                        atomicMin(&r[1], mny);
-                        atomicMin(&r[2], mnz);
-                        atomicMax(&r[3], mxx);
-                        atomicMax(&r[4], mxy);
-                        atomicMax(&r[5], mxz);
-                        atomicAdd(&r[6], (uint32_t)cnt);
-                    }
-                    if (mine) todo = false;
-                }
+                const uint32_t b0 = cc_ldu(&r[0]), b1 = cc_ldu(&r[1]), b2 = cc_ldu(&r[2]), b3 = cc_ldu(&r[3]), b4 = cc_ldu(&r[4]), b5 = cc_ldu(&r[5]);
+                if (ox < b0) atomicMin(&r[0], ox);
+                if (oy < b1) atomicMin(&r[1], oy);
+                if (oz < b2) atomicMin(&r[2], oz);
+                if (ox > b3) atomicMax(&r[3], ox);
+                if (oy > b4) atomicMax(&r[4], oy);
+                if (oz > b5) atomicMax(&r[5], oz);
+                atomicAdd(&r[6], 1u);
             }
         }
     }
+    CC_MARK(7);
     __syncthreads();
     for (int c = tid; c < ncl; c += kCcThreads) {
         uint32_t* r = c < kCcBoxes ? bb + 7 * c : ov + 7 * (size_t)(c - kCcBoxes);
@@ -2216,6 +2339,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         r[0] = t;
         A.cl_count[(size_t)base + names[c]] = cnt;  // Cluster::occupy_pts.size(), kept at the cluster's canonical name
     }
+    CC_MARK(8);
     __syncthreads();
     for (int i0 = 0; i0 < n; i0 += kCcThreads * 4) {
         int cv[4];
@@ -2232,6 +2356,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
             A.pt_type[(size_t)base + i0 + u * kCcThreads + tid] = (uint8_t)r[0];
         }
     }
+    CC_MARK(9);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2918,3 +3043,13 @@ void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t 
 }
 
 }  // namespace scvod
+
+#ifdef SCVOD_CC_PROFILE
+// development build only (make prof): summed phase clocks of k_cc_scan, 100 MHz ticks; reading resets them
+extern "C" int scvod_debug_cc_profile(unsigned long long* out16) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(scvod::g_cc_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long z[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(scvod::g_cc_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

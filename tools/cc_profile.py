@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Development tool: where k_cc_scan spends its time.  Needs the profiling build (make -C dr-using-scv-od_amd/csrc prof):
+the kernel then sums the 100 MHz wall clock between its phases over all workgroups (thread 0, behind a barrier).
+usage: python tools/cc_profile.py [--kind K64|PARK|OS128] [--preset semantickitti] [--scans 256]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
+PHASES = ["clear + voxel start bits", "runs (two gathers)", "prefix + key table + init", "neighbour search + unions", "extra runs, canonical names",
+          "flatten + compact ids", "box init", "names + boxes per slot", "types of clusters", "type per point"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", default="K64")
+    ap.add_argument("--preset", default="semantickitti")
+    ap.add_argument("--scans", type=int, default=256)
+    a = ap.parse_args()
+    import torch
+    import scvod_py
+    import synth
+    scvod_py.LIB_PATH = os.path.join(ROOT, "dr-using-scv-od_amd", "csrc", "libscvod_prof.so")
+    lib = scvod_py.load_lib()
+    dev = torch.device("cuda", 0)
+    parts, offs = [], [0]
+    for i in range(a.scans):
+        p, _, _ = synth.make_scan(5, i * 7, a.kind, device=dev)
+        parts.append(p)
+        offs.append(offs[-1] + p.shape[0])
+    pts = torch.cat(parts, 0).contiguous()
+    offs = np.asarray(offs, np.int32)
+    ctx = scvod_py.Ctx(scvod_py.make_params(a.preset), max_points_total=int(offs[-1]) + 1024, max_scans=a.scans, device=0)
+    out = (C.c_ulonglong * 16)()
+    for rep in range(2):
+        ctx.batch_process(pts, offs)
+        lib.scvod_debug_cc_profile(out)
+        ctx.batch_cluster()
+        lib.scvod_debug_cc_profile(out)
+    t = np.asarray(list(out), np.float64)[:len(PHASES)] * 0.01 / a.scans  # us per scan
+    print(f"{a.kind} {a.preset}: {a.scans} scans, {offs[-1] / a.scans:.0f} points per scan; k_cc_scan phases, us per scan (sum {t.sum():.1f})")
+    for name, v in zip(PHASES, t):
+        print(f"  {name:32s} {v:8.1f}  {100 * v / t.sum():5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
