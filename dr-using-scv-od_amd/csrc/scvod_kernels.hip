@@ -1982,11 +1982,73 @@ __device__ __forceinline__ bool cc_search_fast(const CcKeys& K, int* parent, int
                 }
                 if (me_reg && u > me && cc_bit(regular, u)) continue;  // u joins me (and touches me) when its turn comes
                 cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
+#ifndef SCVOD_CC_NOUNION
                 ra = cc_union_r(parent, ra, u);
+#endif
             }
         }
     }
     return found;
+}
+
+// When EVERY node of the scan is regular (no -1 bins, no extra runs: the usual case, the range / FOV verdict keeps such points
+// out of apri_vec) every voxel touches itself and every neighbour pair is mutual, so a node only looks BACKWARDS in key order
+// (z-major, then range, then sector): its predecessor in the row, the row (z, x-1) and the three rows of plane z-1 -- four
+// lower bounds, taken in lockstep so that their LDS reads overlap, instead of nine one after the other.
+__device__ __forceinline__ void cc_search_half(const CcKeys& K, int* parent, int me, int32_t t, int R, int S, int Az) {
+    const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+    const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
+    int k0[4], k1[4], lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = (q == 3) ? ri - 1 : ri - 1 + q;
+        const int z = (q == 3) ? ai : ai - 1;
+        const bool valid = z >= 0 && x >= 0 && x <= R - 1;
+        k0[q] = valid ? x * S + ylo + z * R * S : -1;
+        k1[q] = k0[q] + (yhi - ylo);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int b = max(k0[q], 0) >> K.bshift;
+        lo[q] = K.tab[b];
+        hi[q] = K.tab[b + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (k0[q] < 0) lo[q] = hi[q] = 0;
+    bool more = true;
+    while (more) {
+        more = false;
+        int kq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kq[q] = K.lk[(lo[q] + hi[q]) >> 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (lo[q] < hi[q]) {
+                const int mid = (lo[q] + hi[q]) >> 1;
+                if (kq[q] < k0[q])
+                    lo[q] = mid + 1;
+                else
+                    hi[q] = mid;
+                more |= lo[q] < hi[q];
+            }
+        }
+    }
+    int cand[12];  // a range holds at most three keys (sectors y-1 .. y+1), distinct and ascending
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) cand[q * 3 + e] = K.lk[min(lo[q] + e, K.nv - 1)];
+    const int prev = K.lk[max(me - 1, 0)];
+    int ra = me;
+    if (me > 0 && si >= 1 && prev == K.lk[me] - 1) ra = cc_union_r(parent, ra, me - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int u = lo[q] + e;
+            if (k0[q] >= 0 && u < K.nv && cand[q * 3 + e] <= k1[q]) ra = cc_union_r(parent, ra, u);
+        }
 }
 
 __device__ __forceinline__ uint32_t f2ord(float f) { return float_sort_key(f); }
@@ -2017,25 +2079,23 @@ __device__ unsigned long long g_cc_prof[16];
 #define CC_MARK(i)
 #endif
 
-__global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, int from_apri) {
+// FAST: every table of the scan in LDS, the pointers are LDS pointers at compile time (ds_* instead of flat_* accesses);
+// gives up (returns false, nothing published yet) when the extra runs push the node count over kCcNodes.  The generic
+// variant picks LDS or arena scratch per table at run time.
+extern __shared__ int cc_smem[];
+template <bool FAST>
+__device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A, int from_apri, int* wsum, int& n_extra_s, int s, int base, int n,
+                                             int nv) {
 #ifdef SCVOD_CC_PROFILE
     unsigned long long t_prev = wall_clock64();
 #endif
-    extern __shared__ int cc_smem[];
-    __shared__ int wsum[17];
-    __shared__ int n_extra_s;
-    const int s = blockIdx.x;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    const int nv = A.counts[s * 8 + 6];
-    if (n <= 0) return;
     const int tid = threadIdx.x;
     const int32_t* vbeg = A.vox_pt_begin + base + s;
     const int32_t* vpts = A.vox_pts + base;
     const int32_t* idx3 = A.apri_idx3 + base;
     const int nw = (n + 31) >> 5;             // words of the per-slot bit arrays
     // storage: LDS when the scan fits, the arena's per-point scratch otherwise (none of it is live during clustering)
-    const bool slots_lds = n <= kCcSlots;
+    const bool slots_lds = FAST || n <= kCcSlots;
     int* vstart = slots_lds ? cc_smem + 2 * kCcNodes : A.pt_voxel + base;
     int* rstart = slots_lds ? vstart + kCcSlots / 32 : A.tk_members + base;
     int* prefix = slots_lds ? rstart + kCcSlots / 32 : A.tk_clusters + base;
@@ -2097,7 +2157,8 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     __syncthreads();
     const int n_extra = n_extra_s;
     const int nn = nv + n_extra;
-    const bool nodes_lds = nn <= kCcNodes;
+    if (FAST && nn > kCcNodes) return false;
+    const bool nodes_lds = FAST || nn <= kCcNodes;
     int* lkeys = cc_smem;
     int* parent = nodes_lds ? cc_smem + kCcNodes : A.cc_parent + base;
     int* touched = nodes_lds ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) : A.tk_npairs + base;
@@ -2138,7 +2199,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         return prefix[k >> 5] + __popc(m) - 1;
     };
     // the run that starts a voxel is node v, an extra run is node nv + e
-    if (nodes_lds && K.tab) {
+    if (FAST && K.tab) {
         int* regular = cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2;
         int tc[kCcIter];  // the opener's triple of this thread's nodes: the three dependent gathers of all of them in flight together
 #pragma unroll
@@ -2151,6 +2212,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
 #pragma unroll
         for (int it = 0; it < kCcIter; ++it) tc[it] = idx3[tc[it]];
         int* triple = A.cc_parent + base;  // [nn] arena scratch (the parents are in LDS): the search loop below stays rolled
+        bool irregular = false;
 #pragma unroll
         for (int it = 0; it < kCcIter; ++it) {
             const int j = it * kCcThreads + tid;
@@ -2160,13 +2222,23 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
             const unsigned long long b = __ballot(reg);
             if ((tid & 31) == 0) regular[j >> 5] = (int)(unsigned)((tid & 32) ? (b >> 32) : b);
             if (j < nn) triple[j] = t;
+            irregular |= (j < nn) && !reg;
         }
-        __syncthreads();
+        const bool all_regular = !__syncthreads_or(irregular ? 1 : 0);
         int t_next = triple[min(tid, nn - 1)];
-        for (int j = tid; j < nn; j += kCcThreads) {
-            const int t = t_next;
-            t_next = triple[min(j + kCcThreads, nn - 1)];
-            if (cc_search_fast(K, parent, touched, regular, j, j < nv && cc_bit(regular, j), t, R, S, Az)) cc_set(found, j);
+        if (all_regular) {
+            for (int w = tid; w < ((nn + 31) >> 5); w += kCcThreads) touched[w] = found[w] = -1;  // every voxel finds itself
+            for (int j = tid; j < nn; j += kCcThreads) {
+                const int t = t_next;
+                t_next = triple[min(j + kCcThreads, nn - 1)];
+                cc_search_half(K, parent, j, t, R, S, Az);
+            }
+        } else {
+            for (int j = tid; j < nn; j += kCcThreads) {
+                const int t = t_next;
+                t_next = triple[min(j + kCcThreads, nn - 1)];
+                if (cc_search_fast(K, parent, touched, regular, j, j < nv && cc_bit(regular, j), t, R, S, Az)) cc_set(found, j);
+            }
         }
     } else {
         for (int j = tid; j < nn; j += kCcThreads) {
@@ -2357,6 +2429,22 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         }
     }
     CC_MARK(9);
+    return true;
+}
+
+__global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, int from_apri) {
+    __shared__ int wsum[17];
+    __shared__ int n_extra_s;
+    const int s = blockIdx.x;
+    const int base = A.scan_off[s];
+    const int n = A.counts[s * 8 + 4];
+    const int nv = A.counts[s * 8 + 6];
+    if (n <= 0) return;
+    if (n <= kCcSlots && nv <= kCcNodes) {
+        if (cc_scan_impl<true>(P, A, from_apri, wsum, n_extra_s, s, base, n, nv)) return;
+        __syncthreads();
+    }
+    cc_scan_impl<false>(P, A, from_apri, wsum, n_extra_s, s, base, n, nv);
 }
 
 // ------------------------------------------------------------------------------------------
