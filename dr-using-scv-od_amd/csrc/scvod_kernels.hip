@@ -22,6 +22,8 @@
 // intensity sums in point order.  Parallelism therefore comes from patches x scans and
 // voxels x scans (and, inside a large patch, from its nine independent sums), not from
 // tree reductions of those sums.
+#include <type_traits>
+
 #include "scvod_dev.h"
 
 namespace scvod {
@@ -1848,12 +1850,13 @@ constexpr int kCcNodes = 14336;  // voxels + extra run openers per scan held in 
 constexpr int kCcSlots = 65536;  // apri points per scan whose run / voxel start bits are held in LDS
 constexpr int kCcThreads = 1024;
 constexpr int kCcBoxes = 2048;   // bounding boxes per scan held in LDS (7 words each, in the key table once the search is over)
-constexpr int kCcBuckets = 8192; // entries of the key-bucket index (uint16 node numbers)
+constexpr int kCcBuckets = 8192; // entries of the key-bucket index (uint16 node numbers; the generic variant: kCcNodes 32-bit entries)
+constexpr int kCcSlotsBig = 262144;  // generic variant: the nodes live in HBM, which leaves LDS for the bit arrays of this many points
+
 static_assert(7 * kCcBoxes <= kCcNodes, "box records must fit the released key table");
 constexpr size_t kCcLdsBytes = (size_t)(2 * kCcNodes + 3 * (kCcSlots / 32) + 3 * (kCcNodes / 32) + kCcBuckets / 2 + 64) * 4;
-constexpr int kCcIter = kCcNodes / kCcThreads;  // nodes per thread when the scan's nodes fit LDS
-static_assert(kCcNodes % kCcThreads == 0, "the register-cached node loop covers kCcNodes exactly");
 static_assert(kCcLdsBytes <= 160 * 1024, "one workgroup per CU: all of its LDS");
+static_assert((size_t)(kCcNodes + 3 * (kCcSlotsBig / 32)) * 4 <= kCcLdsBytes, "generic layout inside the same LDS");
 
 __device__ __forceinline__ int cc_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t cc_ldu(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1894,38 +1897,33 @@ __device__ __forceinline__ int cc_lower_bound(const int* keys, int nv, int key) 
 __device__ __forceinline__ bool cc_bit(const int* bits, int i) { return (cc_ld(&bits[i >> 5]) >> (i & 31)) & 1; }
 __device__ __forceinline__ void cc_set(int* bits, int i) { atomicOr(&bits[i >> 5], 1 << (i & 31)); }
 
-// two-level table: `lk` holds every 2^shift-th key (all of them when shift == 0) in LDS, the rest stays in `gk` (HBM):
-// one LDS search + at most 2^shift adjacent global reads instead of log2(nv) dependent global round trips
+// sorted voxel keys of the scan (`k`: LDS in the FAST variant, HBM otherwise) + bucket index in LDS: tab[b] = first node whose
+// key is >= b << bshift, for the keys a search can ask for (0 .. R*S*Az - 1).  A lower bound then costs two table reads and a
+// search among the few keys of one bucket instead of log2(nv) dependent reads.
+template <typename TabT>
 struct CcKeys {
-    const int* lk;
-    const int* gk;
-    int ns, nv, shift;
-    const uint16_t* tab;  // tab[b] = first node whose key is >= b << bshift (nullptr: no index; keys >= 0 only)
+    const int* k;
+    int nv;
+    const TabT* tab;
     int bshift;
 };
-__device__ __forceinline__ int cc_lower_bound2(const CcKeys& K, int key) {
-    if (K.tab) {  // whole key table in LDS + bucket index: the search runs inside one bucket (a handful of keys)
-        const int b = key >> K.bshift;
-        int lo = K.tab[b], hi = K.tab[b + 1];
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (K.lk[mid] < key)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        return lo;
+template <typename TabT>
+__device__ __forceinline__ int cc_lower_bound2(const CcKeys<TabT>& K, int key) {  // key >= 0
+    const int b = key >> K.bshift;
+    int lo = (int)K.tab[b], hi = (int)K.tab[b + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (K.k[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
     }
-    const int lo = cc_lower_bound(K.lk, K.ns, key);  // first sample >= key
-    if (K.shift == 0 || lo == 0) return lo << K.shift;
-    int u = ((lo - 1) << K.shift) + 1;
-    const int end = min(lo << K.shift, K.nv);
-    while (u < end && K.gk[u] < key) ++u;
-    return u;
+    return lo;
 }
 
 // neighbourhood of triple t for node `me`: unions with every occupied voxel found, marks them touched
-__device__ __forceinline__ bool cc_search(const CcKeys& K, int* parent, int* touched, int me, int32_t t, int R, int S, int Az) {
+template <typename TabT>
+__device__ __forceinline__ bool cc_search(const CcKeys<TabT>& K, int* parent, int* touched, int me, int32_t t, int R, int S, int Az) {
     const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
     const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
     bool found = false;
@@ -1935,7 +1933,7 @@ __device__ __forceinline__ bool cc_search(const CcKeys& K, int* parent, int* tou
         for (int x = ri - 1; x <= ri + 1; ++x) {
             if (x > R - 1 || x < 0) continue;
             const int k0 = x * S + ylo + z * R * S, k1 = k0 + (yhi - ylo);
-            for (int u = cc_lower_bound2(K, k0); u < K.nv && K.gk[u] <= k1; ++u) {
+            for (int u = cc_lower_bound2(K, k0); u < K.nv && K.k[u] <= k1; ++u) {
                 cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
                 if (u != me) cc_union(parent, me, u);
                 found = true;
@@ -1959,44 +1957,34 @@ __device__ __forceinline__ int cc_union_r(int* parent, int a, int b) {
         if (atomicCAS(&parent[a], a, b) == a) return b;
     }
 }
-// cc_search for the all-in-LDS case.  A REGULAR node is a voxel whose opener's triple is in range and encodes to the voxel's
-// own key: it finds itself (so it is touched and found), and two regular voxels find each other, so the pair is joined by
-// the one with the larger index only -- half the unions, and every union starts from the root the previous one returned.
-__device__ __forceinline__ bool cc_search_fast(const CcKeys& K, int* parent, int* touched, const int* regular, int me, bool me_reg,
-                                               int32_t t, int R, int S, int Az) {
-    const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+// A REGULAR node is a voxel whose opener's triple is in range and encodes to the voxel's own key: it finds itself (so it is
+// touched and found), and two regular voxels find each other, so such a pair is joined once, by the one with the larger
+// index looking backwards (cc_search_half).  The few irregular nodes (-1 bins, extra runs) run the full search around their
+// own triple, and an irregular VOXEL also looks around its key's own triple on behalf of the regular voxels that find it there.
+template <typename TabT>
+__device__ __forceinline__ void cc_search_canon(const CcKeys<TabT>& K, int* parent, int* touched, const int* regular, int me, int key, int R,
+                                                int S, int Az) {
+    const int RS = R * S;
+    const int ai = key / RS, rem = key - ai * RS;
+    const int ri = rem / S, si = rem - ri * S;
     const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
-    bool found = false;
-    if (ylo > yhi) return false;
-    int ra = me;
-    for (int z = ai - 1; z <= ai + 1; ++z) {
-        if (z > Az - 1 || z < 0) continue;
-        for (int x = ri - 1; x <= ri + 1; ++x) {
-            if (x > R - 1 || x < 0) continue;
-            const int k0 = x * S + ylo + z * R * S, k1 = k0 + (yhi - ylo);
-            for (int u = cc_lower_bound2(K, k0); u < K.nv && K.lk[u] <= k1; ++u) {
-                found = true;
-                if (u == me) {
-                    cc_set(touched, u);
-                    continue;
-                }
-                if (me_reg && u > me && cc_bit(regular, u)) continue;  // u joins me (and touches me) when its turn comes
-                cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
-#ifndef SCVOD_CC_NOUNION
-                ra = cc_union_r(parent, ra, u);
-#endif
+    for (int z = max(ai - 1, 0); z <= min(ai + 1, Az - 1); ++z)
+        for (int x = max(ri - 1, 0); x <= min(ri + 1, R - 1); ++x) {
+            const int k0 = x * S + ylo + z * RS, k1 = k0 + (yhi - ylo);
+            for (int u = cc_lower_bound2(K, k0); u < K.nv && K.k[u] <= k1; ++u) {
+                if (u == me || !cc_bit(regular, u)) continue;
+                cc_set(touched, me);  // the regular voxel u finds me here (ssc.cpp:316)
+                cc_union(parent, me, u);
             }
         }
-    }
-    return found;
 }
 
 // When EVERY node of the scan is regular (no -1 bins, no extra runs: the usual case, the range / FOV verdict keeps such points
 // out of apri_vec) every voxel touches itself and every neighbour pair is mutual, so a node only looks BACKWARDS in key order
 // (z-major, then range, then sector): its predecessor in the row, the row (z, x-1) and the three rows of plane z-1 -- four
 // lower bounds, taken in lockstep so that their LDS reads overlap, instead of nine one after the other.
-__device__ __forceinline__ void cc_search_half(const CcKeys& K, int* parent, int me, int32_t t, int R, int S, int Az) {
-    const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+template <typename TabT>
+__device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* parent, int me, int ri, int si, int ai, int R, int S, int Az) {
     const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
     int k0[4], k1[4], lo[4], hi[4];
 #pragma unroll
@@ -2010,8 +1998,8 @@ __device__ __forceinline__ void cc_search_half(const CcKeys& K, int* parent, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int b = max(k0[q], 0) >> K.bshift;
-        lo[q] = K.tab[b];
-        hi[q] = K.tab[b + 1];
+        lo[q] = (int)K.tab[b];
+        hi[q] = (int)K.tab[b + 1];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -2021,7 +2009,7 @@ __device__ __forceinline__ void cc_search_half(const CcKeys& K, int* parent, int
         more = false;
         int kq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) kq[q] = K.lk[(lo[q] + hi[q]) >> 1];
+        for (int q = 0; q < 4; ++q) kq[q] = K.k[min((lo[q] + hi[q]) >> 1, K.nv - 1)];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (lo[q] < hi[q]) {
@@ -2038,10 +2026,10 @@ __device__ __forceinline__ void cc_search_half(const CcKeys& K, int* parent, int
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 3; ++e) cand[q * 3 + e] = K.lk[min(lo[q] + e, K.nv - 1)];
-    const int prev = K.lk[max(me - 1, 0)];
+        for (int e = 0; e < 3; ++e) cand[q * 3 + e] = K.k[min(lo[q] + e, K.nv - 1)];
+    const int prev = K.k[max(me - 1, 0)];
     int ra = me;
-    if (me > 0 && si >= 1 && prev == K.lk[me] - 1) ra = cc_union_r(parent, ra, me - 1);
+    if (me > 0 && si >= 1 && prev == K.k[me] - 1) ra = cc_union_r(parent, ra, me - 1);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -2093,12 +2081,38 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     const int32_t* vbeg = A.vox_pt_begin + base + s;
     const int32_t* vpts = A.vox_pts + base;
     const int32_t* idx3 = A.apri_idx3 + base;
+    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
+    const long long span = (long long)R * S * Az;
+    // A scan is REGULAR when every apri point's index triple lies inside the grid and encodes to its voxel key (no -1 bins:
+    // the usual case, the range / FOV verdict keeps such points out of apri_vec).  Then equal keys mean equal triples -- no
+    // extra runs --, every voxel finds itself and every neighbour pair is mutual (cc_search_half).  One coalesced pass decides.
+    bool bad = !(span > 0 && span < 0x7fffffffLL);
+    for (int i0 = 0; i0 < n; i0 += kCcThreads * 4) {
+        int tv[4], kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * kCcThreads + tid, n - 1);
+            tv[u] = idx3[i];
+            kv[u] = from_apri ? A.apri_key[(size_t)base + i] : 0;  // k_emit / k_bin_direct encode the key from the triple themselves
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tv[u];
+            const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+            bad |= ri < 0 || ri >= R || si < 0 || si >= S || ai < 0 || ai >= Az;
+            if (from_apri) bad |= kv[u] != ri * S + si + ai * R * S;
+        }
+    }
+    const bool allreg = !__syncthreads_or(bad ? 1 : 0);
     const int nw = (n + 31) >> 5;             // words of the per-slot bit arrays
-    // storage: LDS when the scan fits, the arena's per-point scratch otherwise (none of it is live during clustering)
-    const bool slots_lds = FAST || n <= kCcSlots;
-    int* vstart = slots_lds ? cc_smem + 2 * kCcNodes : A.pt_voxel + base;
-    int* rstart = slots_lds ? vstart + kCcSlots / 32 : A.tk_members + base;
-    int* prefix = slots_lds ? rstart + kCcSlots / 32 : A.tk_clusters + base;
+    // storage.  FAST: everything in LDS -- [keys N][parents N][vstart][rstart][prefix][touched][found][bucket index][regular].
+    // Generic: nodes (keys, parents, touched / found) in HBM, LDS = [bucket index, 32-bit][vstart][rstart][prefix] for up to
+    // kCcSlotsBig points; beyond that the bit arrays move to the arena's per-point scratch (nothing of it is live here).
+    const bool slots_lds = FAST || n <= kCcSlotsBig;
+    constexpr int kSlotWords = FAST ? kCcSlots / 32 : kCcSlotsBig / 32;
+    int* vstart = FAST ? cc_smem + 2 * kCcNodes : (slots_lds ? cc_smem + kCcNodes : A.pt_voxel + base);
+    int* rstart = slots_lds ? vstart + kSlotWords : A.tk_members + base;
+    int* prefix = slots_lds ? rstart + kSlotWords : A.tk_clusters + base;
     int* extras = A.tk_uniq + base;            // slots of the extra run openers (rare: global scratch in both modes)
     int* extra_of_slot = A.tk_mbegin + base;   // slot -> index in extras
     if (tid == 0) n_extra_s = 0;
@@ -2110,34 +2124,36 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     for (int v = tid; v < nv; v += kCcThreads) {
         const int k = vbeg[v];
         cc_set(vstart, k);
-        cc_set(rstart, k);
+        if (!allreg) cc_set(rstart, k);
     }
     __syncthreads();
     CC_MARK(0);
     // runs inside a voxel: a slot whose triple differs from the previous slot's opens one (ssc.cpp:306-330 walks the
     // voxel's points with their own triples; equal triples have equal neighbourhoods)
-    for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {
-        int pa[4], pb[4], ta[4], tb[4];
+    if (!allreg) {
+        for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {
+            int pa[4], pb[4], ta[4], tb[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // the two dependent gathers of four slots in flight together
-            const int k = min(k0 + u * kCcThreads + tid, n - 1);
-            pa[u] = vpts[k];
-            pb[u] = vpts[max(k - 1, 0)];
-        }
+            for (int u = 0; u < 4; ++u) {  // the two dependent gathers of four slots in flight together
+                const int k = min(k0 + u * kCcThreads + tid, n - 1);
+                pa[u] = vpts[k];
+                pb[u] = vpts[max(k - 1, 0)];
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ta[u] = idx3[pa[u]];
-            tb[u] = idx3[pb[u]];
-        }
+            for (int u = 0; u < 4; ++u) {
+                ta[u] = idx3[pa[u]];
+                tb[u] = idx3[pb[u]];
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * kCcThreads + tid;
-            if (k >= n || cc_bit(vstart, k)) continue;
-            if (ta[u] != tb[u]) {
-                const int e = atomicAdd(&n_extra_s, 1);
-                extras[e] = k;
-                extra_of_slot[k] = e;
-                cc_set(rstart, k);
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * kCcThreads + tid;
+                if (k >= n || cc_bit(vstart, k)) continue;
+                if (ta[u] != tb[u]) {
+                    const int e = atomicAdd(&n_extra_s, 1);
+                    extras[e] = k;
+                    extra_of_slot[k] = e;
+                    cc_set(rstart, k);
+                }
             }
         }
     }
@@ -2158,92 +2174,100 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     const int n_extra = n_extra_s;
     const int nn = nv + n_extra;
     if (FAST && nn > kCcNodes) return false;
-    const bool nodes_lds = FAST || nn <= kCcNodes;
-    int* lkeys = cc_smem;
-    int* parent = nodes_lds ? cc_smem + kCcNodes : A.cc_parent + base;
-    int* touched = nodes_lds ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) : A.tk_npairs + base;
-    int* found = nodes_lds ? touched + kCcNodes / 32 : A.tk_hit + base;
-    CcKeys K;
+    int* lkeys = cc_smem;  // FAST only
+    int* parent = FAST ? cc_smem + kCcNodes : A.cc_parent + base;
+    int* touched = FAST ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) : A.tk_npairs + base;
+    int* found = FAST ? touched + kCcNodes / 32 : A.tk_hit + base;
+    using TabT = typename std::conditional<FAST, uint16_t, uint32_t>::type;
+    constexpr int kTabEntries = FAST ? kCcBuckets : kCcNodes;
+    TabT* tab = FAST ? (TabT*)(cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32)) : (TabT*)cc_smem;
+    CcKeys<TabT> K;
     K.nv = nv;
-    K.shift = 0;
-    while (((nv + (1 << K.shift) - 1) >> K.shift) > kCcNodes) ++K.shift;
-    K.ns = (nv + (1 << K.shift) - 1) >> K.shift;
-    K.lk = lkeys;
-    K.gk = (K.shift == 0) ? lkeys : A.vox_key + base;
-    for (int v = tid; v < K.ns; v += kCcThreads) lkeys[v] = A.vox_key[(size_t)base + ((size_t)v << K.shift)];
-    for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;
-    for (int w = tid; w < ((nn + 31) >> 5); w += kCcThreads) {
-        touched[w] = 0;
-        found[w] = 0;
-    }
-    __syncthreads();
-    const int R = P.bin.range_num, S = P.bin.sector_num, Az = P.bin.azimuth_num;
-    // bucket index over the keys a search can ask for (0 .. R*S*Az - 1): a lower bound then costs two table reads and a
-    // search among the few keys of one bucket instead of log2(nv) dependent LDS reads
-    K.tab = nullptr;
+    K.k = FAST ? lkeys : A.vox_key + base;
+    K.tab = tab;
     K.bshift = 0;
-    {
-        const long long span = (long long)R * S * Az;
-        if (K.shift == 0 && span > 0 && span < 0x7fffffffLL) {
-            uint16_t* tab = (uint16_t*)(cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32));
-            while ((((int)span - 1) >> K.bshift) + 2 > kCcBuckets) ++K.bshift;
-            const int nb = (((int)span - 1) >> K.bshift) + 1;
-            for (int b = tid; b <= nb; b += kCcThreads) tab[b] = (uint16_t)cc_lower_bound(lkeys, nv, (int)min((long long)b << K.bshift, 0x7fffffffLL));
-            K.tab = tab;
-            __syncthreads();
+    const int kspan = (span > 0 && span < 0x7fffffffLL) ? (int)span : 0x7ffffffe;  // (an overflowing grid: all int keys searchable)
+    while (((kspan - 1) >> K.bshift) + 2 > kTabEntries) ++K.bshift;
+    const int nb = ((kspan - 1) >> K.bshift) + 1;
+    if (FAST)
+        for (int v = tid; v < nv; v += kCcThreads) lkeys[v] = A.vox_key[(size_t)base + v];
+    for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;
+    __syncthreads();
+    if (FAST) {
+        for (int b = tid; b <= nb; b += kCcThreads) tab[b] = (TabT)cc_lower_bound(lkeys, nv, (int)min((long long)b << K.bshift, 0x7fffffffLL));
+    } else {
+        // keys in HBM: the nodes fill the table -- node v owns the buckets after its predecessor's up to its own
+        auto bucket_of = [&](int key) -> int { return key < 0 ? -1 : min(key >> K.bshift, nb); };
+        for (int v = tid; v < nv; v += kCcThreads) {
+            const int bc = bucket_of(K.k[v]);
+            const int bp = (v > 0) ? bucket_of(K.k[v - 1]) : -1;
+            for (int b = bp + 1; b <= bc; ++b) tab[b] = (TabT)v;
+            if (v == nv - 1)
+                for (int b = bc + 1; b <= nb; ++b) tab[b] = (TabT)nv;
         }
     }
+    __syncthreads();
     CC_MARK(2);
     auto voxel_of_slot = [&](int k) -> int {
         const unsigned m = (unsigned)vstart[k >> 5] & (0xffffffffu >> (31 - (k & 31)));
         return prefix[k >> 5] + __popc(m) - 1;
     };
     // the run that starts a voxel is node v, an extra run is node nv + e
-    if (FAST && K.tab) {
-        int* regular = cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2;
-        int tc[kCcIter];  // the opener's triple of this thread's nodes: the three dependent gathers of all of them in flight together
-#pragma unroll
-        for (int it = 0; it < kCcIter; ++it) {
-            const int j = it * kCcThreads + tid;
-            tc[it] = (j < nn) ? ((j < nv) ? vbeg[j] : extras[j - nv]) : 0;
-        }
-#pragma unroll
-        for (int it = 0; it < kCcIter; ++it) tc[it] = vpts[tc[it]];
-#pragma unroll
-        for (int it = 0; it < kCcIter; ++it) tc[it] = idx3[tc[it]];
-        int* triple = A.cc_parent + base;  // [nn] arena scratch (the parents are in LDS): the search loop below stays rolled
-        bool irregular = false;
-#pragma unroll
-        for (int it = 0; it < kCcIter; ++it) {
-            const int j = it * kCcThreads + tid;
-            const int t = tc[it];
-            const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
-            const bool reg = j < nv && ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == lkeys[j]);
-            const unsigned long long b = __ballot(reg);
-            if ((tid & 31) == 0) regular[j >> 5] = (int)(unsigned)((tid & 32) ? (b >> 32) : b);
-            if (j < nn) triple[j] = t;
-            irregular |= (j < nn) && !reg;
-        }
-        const bool all_regular = !__syncthreads_or(irregular ? 1 : 0);
-        int t_next = triple[min(tid, nn - 1)];
-        if (all_regular) {
-            for (int w = tid; w < ((nn + 31) >> 5); w += kCcThreads) touched[w] = found[w] = -1;  // every voxel finds itself
-            for (int j = tid; j < nn; j += kCcThreads) {
-                const int t = t_next;
-                t_next = triple[min(j + kCcThreads, nn - 1)];
-                cc_search_half(K, parent, j, t, R, S, Az);
-            }
-        } else {
-            for (int j = tid; j < nn; j += kCcThreads) {
-                const int t = t_next;
-                t_next = triple[min(j + kCcThreads, nn - 1)];
-                if (cc_search_fast(K, parent, touched, regular, j, j < nv && cc_bit(regular, j), t, R, S, Az)) cc_set(found, j);
-            }
+    if (allreg) {
+        const int RS = R * S;
+        int k_next = K.k[min(tid, nv - 1)];
+        for (int j = tid; j < nv; j += kCcThreads) {
+            const int key = k_next;
+            k_next = K.k[min(j + kCcThreads, nv - 1)];
+            const int ai = key / RS, rem = key - ai * RS;  // the triple IS the key's decomposition
+            const int ri = rem / S, si = rem - ri * S;
+            cc_search_half(K, parent, j, ri, si, ai, R, S, Az);
         }
     } else {
+        int* regular = FAST ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2 : A.pt_cluster + base;
+        int* triple = (int*)(A.tk_pairs + base);  // [nn] opener triples (arena scratch, free until the naming pass)
+        const int nwords = (nn + 31) >> 5;
+        for (int j0 = 0; j0 < nn; j0 += kCcThreads * 4) {  // the three dependent gathers of four nodes per thread in flight together
+            int tc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCcThreads + tid;
+                tc[u] = (j < nn) ? ((j < nv) ? vbeg[j] : extras[j - nv]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tc[u] = vpts[tc[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tc[u] = idx3[tc[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCcThreads + tid;
+                const int t = tc[u];
+                const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+                const bool reg = kspan == (int)span && j < nv && ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == K.k[min(j, nv - 1)]);
+                const unsigned long long b = __ballot(reg);
+                if ((tid & 31) == 0 && (j >> 5) < nwords) {
+                    const int word = (int)(unsigned)((tid & 32) ? (b >> 32) : b);
+                    regular[j >> 5] = word;
+                    touched[j >> 5] = word;  // a regular voxel finds itself
+                    found[j >> 5] = word;
+                }
+                if (j < nn) triple[j] = t;
+            }
+        }
+        __syncthreads();
+        int t_next = triple[min(tid, nn - 1)];
         for (int j = tid; j < nn; j += kCcThreads) {
-            const int k = (j < nv) ? vbeg[j] : extras[j - nv];
-            if (cc_search(K, parent, touched, j, idx3[vpts[k]], R, S, Az)) cc_set(found, j);
+            const int t = t_next;
+            t_next = triple[min(j + kCcThreads, nn - 1)];
+            if (cc_bit(regular, j)) {
+                cc_search_half(K, parent, j, (t & 2047) - 2, ((t >> 11) & 2047) - 2, ((t >> 22) & 1023) - 2, R, S, Az);
+            } else {
+                if (cc_search(K, parent, touched, j, t, R, S, Az)) cc_set(found, j);
+                if (j < nv) {
+                    const int key = K.k[j];
+                    if (key >= 0 && key < kspan) cc_search_canon(K, parent, touched, regular, j, key, R, S, Az);
+                }
+            }
         }
     }
     __syncthreads();
@@ -2256,7 +2280,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     __syncthreads();
     // canonical name of a component: the smallest apri index among the openers of its nodes (every other member of a
     // node sits behind its opener in an ascending point list)
-    int* minpt = nodes_lds ? lkeys : A.cl_count + base;  // the key table is not needed any more
+    int* minpt = FAST ? lkeys : A.cl_count + base;  // the key table is not needed any more
     for (int j = tid; j < nn; j += kCcThreads) minpt[j] = 0x7fffffff;
     __syncthreads();
     for (int j = tid; j < nn; j += kCcThreads) {
@@ -2303,7 +2327,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             int cid = -2;
             if (k < n) {
                 const int v = voxel_of_slot(k);
-                if (cc_bit(touched, v)) {
+                if (allreg || cc_bit(touched, v)) {
                     cid = parent[v];
                 } else {
                     int o = k;  // opener of this slot's run: the closest run start at or before k (a voxel start is one)
@@ -2440,7 +2464,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     const int n = A.counts[s * 8 + 4];
     const int nv = A.counts[s * 8 + 6];
     if (n <= 0) return;
-    if (n <= kCcSlots && nv <= kCcNodes) {
+    if (n <= kCcSlots && nv <= kCcNodes && (long long)P.bin.range_num * P.bin.sector_num * P.bin.azimuth_num < 0x7fffffffLL) {
         if (cc_scan_impl<true>(P, A, from_apri, wsum, n_extra_s, s, base, n, nv)) return;
         __syncthreads();
     }

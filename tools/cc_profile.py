@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--kind", default="K64")
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--scans", type=int, default=256)
+    ap.add_argument("--lib", default="libscvod_prof.so", help="profiling build to load (file name under csrc/)")
     a = ap.parse_args()
     import torch
     import scvod_py
     import synth
-    scvod_py.LIB_PATH = os.path.join(ROOT, "dr-using-scv-od_amd", "csrc", "libscvod_prof.so")
+    scvod_py.LIB_PATH = os.path.join(ROOT, "dr-using-scv-od_amd", "csrc", a.lib)
     lib = scvod_py.load_lib()
     dev = torch.device("cuda", 0)
     parts, offs = [], [0]
