@@ -217,7 +217,6 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.tk_cursor = c->t_pair;
     A.tk_mbegin = c->t_begin;
     A.vox_track = k.take<int4>(N);
-    A.cl_nvox = k.take<int32_t>(N);
     A.cl_state = k.take<int8_t>(N);
     A.tk_members = k.take<int32_t>(N);
     A.tk_pairs = k.take<int2>(N);

@@ -117,7 +117,6 @@ struct Arena {
     int4* vox_track;          // [N] per voxel: {key, label = cluster root of its points or -1, |occupy_voxels| of that
                               //     cluster, its type}: the table the probe of the PREVIOUS scan runs against; also the
                               //     boundary message between sequence shards (scvod_batch_export_table)
-    int32_t* cl_nvox;         // [N] per cluster root: number of voxels labelled with it (Cluster::occupy_voxels.size())
     int8_t* cl_state;         // [N] per cluster root: Cluster::state (-1 untouched, 0 static, 1 dynamic)
     int32_t* tk_mbegin;       // [N] per car root: first slot of its members in tk_members (scan-local)
     int32_t* tk_cursor;       // [N] per car root: scatter cursor

@@ -2433,10 +2433,38 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
                 t = 1;
         }
         r[0] = t;
+        r[1] = 0;  // (the box is used up: the word counts the cluster's voxels below)
         A.cl_count[(size_t)base + names[c]] = cnt;  // Cluster::occupy_pts.size(), kept at the cluster's canonical name
     }
-    CC_MARK(8);
     __syncthreads();
+    // ---- successor table of the scan: Voxel::label after clusterAndCreateFrame + refineClusterByBoundingBox (ssc.cpp:388-392,
+    // 461-466) = the cluster of the voxel's first point, -1 when the refine erased it; |occupy_voxels| of that cluster
+    // (sampleVec of its points' voxel_idx, ssc.cpp:382-384) = the number of voxels carrying its label; its type.  This is what
+    // SSC::tracking probes a predecessor against and what a shard exports (scvod_batch_export_table).
+    auto cid_of_voxel = [&](int v) -> int {  // the voxel's first point opens node v
+        return (allreg || cc_bit(touched, v) || cc_bit(found, v)) ? parent[v] : -1;
+    };
+    for (int v = tid; v < nv; v += kCcThreads) {
+        const int cid = cid_of_voxel(v);
+        if (cid < 0) continue;
+        uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+        if (r[0]) atomicAdd(&r[1], 1u);
+    }
+    __syncthreads();
+    for (int v = tid; v < nv; v += kCcThreads) {
+        const int cid = cid_of_voxel(v);
+        int4 rec = make_int4(A.vox_key[(size_t)base + v], -1, 0, 0);
+        if (cid >= 0) {
+            const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+            if (r[0]) {
+                rec.y = names[cid];
+                rec.z = (int)r[1];
+                rec.w = (int)r[0];
+            }
+        }
+        A.vox_track[(size_t)base + v] = rec;
+    }
+    CC_MARK(8);
     for (int i0 = 0; i0 < n; i0 += kCcThreads * 4) {
         int cv[4];
 #pragma unroll

@@ -64,8 +64,8 @@ __device__ __forceinline__ NextTable next_table_of(const Arena& A, const TrackBa
     return t;
 }
 
-// per cluster root: reset the per-cluster words a phase accumulates into (phase 1: the successor tables, phase 2: the
-// member lists and decisions -- a second scvod_batch_track on the same tables must start from clean words too)
+// per cluster root: reset the per-cluster words the decision pass accumulates into (member lists, pairs, states: a second
+// scvod_batch_track on the same tables must start from clean words too)
 __global__ __launch_bounds__(256) void k_tk_init(Arena A, int phase) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
@@ -73,48 +73,10 @@ __global__ __launch_bounds__(256) void k_tk_init(Arena A, int phase) {
     if (phase == 2 && blockIdx.x == 0 && threadIdx.x < 4) A.tk_scan[s * 4 + threadIdx.x] = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         if (A.pt_cluster[(size_t)base + i] != i) continue;
-        if (phase == 1) {
-            A.cl_nvox[(size_t)base + i] = 0;
-        } else {
-            A.tk_cursor[(size_t)base + i] = 0;
-            A.cl_state[(size_t)base + i] = -1;
-            A.tk_npairs[(size_t)base + i] = 0;
-            A.tk_nuniq[(size_t)base + i] = 0;
-        }
-    }
-}
-
-// Voxel::label after clusterAndCreateFrame + refineClusterByBoundingBox (ssc.cpp:388-392, 461-466): the cluster of the
-// voxel's points (all points of a voxel share one), -1 when the bounding-box refine erased that cluster; and
-// |occupy_voxels| per cluster (sampleVec of its points' voxel_idx, ssc.cpp:382-384) = the number of voxels carrying its label.
-__global__ __launch_bounds__(256) void k_tk_voxlabel(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int nv = A.counts[s * 8 + 6];
-    const int32_t* vbeg = A.vox_pt_begin + base + s;
-    for (int v0 = blockIdx.x * 256; v0 < nv; v0 += gridDim.x * 256) {
-        const int v = v0 + threadIdx.x;
-        int label = -1;
-        if (v < nv) {
-            const int p = A.vox_pts[(size_t)base + vbeg[v]];
-            label = A.pt_type[(size_t)base + p] ? A.pt_cluster[(size_t)base + p] : -1;
-            A.vox_track[(size_t)base + v] = make_int4(A.vox_key[(size_t)base + v], label, 0, 0);
-        }
-        int leader, rank, count;
-        wave_group(label, leader, rank, count);
-        if (label >= 0 && rank == 0) atomicAdd(&A.cl_nvox[(size_t)base + label], count);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_tk_voxfill(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int nv = A.counts[s * 8 + 6];
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
-        const int label = A.vox_track[(size_t)base + v].y;
-        if (label < 0) continue;
-        A.vox_track[(size_t)base + v].z = A.cl_nvox[(size_t)base + label];
-        A.vox_track[(size_t)base + v].w = (int)A.pt_type[(size_t)base + label];  // the root is a member: its type is the cluster's
+        A.tk_cursor[(size_t)base + i] = 0;
+        A.cl_state[(size_t)base + i] = -1;
+        A.tk_npairs[(size_t)base + i] = 0;
+        A.tk_nuniq[(size_t)base + i] = 0;
     }
 }
 
@@ -407,14 +369,7 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
-    if (phases & 1) {
-        TH_BEGIN("tk_labels");
-        hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A, 1);
-        hipLaunchKernelGGL(k_tk_voxlabel, g, dim3(256), 0, st, A);
-        hipLaunchKernelGGL(k_tk_voxfill, g, dim3(256), 0, st, A);
-        TH_END("tk_labels");
-    }
-    if (!(phases & 2)) return;
+    if (!(phases & 2)) return;  // (phase 1, the successor tables, is written by k_cc_scan with the clustering itself)
     TH_BEGIN("tk_members");
     hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A, 2);
     hipLaunchKernelGGL(k_tk_members, dim3(B), dim3(1024), 0, st, A);

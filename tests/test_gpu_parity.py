@@ -496,14 +496,47 @@ def _canonical(labels):
     return out
 
 
+def _with_irregular_returns(x, count, seed):
+    """returns at polar angle exactly 0 (y == +0, x > 0): sector index ceil(0) - 1 = -1 (ssc.cpp:186), above the ground"""
+    rng = np.random.default_rng(seed)
+    extra = np.stack([rng.uniform(3, 25, count), np.zeros(count), rng.uniform(-0.6, 1.2, count), rng.uniform(0, 1, count)], 1)
+    return np.concatenate([x, extra.astype(np.float32)])
+
+
+@pytest.mark.parametrize("kind,preset,seq,idx,stride", [("K64", "semantickitti", 5, 77, 3), ("PARK", "parkinglot", 3, 9, 1)])
+def test_cluster_partition_with_irregular_nodes(scvod, oracle, kind, preset, seq, idx, stride):
+    """a mostly regular scan (all-in-LDS variant): regular voxels look backwards only, the irregular nodes search in full"""
+    import synth
+    P = _params(scvod, preset)
+    x = _with_irregular_returns(synth.make_scan(seq, idx, kind)[0].numpy(), 60, 9)
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    assert (r["apri"]["sector_idx"] < 0).any()
+    ctx.batch_cluster()
+    full = ctx.batch_fetch_clusters(0, r["n_apri"])
+    assert np.array_equal(full, ctx.cluster(r["apri"]))   # cloud on the device == apri_vec handed in
+    apri = r["apri"][::stride].copy()
+    if stride > 1:   # keep every irregular point in the thinned cloud
+        keep = np.zeros(len(r["apri"]), bool)
+        keep[::stride] = True
+        keep |= r["apri"]["sector_idx"] < 0
+        apri = r["apri"][keep].copy()
+    ref, n_ref, _ = oracle.cluster(P, apri)
+    got = ctx.cluster(apri)
+    assert np.array_equal(got, _canonical(ref))
+    assert len(np.unique(got)) == n_ref
+    ctx.close()
+
+
 def test_cluster_partition_on_a_fine_grid(scvod, oracle):
     """more voxels than the clustering kernel's LDS key table holds: neighbourhood searches in global memory"""
     import synth
     P = scvod.make_params("semantickitti", range_res=0.05, sector_res=0.2, azimuth_res=0.25)
-    x = synth.make_scan(5, 33, "K64")[0].numpy()
+    x = _with_irregular_returns(synth.make_scan(5, 33, "K64")[0].numpy(), 80, 5)
     ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
     r = ctx.process_scan(x)
-    assert r["n_voxels"] > 8192
+    assert r["n_voxels"] > 14336               # the generic variant: keys and parents in HBM
+    assert (r["apri"]["sector_idx"] < 0).any()  # ... with a few irregular nodes among the regular ones
     got = ctx.cluster(r["apri"])
     ref, _, _ = oracle.cluster(P, r["apri"])
     assert np.array_equal(got, _canonical(ref))
