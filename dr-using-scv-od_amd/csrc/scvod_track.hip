@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_tk_probe(DevParams P, Arena A, TrackBat
     __shared__ int32_t skeys[kTkSamples];
     const int s = blockIdx.y;
     const int n_car = A.tk_scan[s * 4 + 1];
-    if ((int)blockIdx.x * 256 >= n_car) return;
+    if ((int)blockIdx.x * 1024 >= n_car) return;
     const NextTable N = next_table_of(A, J, s);
     if (N.nv < 0) return;
     const int base = A.scan_off[s];
@@ -162,43 +162,77 @@ __global__ __launch_bounds__(256) void k_tk_probe(DevParams P, Arena A, TrackBat
     float T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = J.T[12 * s + i];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n_car; k += gridDim.x * 256) {
-        const int i = A.tk_members[(size_t)base + k];
-        float4 q;
+    constexpr int U = 4;  // four points per thread and step: the dependent gathers and the searches of all four overlap
+    for (int k0 = blockIdx.x * (256 * U); k0 < n_car; k0 += gridDim.x * (256 * U)) {
+        int iv[U], key[U], lo[U], hi[U];
+        float4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) iv[u] = A.tk_members[(size_t)base + min(k0 + u * 256 + (int)threadIdx.x, n_car - 1)];
         if (!from_apri) {  // the point itself is read through apri_src (cloud_use[i] = input point apri_src[i])
-            q = A.pts[base + A.apri_src[(size_t)base + i]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) iv[u] = A.apri_src[(size_t)base + iv[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[u] = A.pts[base + iv[u]];
         } else {  // apri_vec supplied by the caller (no input cloud on the device)
-            const scvod_apri& a = A.apri[(size_t)base + i];
-            q = make_float4(a.x, a.y, a.z, a.intensity);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const scvod_apri& a = A.apri[(size_t)base + iv[u]];
+                q[u] = make_float4(a.x, a.y, a.z, a.intensity);
+            }
         }
-        // Utility::transformCloud (utility.h:401-404): explicit fp32 dot products, no FMA
-        const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
-        const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
-        const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
-        Apri a;
-        apri_of_point(P.bin, x, y, z, q.w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
-        const int key = a.voxel_idx;
-        int lo = 0, hi = ns;  // first sample > key
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (skeys[mid] <= key)
-                lo = mid + 1;
-            else
-                hi = mid;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // Utility::transformCloud (utility.h:401-404): explicit fp32 dot products, no FMA
+            const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
+            const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
+            const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
+            Apri a;
+            apri_of_point(P.bin, x, y, z, q[u].w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
+            key[u] = a.voxel_idx;
+            lo[u] = 0;  // first sample > key
+            hi[u] = ns;
         }
-        int slot = -1;
-        if (lo > 0) {
-            int a0 = (lo - 1) << shift;
-            const int a1 = min(a0 + (1 << shift), N.nv);
-            for (; a0 < a1; ++a0) {
-                const int4 rec = N.tab[a0];
-                if (rec.x >= key) {
-                    if (rec.x == key && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
-                    break;
+        bool more = ns > 0;
+        while (more) {
+            more = false;
+            int sk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) sk[u] = skeys[min((lo[u] + hi[u]) >> 1, ns - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (lo[u] < hi[u]) {
+                    const int mid = (lo[u] + hi[u]) >> 1;
+                    if (sk[u] <= key[u])
+                        lo[u] = mid + 1;
+                    else
+                        hi[u] = mid;
+                    more |= lo[u] < hi[u];
                 }
             }
         }
-        A.tk_hit[(size_t)base + k] = slot;
+        int4 first[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) first[u] = N.tab[min(max(lo[u] - 1, 0) << shift, max(N.nv - 1, 0))];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 256 + (int)threadIdx.x;
+            if (k >= n_car) continue;
+            int slot = -1;
+            if (lo[u] > 0) {
+                int a0 = (lo[u] - 1) << shift;
+                const int a1 = min(a0 + (1 << shift), N.nv);
+                int4 rec = first[u];
+                for (;;) {
+                    if (rec.x >= key[u]) {
+                        if (rec.x == key[u] && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
+                        break;
+                    }
+                    if (++a0 >= a1) break;
+                    rec = N.tab[a0];
+                }
+            }
+            A.tk_hit[(size_t)base + k] = slot;
+        }
     }
 }
 
@@ -376,7 +410,7 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     hipLaunchKernelGGL(k_tk_scatter, g, dim3(256), 0, st, A);
     TH_END("tk_members");
     TH_BEGIN("tk_probe");
-    hipLaunchKernelGGL(k_tk_probe, dim3((A.max_scan_pts + 4095) / 4096, B), dim3(256), 0, st, P, A, J, from_apri);
+    hipLaunchKernelGGL(k_tk_probe, dim3(8, B), dim3(256), 0, st, P, A, J, from_apri);  // (a block stages up to 32 KB of keys: few, long-lived blocks)
     TH_END("tk_probe");
     // LDS words of a wave's bitset: a table holds at most max_scan_pts voxels
     // a wave's bitset covers the successor's voxel table: tables of up to 32 768 voxels (any street scan) take the launch
