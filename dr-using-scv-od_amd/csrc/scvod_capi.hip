@@ -215,7 +215,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.tk_uniq = c->t_uniq;
     A.tk_nuniq = c->t_count;
     A.tk_cursor = c->t_pair;
-    A.tk_mbegin = c->t_begin;
+    A.tk_mbegin = k.take<int32_t>(N + 1);  // (published by the clustering: not shared with the one-shot probe's scratch)
     A.vox_track = k.take<int4>(N);
     A.cl_state = k.take<int8_t>(N);
     A.tk_members = k.take<int32_t>(N);

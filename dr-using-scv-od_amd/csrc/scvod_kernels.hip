@@ -2464,6 +2464,71 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         }
         A.vox_track[(size_t)base + v] = rec;
     }
+    // ---- member lists of the car clusters (what SSC::tracking walks, ssc.cpp:1274-1321): the car roots in ascending order
+    // (tk_clusters), exclusive offsets of their sizes (tk_mbegin at the root), and -- in the per-point pass below -- every
+    // car point appended to its cluster's list (tk_members; the order inside a list is immaterial).  The car components are
+    // few (tens): listed in the LDS the bit arrays released, ranked by counting.
+    __syncthreads();
+    int ncar = 0;
+    for (int c0 = 0; c0 < ncl; c0 += kCcThreads) {
+        const int c = c0 + tid;
+        const uint32_t* r = c < kCcBoxes ? bb + 7 * c : ov + 7 * (size_t)(c - kCcBoxes);
+        ncar += __syncthreads_count(c < ncl && r[0] == 2u);
+    }
+    const int carcap = slots_lds ? (3 * kSlotWords) / 4 : 0;
+    const bool car_lds = ncar <= carcap;  // four lists of ncar entries; arena scratch (dead by now) when they are many
+    int* carname = car_lds ? vstart : A.tk_uniq + base;
+    int* carcid = car_lds ? carname + ncar : A.cc_parent + base;
+    int* scnt = car_lds ? carcid + ncar : A.tk_hit + base;
+    int* scid = car_lds ? scnt + ncar : A.tk_npairs + base;
+    {
+        int run = 0;
+        for (int c0 = 0; c0 < ncl; c0 += kCcThreads) {
+            const int c = c0 + tid;
+            const uint32_t* r = c < kCcBoxes ? bb + 7 * c : ov + 7 * (size_t)(c - kCcBoxes);
+            const bool car = c < ncl && r[0] == 2u;
+            int total;
+            const int ex = block_excl_scan<kCcThreads>(car ? 1 : 0, total, wsum);
+            if (car) {
+                carname[run + ex] = names[c];
+                carcid[run + ex] = c;
+            }
+            run += total;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < ncar; j += kCcThreads) {
+        const int mine = carname[j], cid = carcid[j];
+        int rank = 0;
+        for (int i = 0; i < ncar; ++i) rank += carname[i] < mine ? 1 : 0;
+        const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+        scnt[rank] = (int)r[6];
+        scid[rank] = cid;
+        A.tk_clusters[(size_t)base + rank] = mine;
+    }
+    __syncthreads();
+    {
+        int run = 0;
+        for (int j0 = 0; j0 < ncar; j0 += kCcThreads) {
+            const int j = j0 + tid;
+            const int cnt = j < ncar ? scnt[j] : 0;
+            int total;
+            const int ex = block_excl_scan<kCcThreads>(cnt, total, wsum);
+            if (j < ncar) {
+                const int cid = scid[j];
+                uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+                r[2] = (uint32_t)(run + ex);  // where the cluster's member list starts
+                r[3] = 0u;                    // its cursor
+                A.tk_mbegin[(size_t)base + names[cid]] = run + ex;
+            }
+            run += total;
+        }
+        if (tid == 0) {
+            A.tk_scan[s * 4 + 0] = ncar;
+            A.tk_scan[s * 4 + 1] = run;
+        }
+    }
+    __syncthreads();
     CC_MARK(8);
     for (int i0 = 0; i0 < n; i0 += kCcThreads * 4) {
         int cv[4];
@@ -2476,8 +2541,11 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         for (int u = 0; u < 4; ++u) {
             const int cid = cv[u];
             if (cid < 0) continue;
-            const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
-            A.pt_type[(size_t)base + i0 + u * kCcThreads + tid] = (uint8_t)r[0];
+            uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
+            const uint32_t t = r[0];
+            const int i = i0 + u * kCcThreads + tid;
+            A.pt_type[(size_t)base + i] = (uint8_t)t;
+            if (t == 2u) A.tk_members[(size_t)base + r[2] + atomicAdd(&r[3], 1u)] = i;
         }
     }
     CC_MARK(9);
@@ -2491,7 +2559,10 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
     const int nv = A.counts[s * 8 + 6];
-    if (n <= 0) return;
+    if (n <= 0) {
+        if (threadIdx.x < 2) A.tk_scan[s * 4 + threadIdx.x] = 0;  // no car clusters, no car points
+        return;
+    }
     if (n <= kCcSlots && nv <= kCcNodes && (long long)P.bin.range_num * P.bin.sector_num * P.bin.azimuth_num < 0x7fffffffLL) {
         if (cc_scan_impl<true>(P, A, from_apri, wsum, n_extra_s, s, base, n, nv)) return;
         __syncthreads();

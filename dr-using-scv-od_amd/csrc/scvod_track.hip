@@ -70,76 +70,12 @@ __global__ __launch_bounds__(256) void k_tk_init(Arena A, int phase) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
-    if (phase == 2 && blockIdx.x == 0 && threadIdx.x < 4) A.tk_scan[s * 4 + threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 2) A.tk_scan[s * 4 + 2 + threadIdx.x] = 0;  // ([0], [1]: the car lists, written by k_cc_scan)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         if (A.pt_cluster[(size_t)base + i] != i) continue;
-        A.tk_cursor[(size_t)base + i] = 0;
         A.cl_state[(size_t)base + i] = -1;
         A.tk_npairs[(size_t)base + i] = 0;
         A.tk_nuniq[(size_t)base + i] = 0;
-    }
-}
-
-// one workgroup per scan: offsets of the member lists of its car clusters (exclusive scan of the cluster sizes over
-// the roots in ascending order) and the list of those roots
-__global__ __launch_bounds__(1024) void k_tk_members(Arena A) {
-    __shared__ int wsum[17];
-    const int s = blockIdx.x;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    int run_p = 0, run_c = 0;
-    constexpr int U = 4;  // four consecutive points per thread: a quarter of the block scans, loads in flight together
-    for (int c0 = 0; c0 < n; c0 += 1024 * U) {
-        const int i0 = c0 + threadIdx.x * U;
-        int root[U], cnt[U];
-        bool isr[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u;
-            isr[u] = (i < n) && A.pt_cluster[(size_t)base + i] == i && A.pt_type[(size_t)base + i] == 2;
-        }
-        int sp = 0, sc = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cnt[u] = isr[u] ? A.cl_count[(size_t)base + i0 + u] : 0;
-            sp += cnt[u];
-            sc += isr[u] ? 1 : 0;
-        }
-        int tp, tc;
-        int ep = block_excl_scan<1024>(sp, tp, wsum);
-        int ec = block_excl_scan<1024>(sc, tc, wsum);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (isr[u]) {
-                A.tk_mbegin[(size_t)base + i0 + u] = run_p + ep;
-                A.tk_clusters[(size_t)base + run_c + ec] = i0 + u;
-                ep += cnt[u];
-                ++ec;
-            }
-        }
-        run_p += tp;
-        run_c += tc;
-    }
-    if (threadIdx.x == 0) {
-        A.tk_scan[s * 4 + 0] = run_c;
-        A.tk_scan[s * 4 + 1] = run_p;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_tk_scatter(Arena A) {
-    const int s = blockIdx.y;
-    const int base = A.scan_off[s];
-    const int n = A.counts[s * 8 + 4];
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        int r = -1;
-        if (i < n && A.pt_type[(size_t)base + i] == 2) r = A.pt_cluster[(size_t)base + i];
-        int leader, rank, count;
-        wave_group(r, leader, rank, count);
-        int old = 0;
-        if (r >= 0 && rank == 0) old = atomicAdd(&A.tk_cursor[(size_t)base + r], count);
-        old = __shfl(old, leader);
-        if (r >= 0) A.tk_members[(size_t)base + A.tk_mbegin[(size_t)base + r] + old + rank] = i;
     }
 }
 
@@ -404,11 +340,9 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     if (B <= 0 || A.max_scan_pts <= 0) return;
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
     if (!(phases & 2)) return;  // (phase 1, the successor tables, is written by k_cc_scan with the clustering itself)
-    TH_BEGIN("tk_members");
+    TH_BEGIN("tk_init");  // (the member lists of the car clusters are written by k_cc_scan with the clustering itself)
     hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A, 2);
-    hipLaunchKernelGGL(k_tk_members, dim3(B), dim3(1024), 0, st, A);
-    hipLaunchKernelGGL(k_tk_scatter, g, dim3(256), 0, st, A);
-    TH_END("tk_members");
+    TH_END("tk_init");
     TH_BEGIN("tk_probe");
     hipLaunchKernelGGL(k_tk_probe, dim3(8, B), dim3(256), 0, st, P, A, J, from_apri);  // (a block stages up to 32 KB of keys: few, long-lived blocks)
     TH_END("tk_probe");
