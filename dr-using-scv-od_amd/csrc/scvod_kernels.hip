@@ -28,6 +28,32 @@
 
 namespace scvod {
 
+// development build only (make prof, tools/kernel_phases.py): phase clocks inside the list-driven kernels.  Thread 0 of a workgroup
+// adds the 100 MHz wall clock between two marks (behind a barrier) to g_prof[kernel][phase]; never in the shipped library.
+#ifdef SCVOD_PROFILE
+__device__ unsigned long long g_prof[8][16];
+#define PROF_BEGIN() unsigned long long t_prev = wall_clock64()
+#define PROF_RESET()                                   \
+    do {                                               \
+        __syncthreads();                               \
+        if (threadIdx.x == 0) t_prev = wall_clock64(); \
+    } while (0)
+#define PROF_MARK(k, i)                                      \
+    do {                                                     \
+        __syncthreads();                                     \
+        if (threadIdx.x == 0) {                              \
+            const unsigned long long t_now = wall_clock64(); \
+            atomicAdd(&g_prof[k][i], t_now - t_prev);        \
+            t_prev = t_now;                                  \
+        }                                                    \
+    } while (0)
+#else
+#define PROF_BEGIN()
+#define PROF_RESET()
+#define PROF_MARK(k, i)
+#endif
+#define CC_MARK(i) PROF_MARK(0, i)
+
 // Normalised bitonic network (every comparator puts the minimum at the lower index), valid for any n:
 // indices >= n act as +inf (all-ones key) and are never read or written.  Works on LDS or global (flat)
 // storage.  Register blocking: runs of 8 are sorted in registers (19-comparator network = stages
@@ -255,35 +281,59 @@ __device__ __forceinline__ void bitonic_pass(T* a, int np2, int k, int r) {
     __syncthreads();
 }
 
+// stages k = 2 .. E of the network on a run of E elements held in registers; directions inside the run are compile-time,
+// the direction of the whole run (bit E of its base b) is applied by storing it reversed
+template <bool PAD, int LGE, typename T>
+__device__ __forceinline__ void bitonic_run_to_lds(T (&e)[1 << LGE], T* a, int b) {
+    constexpr int E = 1 << LGE;
+#pragma unroll
+    for (int kk = 2; kk <= E; kk <<= 1) {
+#pragma unroll
+        for (int d = kk >> 1; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int m = 0; m < E; ++m)
+                if ((m & d) == 0) {
+                    if (kk == E || (m & kk) == 0)
+                        cswap_asc(e[m], e[m + d]);
+                    else
+                        cswap_asc(e[m + d], e[m]);
+                }
+        }
+    }
+    const int rev = ((b & E) == 0) ? 0 : (E - 1);
+#pragma unroll
+    for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + (m ^ rev))] = e[m];
+}
+
+template <int THREADS, bool PAD, int LGE, typename T>
+__device__ __forceinline__ void block_bitonic_merge_stages(T* a, int np2);
+
 template <int THREADS, bool PAD, int LGE, typename T>
 __device__ __forceinline__ void block_bitonic_sort_pow2(T* a, int np2) {  // np2 >= 2^LGE, power of two
     constexpr int E = 1 << LGE;
-    // stages k = 2 .. E inside registers: runs of E; directions inside the run are compile-time, the direction
-    // of the whole run (bit E of its base) is applied by storing it reversed
     for (int g = threadIdx.x; g < (np2 >> LGE); g += THREADS) {
         const int b = g << LGE;
         T e[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) e[m] = a[sort_slot<PAD>(b + m)];
-#pragma unroll
-        for (int kk = 2; kk <= E; kk <<= 1) {
-#pragma unroll
-            for (int d = kk >> 1; d >= 1; d >>= 1) {
-#pragma unroll
-                for (int m = 0; m < E; ++m)
-                    if ((m & d) == 0) {
-                        if (kk == E || (m & kk) == 0)
-                            cswap_asc(e[m], e[m + d]);
-                        else
-                            cswap_asc(e[m + d], e[m]);
-                    }
-            }
-        }
-        const int rev = ((b & E) == 0) ? 0 : (E - 1);
-#pragma unroll
-        for (int m = 0; m < E; ++m) a[sort_slot<PAD>(b + (m ^ rev))] = e[m];
+        bitonic_run_to_lds<PAD, LGE>(e, a, b);
     }
     __syncthreads();
+    block_bitonic_merge_stages<THREADS, PAD, LGE>(a, np2);
+}
+
+// the same sort for np2 == THREADS << LGE unsorted keys that arrive in registers (e[it] = the thread's it-th coalesced load):
+// which key starts in which slot is immaterial, so thread t's loads ARE run t -- no staging pass through LDS
+template <int THREADS, bool PAD, int LGE, typename T>
+__device__ __forceinline__ void block_bitonic_sort_pow2_regs(T (&e)[1 << LGE], T* a) {
+    bitonic_run_to_lds<PAD, LGE>(e, a, (int)threadIdx.x << LGE);
+    __syncthreads();
+    block_bitonic_merge_stages<THREADS, PAD, LGE>(a, THREADS << LGE);
+}
+
+template <int THREADS, bool PAD, int LGE, typename T>
+__device__ __forceinline__ void block_bitonic_merge_stages(T* a, int np2) {
+    constexpr int E = 1 << LGE;
     int lgk = LGE + 1;
     for (int k = 2 * E; k <= np2; k <<= 1, ++lgk) {
         int r = lgk;  // levels still to do in this stage (distances 2^(r-1) .. 1)
@@ -422,19 +472,42 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int lo, hi;
     order_range(A.order_off, C_LO, C_HI, lo, hi);
+    constexpr int PK = (CAP == 4096) ? 1 : 2;  // (profiling build: the two large tiers are clocked)
+    PROF_BEGIN();
     for (int w = lo + blockIdx.x; w < hi; w += gridDim.x) {
         const int4 item = A.order[w];
         const int n = item.y, base = item.z, off = item.w;
         const bool in_lds = (n <= CAP);
         unsigned long long* keys;
+        if (CAP >= 4096) PROF_RESET();
         if (in_lds) {
             keys = (unsigned long long*)smem;
             int np2 = 1 << LGE;
             while (np2 < n) np2 <<= 1;
-            for (int j = threadIdx.x; j < np2; j += THREADS)
-                keys[sort_slot<true>(j)] = (j < n) ? A.keys[(size_t)base + off + j] : kKeyPad;
-            __syncthreads();
-            block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
+            // a full tier: all of a thread's key loads in flight together (coalesced), sorted straight from the registers
+            constexpr int IT = CAP / THREADS;
+            const unsigned long long* gk = (const unsigned long long*)A.keys + (size_t)base + off;
+            bool from_regs = false;
+            if constexpr (IT == (1 << LGE) && CAP >= 4096) {  // (the small tiers are occupancy-bound: they keep their registers)
+                if (np2 == CAP) {
+                    from_regs = true;
+                    unsigned long long tmp[IT];
+#pragma unroll
+                    for (int it = 0; it < IT; ++it) {
+                        const int j = it * THREADS + (int)threadIdx.x;
+                        tmp[it] = (j < n) ? gk[j] : kKeyPad;
+                    }
+                    if (CAP >= 4096) PROF_MARK(PK, 0);
+                    block_bitonic_sort_pow2_regs<THREADS, true, LGE>(tmp, keys);
+                }
+            }
+            if (!from_regs) {
+                for (int j = threadIdx.x; j < np2; j += THREADS) keys[sort_slot<true>(j)] = (j < n) ? gk[j] : kKeyPad;
+                __syncthreads();
+                if (CAP >= 4096) PROF_MARK(PK, 0);
+                block_bitonic_sort_pow2<THREADS, true, LGE>(keys, np2);
+            }
+            if (CAP >= 4096) PROF_MARK(PK, 1);
         } else {
             keys = (unsigned long long*)(A.keys + (size_t)base + off);  // oversize patch: sort in place in global memory
             block_bitonic_sort<THREADS, false>(keys, n);
@@ -466,6 +539,7 @@ __global__ __launch_bounds__(THREADS) void k_pw_sort(DevParams P, Arena A) {
             }
         }
         __syncthreads();  // LDS is reused by the next item
+        if (CAP >= 4096) PROF_MARK(PK, 2);
     }
 }
 
@@ -1688,7 +1762,10 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     int* wsum = (int*)(smem + (size_t)SLOTS * 8 + (size_t)CAP * 8);
     int lo, hi;
     order_range(A.vorder_off, C_LO, C_HI, lo, hi);
+    constexpr bool PV = (CAP == 4096 && MODE == 0);  // (profiling build: the dominant tier is clocked)
+    PROF_BEGIN();
     for (int w = lo + blockIdx.x; w < hi; w += gridDim.x) {
+    if (PV) PROF_RESET();
     const int4 item = A.vorder[w];
     const int code = item.x;
     const int s = code / kMaxBuckets, b = code - s * kMaxBuckets;
@@ -1710,12 +1787,32 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
     if (in_lds) {
         int np2 = 1 << LGE;
         while (np2 < m) np2 <<= 1;
-        for (int j = threadIdx.x; j < np2; j += THREADS) l_keys[sort_slot<PADK>(j)] = (j < m) ? gkeys[j] : kpad;
-        __syncthreads();
+        // a full tier: all of a thread's key loads in flight together (coalesced), sorted straight from the registers
+        constexpr int IT = CAP / THREADS;
         keys = l_keys;
         vbeg = l_vbeg;
         ints = l_int;
-        block_bitonic_sort_pow2<THREADS, PADK, LGE>(keys, np2);
+        bool from_regs = false;
+        if constexpr (IT == (1 << LGE) && CAP >= 4096) {  // (the small tiers are occupancy-bound: they keep their registers)
+            if (np2 == CAP) {
+                from_regs = true;
+                KT tmp[IT];
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int j = it * THREADS + (int)threadIdx.x;
+                    tmp[it] = (j < m) ? gkeys[j] : kpad;
+                }
+                if (PV) PROF_MARK(3, 0);
+                block_bitonic_sort_pow2_regs<THREADS, PADK, LGE>(tmp, keys);
+            }
+        }
+        if (!from_regs) {
+            for (int j = threadIdx.x; j < np2; j += THREADS) l_keys[sort_slot<PADK>(j)] = (j < m) ? gkeys[j] : kpad;
+            __syncthreads();
+            if (PV) PROF_MARK(3, 0);
+            block_bitonic_sort_pow2<THREADS, PADK, LGE>(keys, np2);
+        }
+        if (PV) PROF_MARK(3, 1);
     } else {
         keys = gkeys;
         vbeg = A.tmp_vox_begin + (size_t)base + off;  // rewritten below with final values
@@ -1742,6 +1839,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         run += th;
     }
     __syncthreads();
+    if (PV) PROF_MARK(3, 2);
     const int nv = run;
     if (MODE == 1) {
         // CentroidPoint (PCL 1.8.1 accumulators.hpp): fp32 running sums of x, y, z, intensity in ascending input index,
@@ -1769,6 +1867,7 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         for (int j = threadIdx.x; j < m; j += THREADS) ints[j] = A.apri_int[(size_t)base + k_idx(keys[KX(j)])];
         __syncthreads();
     }
+    if (PV) PROF_MARK(3, 3);
     // per voxel: sequential fp32 mean, then population variance accumulated as float += double
     for (int v = threadIdx.x; v < nv; v += THREADS) {
         const int j0 = vbeg[v];
@@ -1794,10 +1893,12 @@ __global__ __launch_bounds__(THREADS) void k_vx_bucket(DevParams P, Arena A) {
         A.tmp_vox_av[(size_t)base + off + v] = av;
     }
     __syncthreads();
+    if (PV) PROF_MARK(3, 4);
     // vbeg aliases tmp_vox_begin in the oversize path: every thread rewrites only its own entries
     for (int v = threadIdx.x; v < nv; v += THREADS) A.tmp_vox_begin[(size_t)base + off + v] = off + vbeg[v];
     if (threadIdx.x == 0) A.vb_nvox[s * kMaxBuckets + b] = nv;
     __syncthreads();  // LDS is reused by the next item
+    if (PV) PROF_MARK(3, 5);
     }
 #undef KX
 }
@@ -2052,21 +2153,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-#ifdef SCVOD_CC_PROFILE
-__device__ unsigned long long g_cc_prof[16];
-#define CC_MARK(i)                                                             \
-    do {                                                                       \
-        __syncthreads();                                                       \
-        if (threadIdx.x == 0) {                                                \
-            const unsigned long long t_now = wall_clock64();                   \
-            atomicAdd(&g_cc_prof[i], t_now - t_prev);                          \
-            t_prev = t_now;                                                    \
-        }                                                                      \
-    } while (0)
-#else
-#define CC_MARK(i)
-#endif
-
 // FAST: every table of the scan in LDS, the pointers are LDS pointers at compile time (ds_* instead of flat_* accesses);
 // gives up (returns false, nothing published yet) when the extra runs push the node count over kCcNodes.  The generic
 // variant picks LDS or arena scratch per table at run time.
@@ -2074,9 +2160,7 @@ extern __shared__ int cc_smem[];
 template <bool FAST>
 __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A, int from_apri, int* wsum, int& n_extra_s, int s, int base, int n,
                                              int nv) {
-#ifdef SCVOD_CC_PROFILE
-    unsigned long long t_prev = wall_clock64();
-#endif
+    PROF_BEGIN();
     const int tid = threadIdx.x;
     const int32_t* vbeg = A.vox_pt_begin + base + s;
     const int32_t* vpts = A.vox_pts + base;
@@ -3255,12 +3339,12 @@ void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t 
 
 }  // namespace scvod
 
-#ifdef SCVOD_CC_PROFILE
-// development build only (make prof): summed phase clocks of k_cc_scan, 100 MHz ticks; reading resets them
-extern "C" int scvod_debug_cc_profile(unsigned long long* out16) {
+#ifdef SCVOD_PROFILE
+// development build only (make prof): the summed phase clocks, 100 MHz ticks, [8 kernels][16 phases]; reading resets them
+extern "C" int scvod_debug_profile(unsigned long long* out128) {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(scvod::g_cc_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    unsigned long long z[16] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(scvod::g_cc_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    if (hipMemcpyFromSymbol(out128, HIP_SYMBOL(scvod::g_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    unsigned long long z[128] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(scvod::g_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
