@@ -96,23 +96,42 @@ __device__ __forceinline__ bool map_encode(float x, float y, float z, float inte
     return true;
 }
 
-__device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mask, unsigned long long key, unsigned long long val) {
-    unsigned long long h = map_mix(key) & mask;
+// One 16-byte load per probe (key and value together).  The load is an ordinary cached one: a key, once set, never changes
+// and a value only decreases, so a stale record can only show (a) an empty slot that is taken by now -- the CAS then returns
+// the owner -- or (b) a value above the current one -- the atomicMin then runs although it was not needed.  Both are harmless.
+__device__ __forceinline__ MapRec map_peek(const MapRec* table, unsigned long long h) {
+    const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(&table[h]);
+    MapRec m;
+    m.key = r.x;
+    m.val = r.y;
+    return m;
+}
+// `first` = map_peek(table, h0) with h0 = map_mix(key) & mask (the caller issued it early, several probes in flight)
+__device__ __forceinline__ bool map_insert_from(MapRec* table, unsigned long long mask, unsigned long long key, unsigned long long val,
+                                                unsigned long long h, MapRec rec) {
     // a table that is (nearly) full is an error the caller hears about at export time, not a reason to walk 2^n slots
     for (int probes = 0; probes < kMapMaxProbes; ++probes) {
-        unsigned long long k = __hip_atomic_load(&table[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long k = rec.key;
         if (k == kEmpty) {
             k = atomicCAS(&table[h].key, kEmpty, key);
-            if (k == kEmpty) k = key;
+            if (k == kEmpty) {
+                k = key;
+                rec.val = kEmpty;  // a fresh record
+            }
         }
         if (k == key) {
             // most points find a cell an earlier scan opened and a value that already beats theirs: test before the atomic
-            if (val < __hip_atomic_load(&table[h].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&table[h].val, val);
+            if (val < rec.val) atomicMin(&table[h].val, val);
             return true;
         }
         h = (h + 1) & mask;
+        rec = map_peek(table, h);
     }
     return false;
+}
+__device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mask, unsigned long long key, unsigned long long val) {
+    const unsigned long long h = map_mix(key) & mask;
+    return map_insert_from(table, mask, key, val, h, map_peek(table, h));
 }
 
 // static points of scan blockIdx.y: cloud_out (ground), cloud_eva_static (range/FOV rejects) and the apri points that are
@@ -132,45 +151,66 @@ __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = pose[12 * s + i];
     int dropped = 0;
-    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        unsigned long long key = kEmpty, val = kEmpty;
-        if (i < n) {
-            // in a cloud at all?  Patchwork drops the points outside its range gate / below the z cut (pid < 0) and whole
-            // patches of at most num_min_pts points (patchwork.h:331); a batch binned without Patchwork keeps every point
-            bool keep = true;
-            if (have_pid) {
-                const int pid = A.pid[(size_t)base + i];
-                keep = pid >= 0 && A.patch_count[s * kMaxPatches + pid] > min_pts;
-            }
-            if (keep && marks) {
-                const uint8_t c = A.pt_mapcls[(size_t)base + i];
-                keep = !((c & kMapDynamic) && have_dyn) && !((c & kMapGround) && !with_ground) && !((c & kMapRejected) && !with_rejected);
-            }
-            if (keep) {
-                const float4 q = A.pts[base + i];
-                const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
-                const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
-                const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
-                if (!map_encode(x, y, z, q.w, inv_leaf, key, val)) {
-                    ++dropped;
-                    key = kEmpty;
+    constexpr int U = 4;  // four points per thread and step: their loads, then their first probes, are in flight together
+    for (int i0 = blockIdx.x * (256 * U); i0 < n; i0 += gridDim.x * (256 * U)) {
+        int pid[U], pcnt[U];
+        uint8_t cls[U];
+        float4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * 256 + (int)threadIdx.x, n - 1);
+            pid[u] = have_pid ? (int)A.pid[(size_t)base + i] : 0;
+            cls[u] = marks ? A.pt_mapcls[(size_t)base + i] : (uint8_t)0;
+            q[u] = A.pts[base + i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pcnt[u] = have_pid ? A.patch_count[s * kMaxPatches + max(pid[u], 0)] : 0;
+        unsigned long long key[U], val[U], h[U];
+        bool need[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256 + (int)threadIdx.x;
+            key[u] = kEmpty;
+            val[u] = kEmpty;
+            if (i < n) {
+                // in a cloud at all?  Patchwork drops the points outside its range gate / below the z cut (pid < 0) and whole
+                // patches of at most num_min_pts points (patchwork.h:331); a batch binned without Patchwork keeps every point
+                bool keep = !have_pid || (pid[u] >= 0 && pcnt[u] > min_pts);
+                if (keep && marks) {
+                    const uint8_t c = cls[u];
+                    keep = !((c & kMapDynamic) && have_dyn) && !((c & kMapGround) && !with_ground) && !((c & kMapRejected) && !with_rejected);
+                }
+                if (keep) {
+                    const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
+                    const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
+                    const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
+                    if (!map_encode(x, y, z, q[u].w, inv_leaf, key[u], val[u])) {
+                        ++dropped;
+                        key[u] = kEmpty;
+                    }
                 }
             }
-        }
-        // runs of equal keys among consecutive lanes: the head of a run takes the smallest value of the run
-        const unsigned long long prev = __shfl_up(key, 1);
-        const bool head = (lane == 0) || (prev != key);
-        const unsigned long long heads = __ballot(head);
-        // end of my run = position of the next head after my lane (exclusive), 64 if none
-        const unsigned long long after = heads & ~((2ull << lane) - 1ull);
-        const int run_end = after ? (__ffsll((long long)after) - 1) : 64;
+            // runs of equal keys among consecutive lanes: the head of a run takes the smallest value of the run
+            const unsigned long long prev = __shfl_up(key[u], 1);
+            const bool head = (lane == 0) || (prev != key[u]);
+            const unsigned long long heads = __ballot(head);
+            // end of my run = position of the next head after my lane (exclusive), 64 if none
+            const unsigned long long after = heads & ~((2ull << lane) - 1ull);
+            const int run_end = after ? (__ffsll((long long)after) - 1) : 64;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = __shfl_down(val, d);
-            if (lane + d < run_end && o < val) val = o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long o = __shfl_down(val[u], d);
+                if (lane + d < run_end && o < val[u]) val[u] = o;
+            }
+            need[u] = head && key[u] != kEmpty;
+            h[u] = map_mix(key[u]) & mask;
         }
-        if (head && key != kEmpty && !map_insert(table, mask, key, val)) ++dropped;
+        MapRec first[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) first[u] = map_peek(table, need[u] ? h[u] : 0ull);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (need[u] && !map_insert_from(table, mask, key[u], val[u], h[u], first[u])) ++dropped;
     }
     if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
 }
@@ -382,7 +422,7 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
             if (!track_valid) MHIP(m, hipMemsetAsync(A.pt_mapcls, 0, (size_t)A.total_pts, st));  // (tracking clears the marks itself)
             hipLaunchKernelGGL(k_map_mark_lists, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A);
         }
-        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 1023) / 1024, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
                            (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, mode == 1 ? 1 : 0, min_pts, (use_dyn || need_lists) ? 1 : 0, m->counters);
         MHIP(m, hipGetLastError());
