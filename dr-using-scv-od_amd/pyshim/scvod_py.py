@@ -87,7 +87,7 @@ def load_lib():
         import torch  # noqa: F401  (must come first: one libamdhip64 per process)
     except Exception:
         pass
-    path = os.path.abspath(LIB_PATH)
+    path = os.path.abspath(os.environ.get("SCVOD_LIB", LIB_PATH))  # (SCVOD_LIB: a development build, e.g. libscvod_prof.so)
     if not os.path.exists(path):
         # the library is a build product (git-ignored): compile it in-tree when a hipcc is around
         import shutil
