@@ -528,6 +528,26 @@ def test_cluster_partition_with_irregular_nodes(scvod, oracle, kind, preset, seq
     ctx.close()
 
 
+def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
+    """more apri points than the generic variant's LDS bit arrays hold (262 144): start bits / prefixes in arena scratch,
+    keys and parents in HBM; a few irregular returns among them"""
+    rng = np.random.default_rng(3)
+    n = 330000
+    r, th = rng.uniform(2, 29, n), rng.uniform(0, 2 * np.pi, n)
+    x = np.stack([r * np.cos(th), r * np.sin(th), rng.uniform(-1.2, 6, n), rng.uniform(0, 255, n)], 1).astype(np.float32)
+    x[:40, 1] = 0.0
+    x[:40, 0] = np.abs(x[:40, 0]) + 2.0
+    P = _params(scvod, "os128_fine")
+    apri = oracle.bin(P, x, True)["apri"]
+    assert len(apri) > 262144 and (apri["sector_idx"] < 0).any()
+    ctx = scvod.Ctx(P, max_points_total=len(apri) + 64, max_scans=1)
+    got = ctx.cluster(apri)
+    ref, n_ref, _ = oracle.cluster(P, apri)
+    assert np.array_equal(got, _canonical(ref))
+    assert len(np.unique(got)) == n_ref
+    ctx.close()
+
+
 def test_cluster_partition_on_a_fine_grid(scvod, oracle):
     """more voxels than the clustering kernel's LDS key table holds: neighbourhood searches in global memory"""
     import synth
