@@ -39,4 +39,9 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
     > /dev/null 2> "$out/rocprof_sq.err"
 f=$(find $d -name '*counter_collection.csv' | head -1)
 [ -n "$f" ] && (head -1 "$f"; grep scvod "$f") > "$out/SQ_counter_collection.csv"
+# 5. phase clocks inside k_cc_scan and the large sort tiers (development build of the library: make -C dr-using-scv-od_amd/csrc prof)
+if [ -f "$R/dr-using-scv-od_amd/csrc/libscvod_prof.so" ]; then
+    (timeout 200 python "$R/tools/kernel_phases.py" --scans 512; timeout 200 python "$R/tools/kernel_phases.py" --kind OS128 --preset os128_fine --scans 128;
+     timeout 200 python "$R/tools/kernel_phases.py" --kind PARK --preset parkinglot --scans 512) > "$out/kernel_phases.txt" 2> "$out/kernel_phases.err"
+fi
 ls -la "$out"

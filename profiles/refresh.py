@@ -49,8 +49,7 @@ def load(path):
 
 LABELS = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_emit_offsets": "emit_offsets",
           "k_emit": "emit", "k_vx_count": "vx_count", "k_vx_offsets": "vx_offsets", "k_vx_scatter": "vx_scatter", "k_vx_final_offsets": "vx_final_offsets",
-          "k_vx_final": "vx_final", "k_pw_sort_wave": "pw_sort_wave", "k_cc_scan": "cc_scan", "k_tk_init": "tk_labels", "k_tk_voxlabel": "tk_labels",
-          "k_tk_voxfill": "tk_labels", "k_tk_members": "tk_members", "k_tk_scatter": "tk_members", "k_tk_probe": "tk_probe", "k_tk_dyn": "tk_dyn",
+          "k_vx_final": "vx_final", "k_pw_sort_wave": "pw_sort_wave", "k_cc_scan": "cc_scan", "k_tk_init": "tk_init", "k_tk_probe": "tk_probe", "k_tk_dyn": "tk_dyn",
           "k_map_accumulate": "map_accumulate"}
 
 
@@ -66,7 +65,6 @@ def label(k):
     return k
 
 
-# k_tk_init runs twice per step (once per phase) and shares its label with two other kernels: sum per label
 scans = 512
 F, W = load(os.path.join(src, "FETCH_SIZE_counter_collection.csv")), load(os.path.join(src, "WRITE_SIZE_counter_collection.csv"))
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --scans 512 --steps 1 --warmup 0 --no-cpu --no-extras; raw values are "
@@ -107,6 +105,11 @@ if os.path.exists(p):
         for r in sorted(rows, reverse=True):
             f.write(f"{r[1][:44]:44s} {r[2]:10.0f} {r[3]:7.3f} {r[4]:7.3f} {r[5]:7.3f} {r[6]:7.3f} {r[7]:7.3f} {r[8]:9.3f}\n")
 
+p = os.path.join(src, "kernel_phases.txt")
+if os.path.exists(p):
+    open(os.path.join(here, f"{tag}_kernel_phases.txt"), "w").write(
+        "tools/kernel_phases.py on the profiling build (make -C dr-using-scv-od_amd/csrc prof): 100 MHz wall clock between phase marks, thread 0 of every\n"
+        "workgroup behind a barrier, summed over the workgroups of a kernel and divided by the scans\n\n" + open(p).read())
 d = last_json(os.path.join(src, "bench_full.json"))
 print("scans/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "roofline frac", round(d["roofline"]["frac"], 4))
 print("cpu", d["cpu_baseline"] and d["cpu_baseline"]["value"], "quality", d.get("quality") and {k: d["quality"][k] for k in ("delta_PR", "delta_RR")})
