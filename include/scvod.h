@@ -291,9 +291,10 @@ typedef struct scvod_track_result {
 } scvod_track_result;
 int scvod_batch_fetch_track(scvod_ctx* ctx, int32_t s, scvod_track_result* out);
 
-/* First half of scvod_batch_track on its own: Voxel::label, cluster sizes and types of every scan (the table its
- * predecessor is tracked against).  A sharded sequence calls this, exports the tables of its blocks' first scans, exchanges
- * them, and then calls scvod_batch_track (which does not repeat the work).  Asynchronous on `stream`. */
+/* Publishes the successor tables of the batch: Voxel::label, cluster sizes and types of every scan (the table its
+ * predecessor is tracked against; the clustering kernel writes them together with the clusters, this call checks that the
+ * clustering and the box rules of the batch are current).  A sharded sequence calls this, exports the tables of its blocks'
+ * first scans, exchanges them, and then calls scvod_batch_track.  Asynchronous on `stream`. */
 int scvod_batch_track_tables(scvod_ctx* ctx, void* stream);
 
 /* Boundary message of a sequence shard: writes 1 + n_voxels records of 16 bytes into d_out (device memory, capacity
