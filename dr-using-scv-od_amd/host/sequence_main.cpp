@@ -62,6 +62,14 @@ int main(int argc, char** argv) {
             for (auto& q : p.pose_vec) std::cout << q.x << " " << q.y << " " << q.z << " " << q.roll << " " << q.pitch << " " << q.yaw << "\n";
             return 0;
         }
+        if (argc >= 6 && std::strcmp(argv[1], "--pcd-copy") == 0) {  // loadCloud + saveCloud, no device: <in.pcd> <out_root> <id> <name>
+            Utility u;
+            pcl::PointCloud<pcl::PointXYZI>::Ptr c(new pcl::PointCloud<pcl::PointXYZI>());
+            u.loadCloud(c, argv[2]);
+            u.saveCloud(c, argv[3], std::atoi(argv[4]), argv[5]);
+            std::cout << "points " << c->points.size() << "\n";
+            return 0;
+        }
         if (argc < 3) {
             std::cerr << "usage: scvod_sequence <config.yaml> <out_dir> [--data DIR] [--labels DIR] [--poses FILE] [--start S] [--end E] [--skip K]\n";
             return 2;
@@ -86,6 +94,13 @@ int main(int argc, char** argv) {
                     ++dyn;
                     for (int p : c.occupy_pts) o.write((const char*)&ssc.frame_set[i].cloud_use->points[p], 16);
                 }
+            }
+            if (ssc.save && dyn) {  // the removed points of the frame as a .pcd (Utility::saveCloud, utility.h:408-419)
+                pcl::PointCloud<pcl::PointXYZI>::Ptr removed(new pcl::PointCloud<pcl::PointXYZI>());
+                for (auto& kv : ssc.frame_set[i].cluster_set)
+                    if (kv.second.state == 1)
+                        for (int p : kv.second.occupy_pts) removed->push_back(ssc.frame_set[i].cloud_use->points[p]);
+                ssc.saveCloud(removed, out + "/", ssc.frame_set[i].id, "_dynamic.pcd");
             }
             dyn_total += dyn;
             std::cout << "frame " << ssc.frame_set[i].id << " points " << ssc.cloud_vec[i]->points.size() << " clusters " << ssc.frame_set[i].cluster_set.size()

@@ -5,6 +5,13 @@
 #ifndef SCVOD_HOST_UTILITY_H_
 #define SCVOD_HOST_UTILITY_H_
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <locale>
+#include <sstream>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -133,6 +140,127 @@ class Utility {
         pose.pitch = rpy[1];
         pose.yaw = rpy[2];
         return true;
+    }
+
+    // Utility::saveCloud / loadCloud (utility.h:408-428): <path_><id><name_> as an ASCII .pcd the way pcl::io::savePCDFile writes
+    // it (PCDWriter::writeASCII of PCL 1.8: the eleven header lines, eight significant digits in the classic locale, "nan"
+    // for NaN); the reader takes ASCII and binary files with x y z and, when present, intensity fields.
+    static std::string pcdFloat(float v) {
+        if (v != v) return "nan";
+        std::ostringstream o;
+        o.imbue(std::locale::classic());
+        o.precision(8);
+        o << v;
+        return o.str();
+    }
+    static bool writePcdAscii(const std::string& file, const pcl::PointCloud<pcl::PointXYZI>& cloud) {
+        std::ofstream f(file.c_str());
+        if (!f) return false;
+        const size_t n = cloud.points.size();
+        f << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+          << "WIDTH " << n << "\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA ascii\n";
+        for (const auto& p : cloud.points) f << pcdFloat(p.x) << ' ' << pcdFloat(p.y) << ' ' << pcdFloat(p.z) << ' ' << pcdFloat(p.intensity) << '\n';
+        return (bool)f;
+    }
+    static bool readPcd(const std::string& file, pcl::PointCloud<pcl::PointXYZI>& cloud) {
+        std::ifstream f(file.c_str(), std::ios::binary);
+        if (!f) return false;
+        std::vector<std::string> fields;
+        std::vector<int> sizes, counts;
+        std::vector<char> types;
+        size_t points = 0;
+        std::string line, data;
+        while (std::getline(f, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty() || line[0] == '#') continue;
+            std::istringstream ls(line);
+            std::string key;
+            ls >> key;
+            if (key == "FIELDS") {
+                for (std::string t; ls >> t;) fields.push_back(t);
+            } else if (key == "SIZE") {
+                for (int t; ls >> t;) sizes.push_back(t);
+            } else if (key == "TYPE") {
+                for (char t; ls >> t;) types.push_back(t);
+            } else if (key == "COUNT") {
+                for (int t; ls >> t;) counts.push_back(t);
+            } else if (key == "POINTS") {
+                ls >> points;
+            } else if (key == "DATA") {
+                ls >> data;
+                break;
+            }
+        }
+        const size_t nf = fields.size();
+        if (!nf || sizes.size() != nf || types.size() != nf || (data != "ascii" && data != "binary")) return false;
+        if (counts.size() != nf) counts.assign(nf, 1);
+        int at[4] = {-1, -1, -1, -1};  // x y z intensity -> field
+        for (size_t k = 0; k < nf; ++k) {
+            if (fields[k] == "x") at[0] = (int)k;
+            if (fields[k] == "y") at[1] = (int)k;
+            if (fields[k] == "z") at[2] = (int)k;
+            if (fields[k] == "intensity") at[3] = (int)k;
+        }
+        if (at[0] < 0 || at[1] < 0 || at[2] < 0) return false;
+        for (int k = 0; k < 4; ++k)
+            if (at[k] >= 0 && (types[at[k]] != 'F' || sizes[at[k]] != 4 || counts[at[k]] != 1)) return false;
+        cloud.points.assign(points, pcl::PointXYZI());
+        if (data == "ascii") {
+            std::vector<size_t> first(nf);  // index of a field's first token on a line
+            size_t tokens = 0;
+            for (size_t k = 0; k < nf; ++k) {
+                first[k] = tokens;
+                tokens += (size_t)counts[k];
+            }
+            std::vector<std::string> tok(tokens);
+            for (size_t i = 0; i < points; ++i) {
+                if (!std::getline(f, line)) return false;
+                std::istringstream ls(line);
+                for (size_t t = 0; t < tokens; ++t)
+                    if (!(ls >> tok[t])) return false;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 4; ++k)
+                    if (at[k] >= 0) v[k] = std::strtof(tok[first[at[k]]].c_str(), nullptr);
+                cloud.points[i].x = v[0];
+                cloud.points[i].y = v[1];
+                cloud.points[i].z = v[2];
+                cloud.points[i].intensity = v[3];
+            }
+        } else {
+            std::vector<size_t> off(nf);
+            size_t stride = 0;
+            for (size_t k = 0; k < nf; ++k) {
+                off[k] = stride;
+                stride += (size_t)sizes[k] * (size_t)counts[k];
+            }
+            std::vector<char> rec(stride);
+            for (size_t i = 0; i < points; ++i) {
+                if (!f.read(rec.data(), (std::streamsize)stride)) return false;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 4; ++k)
+                    if (at[k] >= 0) std::memcpy(&v[k], rec.data() + off[at[k]], 4);
+                cloud.points[i].x = v[0];
+                cloud.points[i].y = v[1];
+                cloud.points[i].z = v[2];
+                cloud.points[i].intensity = v[3];
+            }
+        }
+        cloud.width = (unsigned)points;
+        cloud.height = 1;
+        return true;
+    }
+    template <typename CloudT>
+    void saveCloud(const CloudT& cloud_, const std::string& path_, const int& id, const std::string& name_) {  // root path
+        const std::string save_path = path_ + std::to_string(id) + name_;
+        cloud_->height = 1;
+        cloud_->width = (unsigned)cloud_->points.size();
+        if (save) {
+            if (cloud_->points.size() == 0 || !writePcdAscii(save_path, *cloud_)) std::fprintf(stderr, "%s save error\n", (std::to_string(id) + name_).c_str());
+        }
+    }
+    template <typename CloudT>
+    void loadCloud(CloudT& cloud_, const std::string& path_) {
+        if (!readPcd(path_, *cloud_)) throw std::runtime_error("pose file " + path_ + " load error");
     }
 
     virtual ~Utility() {}
