@@ -1292,14 +1292,33 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int total = A.order_off[64];
-    for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
-        const int4 item = A.order[w];
+    if ((int)(blockIdx.x * 4 + wave) >= total) return;
+    // the dependent chain list item -> patch record / output offsets -> seg words is software-pipelined ACROSS patches (most
+    // hold a few hundred points): the item two patches ahead and the record + offsets of the next patch are in flight while
+    // the current patch is emitted (clamped, unconditional loads)
+    const int stride = gridDim.x * 4;
+    struct Meta {
+        PatchRec r;
+        int4 o;
+    };
+    auto load_item = [&](int k) -> int4 { return A.order[min(k, total - 1)]; };
+    auto load_meta = [&](const int4& it) -> Meta {
+        Meta m;
+        m.r = A.patch_rec[it.x];  // it.x = scan * kMaxPatches + patch
+        m.o = *reinterpret_cast<const int4*>(A.emit_off + (size_t)it.x * 4);
+        return m;
+    };
+    int w = blockIdx.x * 4 + wave;
+    int4 item = load_item(w), item1 = load_item(w + stride);
+    Meta meta = load_meta(item);
+    for (; w < total; w += stride) {
+        const int4 item2 = load_item(w + 2 * stride);
+        const Meta meta1 = load_meta(item1);
         const int code = item.x;
         const int s = code / kMaxPatches, p = code - s * kMaxPatches;
-        const PatchRec r = A.patch_rec[s * kMaxPatches + p];
+        const PatchRec r = meta.r;
         const int base = item.z, off = item.w;
-        const int* o = A.emit_off + ((size_t)s * kMaxPatches + p) * 4;
-        const int xg = o[0], xng = o[1], xa = o[2], xr = o[3];
+        const int xg = meta.o.x, xng = meta.o.y, xa = meta.o.z, xr = meta.o.w;
         const bool kept = (r.status == 1);
         const uint32_t* seg = A.seg + (size_t)base + off;
         // ground part of a kept patch -> cloud_out
@@ -1357,6 +1376,9 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
             }
             run_keep += nk;
         }
+        item = item1;
+        item1 = item2;
+        meta = meta1;
     }
 }
 
