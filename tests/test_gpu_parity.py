@@ -371,6 +371,60 @@ def test_batch_track_decision_parity(scvod, oracle, kind, preset, seq, first):
     ctx.close()
 
 
+def _post_field(shift, moved, seed=11):
+    """flat ground + ~2700 thin posts (12 points each, a `car` by the box rules) on a polar lattice whose neighbours are two
+    range bins / three sectors apart; `shift` = sensor displacement along x, `moved` = posts displaced by 1 m in y"""
+    rng = np.random.default_rng(seed)
+    g = rng.uniform(-30, 30, (30000, 2))
+    ground = np.concatenate([g, np.full((len(g), 1), -1.73) + rng.normal(0, 0.01, (len(g), 1)), rng.uniform(0, 1, (len(g), 1))], 1)
+    posts = []
+    for r in np.arange(4.0, 27.5, 0.9):
+        step = max(1.3 / r, 3.2 * np.deg2rad(1.2))
+        for a in np.arange(0.05, 2 * np.pi - step, step):
+            posts.append((r * np.cos(a), r * np.sin(a)))
+    posts = np.asarray(posts)
+    posts[moved, 1] += 1.0
+    z = np.linspace(-1.5, -0.7, 12)
+    pp = np.repeat(posts, 12, 0) + rng.normal(0, 0.004, (len(posts) * 12, 2))
+    pts = np.concatenate([pp, np.tile(z, len(posts))[:, None], np.full((len(pp), 1), 0.5)], 1)
+    x = np.concatenate([ground, pts]).astype(np.float32)
+    x[:, 0] -= np.float32(shift)
+    return x, len(posts)
+
+
+def test_batch_track_with_thousands_of_car_clusters(scvod, oracle):
+    """more car clusters per scan than the clustering kernel lists in LDS (1536): roots in ascending order, offsets and member
+    lists from arena scratch; decisions against the oracle"""
+    import torch
+    P = _params(scvod, "semantickitti")
+    n_posts = _post_field(0.0, [])[1]
+    moved = np.arange(0, n_posts, 9)
+    scans = [_post_field(0.0, [])[0], _post_field(0.4, moved)[0], _post_field(0.8, [])[0]]
+    poses = np.zeros((3, 6), np.float32)
+    poses[:, 0] = [0.0, 0.4, 0.8]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=3)
+    d = torch.from_numpy(np.concatenate(scans)).cuda()
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    res = [ctx.batch_fetch(s) for s in range(3)]
+    names = [ctx.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(3)]
+    types = [ctx.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(3)]
+    T = np.zeros((3, 12), np.float32)
+    for s in range(2):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    tr = [ctx.batch_fetch_track(s) for s in range(3)]
+    for s in range(2):
+        assert tr[s]["n_clusters"] > 1536, tr[s]["n_clusters"]
+        o = oracle.track_decide(P, res[s]["apri"], names[s], types[s], res[s + 1]["apri"], names[s + 1], types[s + 1], T[s])
+        _assert_track_equal(tr[s], o)
+        assert tr[s]["n_car_points"] == int((types[s] == 2).sum())
+    assert (tr[0]["cluster_state"] == 1).sum() > 100 and (tr[0]["cluster_state"] == 0).sum() > 1000
+    ctx.close()
+
+
 def test_batch_track_across_a_shard_boundary(scvod, oracle):
     """A sequence cut into two shards: the last scan of shard A is tracked against the table shard B exports for its first
     scan (scvod_batch_export_table -> external table of scvod_batch_track) and must give exactly what the unsplit batch
