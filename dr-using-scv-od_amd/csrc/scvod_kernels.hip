@@ -1977,7 +1977,7 @@ constexpr int kCcBuckets = 8192; // entries of the key-bucket index (uint16 node
 constexpr int kCcSlotsBig = 262144;  // generic variant: the nodes live in HBM, which leaves LDS for the bit arrays of this many points
 
 static_assert(7 * kCcBoxes <= kCcNodes, "box records must fit the released key table");
-constexpr size_t kCcLdsBytes = (size_t)(2 * kCcNodes + 3 * (kCcSlots / 32) + 3 * (kCcNodes / 32) + kCcBuckets / 2 + 64) * 4;
+constexpr size_t kCcLdsBytes = (size_t)(2 * kCcNodes + 3 * (kCcSlots / 32) + 3 * (kCcNodes / 32) + kCcBuckets / 2 + 32) * 4;
 static_assert(kCcLdsBytes <= 160 * 1024, "one workgroup per CU: all of its LDS");
 static_assert((size_t)(kCcNodes + 3 * (kCcSlotsBig / 32)) * 4 <= kCcLdsBytes, "generic layout inside the same LDS");
 
@@ -2102,12 +2102,17 @@ __device__ __forceinline__ void cc_search_canon(const CcKeys<TabT>& K, int* pare
         }
 }
 
-// When EVERY node of the scan is regular (no -1 bins, no extra runs: the usual case, the range / FOV verdict keeps such points
-// out of apri_vec) every voxel touches itself and every neighbour pair is mutual, so a node only looks BACKWARDS in key order
-// (z-major, then range, then sector): its predecessor in the row, the row (z, x-1) and the three rows of plane z-1 -- four
-// lower bounds, taken in lockstep so that their LDS reads overlap, instead of nine one after the other.
+// Regular voxels find themselves and each other mutually, so a regular node only looks BACKWARDS in key order (z-major, then
+// range, then sector): the row (z, x-1) and the three rows of plane z-1 -- four lower bounds, taken in lockstep so that their
+// reads overlap, instead of nine one after the other.
+//   Consecutive occupied sectors of a row form a RUN; its nodes start out pointing at the run's head (cc_link_runs: no
+// atomics, flat trees).  Two runs of neighbouring rows that touch are joined as soon as ONE touching pair is, and the pair
+// where the node or the candidate is the HEAD of its run always exists (the head of the run that starts later touches the
+// other run): a node in the middle of a run skips the candidates in the middle of theirs -- the unions left are one or two per
+// run, every find is a step or two.  Irregular voxels do not search like this: they are runs of their own (always heads).
 template <typename TabT>
-__device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* parent, int me, int ri, int si, int ai, int R, int S, int Az) {
+__device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* parent, const int* heads, int me, int ri, int si, int ai, int R,
+                                               int S, int Az) {
     const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
     int k0[4], k1[4], lo[4], hi[4];
 #pragma unroll
@@ -2145,21 +2150,62 @@ __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* paren
             }
         }
     }
-    int cand[12];  // a range holds at most three keys (sectors y-1 .. y+1), distinct and ascending
+    int cand[12], hw[12];  // a range holds at most three keys (sectors y-1 .. y+1), distinct and ascending
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 3; ++e) cand[q * 3 + e] = K.k[min(lo[q] + e, K.nv - 1)];
+        for (int e = 0; e < 3; ++e) {
+            const int u = min(lo[q] + e, K.nv - 1);
+            cand[q * 3 + e] = K.k[u];
+            hw[q * 3 + e] = heads ? heads[u >> 5] : -1;
+        }
     const int prev = K.k[max(me - 1, 0)];
+    // heads == nullptr (parents in LDS, where a union is cheap): every node is treated as a head -- all pairs are joined
+    const bool me_head = heads ? ((heads[me >> 5] >> (me & 31)) & 1) : true;
     int ra = me;
-    if (me > 0 && si >= 1 && prev == K.k[me] - 1) ra = cc_union_r(parent, ra, me - 1);
+    // the predecessor in the row is found too (ssc.cpp:316); inside a linked run it is the parent already
+    if (me_head && me > 0 && si >= 1 && prev == K.k[me] - 1) ra = cc_union_r(parent, ra, me - 1);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int u = lo[q] + e;
-            if (k0[q] >= 0 && u < K.nv && cand[q * 3 + e] <= k1[q]) ra = cc_union_r(parent, ra, u);
+            if (!(k0[q] >= 0 && u < K.nv && cand[q * 3 + e] <= k1[q])) continue;
+            if (me_head || ((hw[q * 3 + e] >> (u & 31)) & 1)) ra = cc_union_r(parent, ra, u);
         }
+}
+
+// Run heads of the voxel list + flat initial forest: head(v) = v starts a run (v == 0, or its key does not continue the
+// predecessor's inside the row, or one of the two is irregular); parent[v] = the head of v's run (the latest head at or
+// before v: ballots inside a wave, one LDS word per wave across the workgroup, a carry across the 1024-node chunks).
+// `regular` = nullptr: every voxel is regular.  Extra-run nodes (>= nv) are their own parents.
+__device__ __forceinline__ void cc_link_runs(const int* keys, int nv, int nn, int S, const int* regular, int* heads, int* parent, int* wlast) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;  // latest head before this chunk
+    for (int j0 = 0; j0 < nv; j0 += kCcThreads) {
+        const int j = j0 + tid;
+        bool head = false;
+        if (j < nv) {
+            const int key = keys[j], pk = keys[max(j - 1, 0)];
+            head = j == 0 || pk != key - 1 || key < 0 || (key % S) == 0;
+            if (regular && !head) head = !cc_bit(regular, j) || !cc_bit(regular, j - 1);
+            if (regular && !cc_bit(regular, j)) head = true;
+        }
+        const unsigned long long b = __ballot(head);
+        if ((tid & 31) == 0 && j0 + (tid & ~31) < nv) heads[j >> 5] = (int)(unsigned)((tid & 32) ? (b >> 32) : b);
+        if (lane == 0) wlast[wave] = b ? j0 + (wave << 6) + 63 - __clzll((long long)b) : -1;
+        __syncthreads();
+        int before = carry;  // latest head in the waves before mine
+        for (int w = 0; w < wave; ++w) before = max(before, wlast[w]);
+        const unsigned long long upto = b & ((2ull << lane) - 1ull);
+        const int mine = upto ? j0 + (wave << 6) + 63 - __clzll((long long)upto) : before;
+        if (j < nv) parent[j] = mine;
+        int last = carry;
+        for (int w = 0; w < kCcThreads / 64; ++w) last = max(last, wlast[w]);
+        carry = last;
+        __syncthreads();
+    }
+    for (int j = nv + tid; j < nn; j += kCcThreads) parent[j] = j;
 }
 
 __device__ __forceinline__ uint32_t f2ord(float f) { return float_sort_key(f); }
@@ -2180,8 +2226,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // variant picks LDS or arena scratch per table at run time.
 extern __shared__ int cc_smem[];
 template <bool FAST>
-__device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A, int from_apri, int* wsum, int& n_extra_s, int s, int base, int n,
-                                             int nv) {
+__device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A, int from_apri, int* wsum, int* wlast, int& n_extra_s, int s, int base,
+                                             int n, int nv) {
     PROF_BEGIN();
     const int tid = threadIdx.x;
     const int32_t* vbeg = A.vox_pt_begin + base + s;
@@ -2297,7 +2343,6 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     const int nb = ((kspan - 1) >> K.bshift) + 1;
     if (FAST)
         for (int v = tid; v < nv; v += kCcThreads) lkeys[v] = A.vox_key[(size_t)base + v];
-    for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;
     __syncthreads();
     if (FAST) {
         for (int b = tid; b <= nb; b += kCcThreads) tab[b] = (TabT)cc_lower_bound(lkeys, nv, (int)min((long long)b << K.bshift, 0x7fffffffLL));
@@ -2319,7 +2364,18 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         return prefix[k >> 5] + __popc(m) - 1;
     };
     // the run that starts a voxel is node v, an extra run is node nv + e
+    // parents in HBM (generic variant): runs linked up front and the head rule, so that few unions with short finds remain;
+    // parents in LDS: plain forest, every neighbour pair joined (measured: the rule costs more than LDS unions save)
+    int* heads = FAST ? nullptr : A.cl_count + base;  // [nv bits]
+    if (FAST) {
+        for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;
+        __syncthreads();
+    }
     if (allreg) {
+        if (!FAST) {
+            cc_link_runs(K.k, nv, nn, S, (const int*)nullptr, heads, parent, wlast);
+            __syncthreads();
+        }
         const int RS = R * S;
         int k_next = K.k[min(tid, nv - 1)];
         for (int j = tid; j < nv; j += kCcThreads) {
@@ -2327,7 +2383,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             k_next = K.k[min(j + kCcThreads, nv - 1)];
             const int ai = key / RS, rem = key - ai * RS;  // the triple IS the key's decomposition
             const int ri = rem / S, si = rem - ri * S;
-            cc_search_half(K, parent, j, ri, si, ai, R, S, Az);
+            cc_search_half(K, parent, heads, j, ri, si, ai, R, S, Az);
         }
     } else {
         int* regular = FAST ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2 : A.pt_cluster + base;
@@ -2361,12 +2417,16 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             }
         }
         __syncthreads();
+        if (!FAST) {
+            cc_link_runs(K.k, nv, nn, S, regular, heads, parent, wlast);
+            __syncthreads();
+        }
         int t_next = triple[min(tid, nn - 1)];
         for (int j = tid; j < nn; j += kCcThreads) {
             const int t = t_next;
             t_next = triple[min(j + kCcThreads, nn - 1)];
             if (cc_bit(regular, j)) {
-                cc_search_half(K, parent, j, (t & 2047) - 2, ((t >> 11) & 2047) - 2, ((t >> 22) & 1023) - 2, R, S, Az);
+                cc_search_half(K, parent, heads, j, (t & 2047) - 2, ((t >> 11) & 2047) - 2, ((t >> 22) & 1023) - 2, R, S, Az);
             } else {
                 if (cc_search(K, parent, touched, j, t, R, S, Az)) cc_set(found, j);
                 if (j < nv) {
@@ -2389,10 +2449,34 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     int* minpt = FAST ? lkeys : A.cl_count + base;  // the key table is not needed any more
     for (int j = tid; j < nn; j += kCcThreads) minpt[j] = 0x7fffffff;
     __syncthreads();
-    for (int j = tid; j < nn; j += kCcThreads) {
-        const int k = (j < nv) ? vbeg[j] : extras[j - nv];
-        const int r = cc_find(parent, j);
-        atomicMin(&minpt[r], vpts[k]);
+    if (FAST) {
+        for (int j = tid; j < nn; j += kCcThreads) {
+            const int k = (j < nv) ? vbeg[j] : extras[j - nv];
+            const int r = cc_find(parent, j);
+            atomicMin(&minpt[r], vpts[k]);
+        }
+    } else {
+        // minima in HBM: neighbours in the node list mostly share their root -- one atomic per distinct root of a wave
+        for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
+            const int j = j0 + tid;
+            int r = -1, name = 0x7fffffff;
+            if (j < nn) {
+                const int k = (j < nv) ? vbeg[j] : extras[j - nv];
+                r = cc_find(parent, j);
+                name = vpts[k];
+            }
+            bool todo = r >= 0;
+            while (__any(todo)) {
+                const int first = __ffsll((long long)__ballot(todo)) - 1;
+                const int r0 = __shfl(r, first);
+                const bool mine = todo && r == r0;
+                int m = mine ? name : 0x7fffffff;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) m = min(m, __shfl_xor(m, d));
+                if ((tid & 63) == first) atomicMin(&minpt[r0], m);
+                if (mine) todo = false;
+            }
+        }
     }
     __syncthreads();
     CC_MARK(4);
@@ -2660,6 +2744,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
 
 __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, int from_apri) {
     __shared__ int wsum[17];
+    __shared__ int wlast[kCcThreads / 64];
     __shared__ int n_extra_s;
     const int s = blockIdx.x;
     const int base = A.scan_off[s];
@@ -2670,10 +2755,10 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         return;
     }
     if (n <= kCcSlots && nv <= kCcNodes && (long long)P.bin.range_num * P.bin.sector_num * P.bin.azimuth_num < 0x7fffffffLL) {
-        if (cc_scan_impl<true>(P, A, from_apri, wsum, n_extra_s, s, base, n, nv)) return;
+        if (cc_scan_impl<true>(P, A, from_apri, wsum, wlast, n_extra_s, s, base, n, nv)) return;
         __syncthreads();
     }
-    cc_scan_impl<false>(P, A, from_apri, wsum, n_extra_s, s, base, n, nv);
+    cc_scan_impl<false>(P, A, from_apri, wsum, wlast, n_extra_s, s, base, n, nv);
 }
 
 // ------------------------------------------------------------------------------------------
