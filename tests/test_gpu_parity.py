@@ -649,6 +649,33 @@ def test_cluster_partition_with_irregular_nodes(scvod, oracle, kind, preset, seq
     ctx.close()
 
 
+@pytest.mark.parametrize("kind,preset,count,step", [("OS128", "os128_fine", 3, 101), ("PARK", "parkinglot", 24, 23), ("K64", "semantickitti", 10, 211)])
+def test_realistic_scans_with_their_irregular_returns_agree(scvod, oracle, kind, preset, count, step):
+    """the synthetic sensors put a few returns at polar angle exactly 0 (sector index -1) into most OS128 / some PARK scans:
+    whole scans through Patchwork + clustering on the device against the oracle's visiting-order restatement (the known
+    divergence of DESIGN.md section 2 does not show on scenes like these)"""
+    import torch
+    import synth
+    P = _params(scvod, preset)
+    R, S, Az = oracle.grid_dims(P)[:3]
+    scans = [synth.make_scan(5, (i * step) % 2700, kind)[0].numpy() for i in range(count)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    ctx.batch_process(torch.from_numpy(np.concatenate(scans)).cuda(), offs)
+    ctx.batch_cluster()
+    irregular = 0
+    for s in range(count):
+        r = ctx.batch_fetch(s)
+        a = r["apri"]
+        irregular += int(((a["sector_idx"] < 0) | (a["sector_idx"] >= S) | (a["range_idx"] < 0) | (a["range_idx"] >= R) |
+                          (a["azimuth_idx"] < 0) | (a["azimuth_idx"] >= Az)).sum())
+        ref, _, _ = oracle.cluster(P, a)
+        assert np.array_equal(ctx.batch_fetch_clusters(s, r["n_apri"]), _canonical(ref)), f"{kind} scan {s}"
+    if kind == "OS128":
+        assert irregular > 0
+    ctx.close()
+
+
 def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
     """more apri points than the generic variant's LDS bit arrays hold (262 144): start bits / prefixes in arena scratch,
     keys and parents in HBM; a few irregular returns among them"""
