@@ -167,6 +167,8 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.apri_idx3 = k.take<int32_t>(N);
     A.rejected_src = k.take<int32_t>(N);
     A.counts = k.take<int32_t>(B * 8);
+    A.scan_irr = k.take<int32_t>(B);
+    A.cc_perm = k.take<int32_t>(B);
     A.vb_count = k.take<int32_t>(B * kMaxBuckets);
     A.vb_cursor = k.take<int32_t>(B * kMaxBuckets);
     A.vb_off = k.take<int32_t>(B * (kMaxBuckets + 1));

@@ -82,6 +82,8 @@ struct Arena {
     int32_t* apri_idx3;       // [N] PointAPRI::{range,sector,azimuth}_idx packed 11+11+10 bits (clustering)
     int32_t* rejected_src;    // [N]
     int32_t* counts;          // [B][8]
+    int32_t* scan_irr;        // [B] != 0: the scan holds an index triple outside the grid (set by the binning kernels; only orders the clustering)
+    int32_t* cc_perm;         // [B] order in which k_cc_scan takes the scans: the irregular ones (the long-running workgroups) first
     // voxel stage
     int32_t* vb_count;        // [B][kMaxBuckets]
     int32_t* vb_cursor;       // [B][kMaxBuckets]

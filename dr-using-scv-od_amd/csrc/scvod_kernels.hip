@@ -1284,6 +1284,7 @@ __global__ __launch_bounds__(1024) void k_emit_offsets(DevParams P, Arena A) {
         c[5] = tr;
         c[6] = 0;
         c[7] = P.n_patches;
+        A.scan_irr[s] = 0;
     }
 }
 
@@ -1370,6 +1371,9 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                     A.apri_key[dst0 + ek] = a.voxel_idx;
                     A.apri_int[dst0 + ek] = a.intensity;
                     A.apri_idx3[dst0 + ek] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
+                    if ((unsigned)a.range_idx >= (unsigned)P.bin.range_num || (unsigned)a.sector_idx >= (unsigned)P.bin.sector_num ||
+                        (unsigned)a.azimuth_idx >= (unsigned)P.bin.azimuth_num)
+                        A.scan_irr[s] = 1;  // (rare: a -1 bin; every writer stores the same value)
                 } else {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;
                 }
@@ -1649,6 +1653,7 @@ __global__ __launch_bounds__(1024) void k_bin_direct(DevParams P, Arena A, int a
         run += tk;
     }
     if (threadIdx.x == 0) {
+        A.scan_irr[s] = 0;  // (order hint only: k_cc_scan decides regularity itself)
         int* c = A.counts + s * 8;
         c[0] = n;
         c[1] = 0;
@@ -2175,6 +2180,21 @@ __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* paren
         }
 }
 
+// The occupied voxels around triple t in the order findVoxelNeighbors lists them (ssc.cpp:395-411: range outermost, azimuth
+// innermost); f(u) returns false to stop
+template <typename TabT, typename Fn>
+__device__ __forceinline__ void cc_for_each_listed(const CcKeys<TabT>& K, int32_t t, int R, int S, int Az, Fn f) {
+    const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+    for (int x = max(ri - 1, 0); x <= min(ri + 1, R - 1); ++x)
+        for (int y = max(si - 1, 0); y <= min(si + 1, S - 1); ++y)
+            for (int z = max(ai - 1, 0); z <= min(ai + 1, Az - 1); ++z) {
+                const int key = x * S + y + z * R * S;
+                const int u = cc_lower_bound2(K, key);
+                if (u < K.nv && K.k[u] == key)
+                    if (!f(u)) return;
+            }
+}
+
 // Run heads of the voxel list + flat initial forest: head(v) = v starts a run (v == 0, or its key does not continue the
 // predecessor's inside the row, or one of the two is irregular); parent[v] = the head of v's run (the latest head at or
 // before v: ballots inside a wave, one LDS word per wave across the workgroup, a carry across the 1024-node chunks).
@@ -2385,6 +2405,194 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             const int ri = rem / S, si = rem - ri * S;
             cc_search_half(K, parent, heads, j, ri, si, ai, R, S, Az);
         }
+    } else if (FAST && n <= 65535) {
+        // ---- a scan with index triples outside the grid, all tables in LDS: the visiting order of clusterAndCreateFrame
+        // (ssc.cpp:303-350) decides which of the asymmetric "finds" stick, so it is modelled exactly.
+        // The loop reduces to a voxel-level state machine: a point is labelled once it was visited or once its voxel became
+        // FULLY labelled at time T(k).  Visiting point i of voxel v with the listed voxels k1 .. km: if T(v) < i every kj joins
+        // i and becomes fully labelled; otherwise with q = the first kj holding a labelled point (T(kj) < i or its first point
+        // < i) the voxels kq .. km join i (kq becomes fully labelled only through a visited first point), the ones before q are
+        // left alone; without any q all of them join.  T is well-founded in visiting order: Jacobi sweeps over all points
+        // reach its fixed point in a handful of rounds; then one pass takes q per point and one pass does the unions.
+        uint16_t* T16 = (uint16_t*)(cc_smem + kCcNodes);  // [nv] (the parents' LDS until the unions start), 0xffff = never
+        uint16_t* P1 = T16 + kCcNodes;                    // [nv] first point of every voxel
+        for (int v = tid; v < nv; v += kCcThreads) {
+            T16[v] = 0xffffu;
+            P1[v] = (uint16_t)vpts[vbeg[v]];
+        }
+        __syncthreads();
+        auto labelled_voxel = [&](int u, int i) -> bool { return T16[u] != 0xffffu && (int)T16[u] < i; };
+        // Work goes by RUN (node): the points of a run share their list.  Of a regular run (triple in the grid, encoding to the
+        // voxel's key: its own voxel is in its list) only the first three points are events -- the second visit at the latest
+        // labels the voxel fully, the third labels the whole list, later ones change nothing; an irregular run visits with
+        // every point.  Up to three events share one walk over the list (their q's are found together).
+        struct Run {
+            int o, v, len;
+            int32_t t;
+            bool regular;
+        };
+        auto run_of_node = [&](int j) -> Run {
+            Run r;
+            r.o = (j < nv) ? vbeg[j] : extras[j - nv];
+            r.v = (j < nv) ? j : voxel_of_slot(r.o);
+            int w = (r.o + 1) >> 5;
+            unsigned m = (w < nw) ? ((unsigned)rstart[w] & ~((1u << ((r.o + 1) & 31)) - 1u)) : 0u;
+            while (!m && ++w < nw) m = (unsigned)rstart[w];
+            r.len = (m ? min((w << 5) + __ffs((int)m) - 1, n) : n) - r.o;
+            r.t = idx3[vpts[r.o]];
+            const int ri = (r.t & 2047) - 2, si = ((r.t >> 11) & 2047) - 2, ai = ((r.t >> 22) & 1023) - 2;
+            r.regular = kspan == (int)span && ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == K.k[r.v]);
+            return r;
+        };
+        // the listed voxels of every node, looked up once: 27 uint16 per node in the box scratch of the scan (free until the
+        // boxes are built) when it is large enough -- the rounds then walk the table instead of repeating 27 searches
+        // (rows of 32 entries = 64 bytes, 16-byte aligned: a row is four wide loads in flight, then registers)
+        uint16_t* nbr = (uint16_t*)(((uintptr_t)(A.cl_bbox + 7 * (size_t)base) + 15) & ~(uintptr_t)15);
+        const bool tabled = (size_t)nn * 64 + 16 <= (size_t)n * 7 * sizeof(float);
+        if (tabled) {
+            for (int j = tid; j < nn; j += kCcThreads) {
+                const int o = (j < nv) ? vbeg[j] : extras[j - nv];
+                uint16_t* row = nbr + (size_t)j * 32;
+                int jj = 0;
+                cc_for_each_listed(K, idx3[vpts[o]], R, S, Az, [&](int u) -> bool {
+                    row[jj++] = (uint16_t)u;
+                    return true;
+                });
+                for (; jj < 32; ++jj) row[jj] = 0xffffu;
+            }
+            __syncthreads();
+        }
+        CC_MARK(10);
+        auto walk = [&](int j, int32_t t, auto f) {  // f(u) in list order; false stops
+            if (tabled) {
+                const uint4* row = reinterpret_cast<const uint4*>(nbr + (size_t)j * 32);
+                const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+                const unsigned w[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+#pragma unroll
+                for (int e = 0; e < 27; ++e) {
+                    const int u = (int)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    if (u == 0xffff || !f(u)) return;
+                }
+            } else {
+                cc_for_each_listed(K, t, R, S, Az, f);
+            }
+        };
+        // what a round needs of a run, gathered once (arena scratch): opener slot, voxel, length (bit 31: regular), triple
+        int4* runs = (int4*)A.tk_pairs + ((size_t)base + 1) / 2;  // [nn] (16-byte aligned inside the scan's 8 n bytes; nn <= n / 2 ... checked)
+        const bool runs_cached = (size_t)nn * 2 + 2 <= (size_t)n;
+        if (runs_cached) {
+            for (int j = tid; j < nn; j += kCcThreads) {
+                const Run r = run_of_node(j);
+                runs[j] = make_int4(r.o, r.v, r.len | (r.regular ? (int)0x80000000u : 0), r.t);
+            }
+            __syncthreads();
+        }
+        auto cached_run = [&](int j) -> Run {
+            if (!runs_cached) return run_of_node(j);
+            const int4 c = runs[j];
+            Run r;
+            r.o = c.x;
+            r.v = c.y;
+            r.len = c.z & 0x7fffffff;
+            r.regular = c.z < 0;
+            r.t = c.w;
+            return r;
+        };
+        // the next round's times: in the key table's LDS once the lists are tabled (no search needs the keys any more)
+        int* Tn = tabled && runs_cached ? lkeys : A.cc_parent + base;  // [nv]
+        for (int round = 0; round < 64; ++round) {
+            for (int v = tid; v < nv; v += kCcThreads) Tn[v] = 0x7fffffff;
+            __syncthreads();
+            for (int j = tid; j < nn; j += kCcThreads) {
+                const Run r = cached_run(j);
+                const int nev = r.regular ? min(r.len, 3) : r.len;
+                for (int p0 = 0; p0 < nev; p0 += 3) {
+                    int ie[3], qe[3];
+                    bool cs[3];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        ie[e] = (p0 + e < nev) ? vpts[r.o + p0 + e] : 0x7fffffff;  // (an absent event never sets anything)
+                        // round 0 starts the iteration from the optimistic end (every visit labels its whole list): any start
+                        // reaches the same fixed point, this one in fewer rounds than "nothing is ever labelled"
+                        cs[e] = p0 + e < nev && (round == 0 || labelled_voxel(r.v, ie[e]));
+                        qe[e] = -1;
+                    }
+                    int jj = 0;
+                    walk(j, r.t, [&](int u) -> bool {
+                        const int p1 = P1[u];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            if (qe[e] < 0 && ie[e] != 0x7fffffff && (labelled_voxel(u, ie[e]) || p1 < ie[e])) qe[e] = jj;
+                        ++jj;
+                        return true;
+                    });
+                    jj = 0;
+                    walk(j, r.t, [&](int u) -> bool {
+                        const int p1 = P1[u];
+                        int te = 0x7fffffff;  // the earliest of the events that labels u fully
+#pragma unroll
+                        for (int e = 2; e >= 0; --e)
+                            if (ie[e] != 0x7fffffff && (cs[e] || qe[e] < 0 || jj > qe[e] || (jj == qe[e] && p1 < ie[e]))) te = ie[e];
+                        if (te != 0x7fffffff && te < cc_ld(&Tn[u])) atomicMin(&Tn[u], te);
+                        ++jj;
+                        return true;
+                    });
+                }
+            }
+            __syncthreads();
+            bool changed = false;
+            for (int v = tid; v < nv; v += kCcThreads) {
+                const int tv = cc_ld(&Tn[v]);  // (written by atomics: read past the L1)
+                const uint16_t t16 = tv == 0x7fffffff ? (uint16_t)0xffffu : (uint16_t)tv;
+                changed |= t16 != T16[v];
+                T16[v] = t16;
+            }
+            CC_MARK(13);
+#ifdef SCVOD_PROFILE
+            if (tid == 0) atomicAdd(&g_prof[0][14], 100ull);  // rounds x 100 (prints as "us": 1.0 per round and scan)
+#endif
+            if (!__syncthreads_or(changed ? 1 : 0)) break;
+        }
+        CC_MARK(11);
+        // the unions: what a run's LAST point joins contains what its earlier points joined (q only moves forward in time)
+        int* qnode = A.cc_parent + base;  // [nn] q of every node
+        for (int j = tid; j < nn; j += kCcThreads) {
+            const Run r = cached_run(j);
+            const int i = vpts[r.o + r.len - 1];
+            int q = -1, jj = 0;
+            if (!labelled_voxel(r.v, i))
+                walk(j, r.t, [&](int u) -> bool {
+                    if (labelled_voxel(u, i) || (int)P1[u] < i) {
+                        q = jj;
+                        return false;
+                    }
+                    ++jj;
+                    return true;
+                });
+            qnode[j] = max(q, 0);
+        }
+        __syncthreads();
+        for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;  // (T16 / P1 are used up)
+        for (int w = tid; w < ((nn + 31) >> 5); w += kCcThreads) {
+            touched[w] = 0;
+            found[w] = 0;
+        }
+        __syncthreads();
+        for (int j = tid; j < nn; j += kCcThreads) {
+            const int o = (j < nv) ? vbeg[j] : extras[j - nv];
+            const int q = qnode[j];
+            int jj = 0;
+            walk(j, idx3[vpts[o]], [&](int u) -> bool {
+                if (jj >= q) {
+                    cc_set(touched, u);  // all of u's points join
+                    if (u != j) cc_union(parent, j, u);
+                }
+                ++jj;
+                return true;
+            });
+            if (jj > 0) cc_set(found, j);
+        }
+        CC_MARK(12);
     } else {
         int* regular = FAST ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2 : A.pt_cluster + base;
         int* triple = (int*)(A.tk_pairs + base);  // [nn] opener triples (arena scratch, free until the naming pass)
@@ -2742,11 +2950,31 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     return true;
 }
 
+// the scans with triples outside the grid run the visiting-order model (milliseconds instead of a quarter of one): they are
+// handed out first, so that they overlap the regular ones instead of trailing them.  One workgroup, stable partition.
+__global__ __launch_bounds__(1024) void k_cc_order(Arena A) {
+    __shared__ int wsum[17];
+    const int B = A.n_scans;
+    int n_irr = 0;
+    for (int s0 = 0; s0 < B; s0 += 1024) n_irr += __syncthreads_count(s0 + (int)threadIdx.x < B && A.scan_irr[s0 + threadIdx.x] != 0);
+    int run_i = 0, run_r = 0;
+    for (int s0 = 0; s0 < B; s0 += 1024) {
+        const int s = s0 + threadIdx.x;
+        const bool irr = s < B && A.scan_irr[s] != 0;
+        int ti, tr;
+        const int ei = block_excl_scan<1024>(irr ? 1 : 0, ti, wsum);
+        const int er = block_excl_scan<1024>((s < B && !irr) ? 1 : 0, tr, wsum);
+        if (s < B) A.cc_perm[irr ? run_i + ei : n_irr + run_r + er] = s;
+        run_i += ti;
+        run_r += tr;
+    }
+}
+
 __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, int from_apri) {
     __shared__ int wsum[17];
     __shared__ int wlast[kCcThreads / 64];
     __shared__ int n_extra_s;
-    const int s = blockIdx.x;
+    const int s = A.cc_perm[blockIdx.x];
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
     const int nv = A.counts[s * 8 + 6];
@@ -3109,6 +3337,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
     }
     if (do_voxels) {
         if (do_patchwork == 2) {
+            hipMemsetAsync(A.scan_irr, 0, sizeof(int32_t) * (size_t)B, st);  // (order hint of the clustering: unknown here)
             hipLaunchKernelGGL(k_apri_split, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A);
         }
         hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
@@ -3224,6 +3453,7 @@ void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream
     if (B <= 0 || A.max_scan_pts <= 0) return;
     hipFuncSetAttribute((const void*)k_cc_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcLdsBytes);
     TH_BEGIN("cc_scan");
+    hipLaunchKernelGGL(k_cc_order, dim3(1), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_cc_scan, dim3(B), dim3(kCcThreads), kCcLdsBytes, st, P, A, from_apri);
     TH_END("cc_scan");
 }

@@ -293,7 +293,7 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle):
     where the two find each other; an aliased voxel is found by points it does not find.  The device joins everything that
     is found: the reference's partition must refine it, and the points that differ stay below 1 %."""
     rng = np.random.default_rng(77)
-    generic = differ = total = 0
+    generic = differ = total = exact = 0
     for case in range(60):
         kw, x = _random_cloud(rng)
         P = scvod.make_params("semantickitti", **kw)
@@ -309,12 +309,17 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle):
         assert len(np.unique(got)) == n_ref
         got = ctx.cluster(apri)
         can = _canonical(oracle.cluster(P, apri)[0])
-        pairs = np.unique(np.stack([can, got], 1), axis=0)
-        assert len(np.unique(pairs[:, 0])) == len(pairs), f"case {case}: a reference cluster is split on the device"
-        differ += int((got != can).sum())
-        total += len(apri)
+        if len(np.unique(apri["voxel_idx"])) <= 14336 and len(apri) <= 65535:
+            # all tables in LDS: the visiting order is modelled exactly
+            exact += 1
+            assert np.array_equal(got, can), f"case {case} (with its irregular points): {kw}"
+        else:
+            pairs = np.unique(np.stack([can, got], 1), axis=0)
+            assert len(np.unique(pairs[:, 0])) == len(pairs), f"case {case}: a reference cluster is split on the device"
+            differ += int((got != can).sum())
+            total += len(apri)
         ctx.close()
-    assert generic >= 5
+    assert generic >= 5 and exact >= 20
     assert differ < 0.01 * total, (differ, total)
 
 

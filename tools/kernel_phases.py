@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
 KERNELS = [
     ("k_cc_scan (per scan)", ["regularity + start bits", "runs (two gathers)", "prefix + key table + init", "neighbour search + unions",
                               "extra runs, canonical names", "flatten + compact ids", "names per slot", "boxes", "types, voxel table, car lists",
-                              "type + members per point"]),
+                              "type + members per point", "exact path: tables + listed voxels", "exact path: (rest of the rounds)", "exact path: q + unions",
+                              "exact path: rounds", "exact path: number of rounds"]),
     ("k_pw_sort<4096> (per scan)", ["load keys", "bitonic sort", "gather + write sorted points"]),
     ("k_pw_sort<8192> (per scan)", ["load keys", "bitonic sort", "gather + write sorted points"]),
     ("k_vx_bucket<4096> (per scan)", ["load keys", "bitonic sort", "heads + voxel starts", "stage intensities", "per-voxel sums", "final writes"]),
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--kind", default="K64")
     ap.add_argument("--preset", default="semantickitti")
     ap.add_argument("--scans", type=int, default=256)
+    ap.add_argument("--irregular", type=int, default=0, help="returns at polar angle exactly 0 appended to every scan (sector index -1)")
     ap.add_argument("--lib", default="libscvod_prof.so", help="profiling build to load (file name under csrc/)")
     a = ap.parse_args()
     import torch
@@ -37,6 +39,11 @@ def main():
     parts, offs = [], [0]
     for i in range(a.scans):
         p, _, _ = synth.make_scan(5, i * 7, a.kind, device=dev)
+        if a.irregular:
+            g = torch.Generator(device="cpu").manual_seed(i)
+            e = torch.stack([torch.rand(a.irregular, generator=g) * 22 + 3, torch.zeros(a.irregular), torch.rand(a.irregular, generator=g) * 1.8 - 0.6,
+                             torch.rand(a.irregular, generator=g)], 1).to(dev)
+            p = torch.cat([p, e], 0)
         parts.append(p)
         offs.append(offs[-1] + p.shape[0])
     pts = torch.cat(parts, 0).contiguous()
