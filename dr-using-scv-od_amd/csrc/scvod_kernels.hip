@@ -2500,7 +2500,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         };
         // the next round's times: in the key table's LDS once the lists are tabled (no search needs the keys any more)
         int* Tn = tabled && runs_cached ? lkeys : A.cc_parent + base;  // [nv]
-        for (int round = 0; round < 64; ++round) {
+        for (int round = 0; round < 1024; ++round) {  // (about seven in practice; the fixed point exists after at most one round per visit)
             for (int v = tid; v < nv; v += kCcThreads) Tn[v] = 0x7fffffff;
             __syncthreads();
             for (int j = tid; j < nn; j += kCcThreads) {
