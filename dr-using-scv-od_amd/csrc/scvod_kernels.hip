@@ -1979,6 +1979,7 @@ constexpr int kCcSlots = 65536;  // apri points per scan whose run / voxel start
 constexpr int kCcThreads = 1024;
 constexpr int kCcBoxes = 2048;   // bounding boxes per scan held in LDS (7 words each, in the key table once the search is over)
 constexpr int kCcBuckets = 8192; // entries of the key-bucket index (uint16 node numbers; the generic variant: kCcNodes 32-bit entries)
+constexpr int kCcExactMaxNodes = 4096;  // generic variant: nodes in components with irregular runs that are re-clustered exactly
 constexpr int kCcSlotsBig = 262144;  // generic variant: the nodes live in HBM, which leaves LDS for the bit arrays of this many points
 
 static_assert(7 * kCcBoxes <= kCcNodes, "box records must fit the released key table");
@@ -2652,6 +2653,204 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         if (cc_bit(touched, v)) cc_union(parent, nv + e, v);
     }
     __syncthreads();
+    if (!FAST && !allreg && slots_lds && kspan == (int)span) {
+        // ---- generic variant, scan with irregular triples: what stands now is "everything found is joined".  The visiting
+        // order (the model of the all-in-LDS variant above) can only SPLIT components that hold an
+        // irregular run, and its state machine never looks outside such a component (a listed voxel is in the lister's
+        // component; a voxel's labelling time depends on its finders only): those components are clustered again, exactly,
+        // with the times / first points / next times of their voxels in arena scratch.
+        int* regular = A.pt_cluster + base;
+        const int* triple = (const int*)(A.tk_pairs + base);  // [nn] opener triples (written by the search above)
+        int* aff = A.tk_members + base;                       // [nn] root flag: the component holds an irregular run
+        int* La = A.tk_clusters + base;                       // [na] the nodes of those components
+        int* Tg = A.cl_count + base;                          // [nv] labelling times (run heads are used up)
+        int* P1g = A.tk_nuniq + base;                         // [nv] first point of a voxel
+        int* Tng = A.tk_cursor + base;                        // [nv] next round's times, then [na] q per listed node
+        for (int j = tid; j < nn; j += kCcThreads) aff[j] = 0;
+        __syncthreads();
+        for (int j = tid; j < nn; j += kCcThreads)
+            if (j >= nv || !cc_bit(regular, j)) aff[cc_find(parent, j)] = 1;
+        __syncthreads();
+        int na = 0;
+        for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
+            const int j = j0 + tid;
+            const bool a = j < nn && aff[cc_find(parent, j)] != 0;
+            int total;
+            const int ex = block_excl_scan<kCcThreads>(a ? 1 : 0, total, wsum);
+            if (a) La[na + ex] = j;
+            na += total;
+        }
+        __syncthreads();
+        // (components of tens of thousands of nodes -- an irregular return on a facade of a 128-beam scan -- are left as they
+        // are: the rounds would cost milliseconds in HBM, and around such a point every voxel has finders with three or
+        // more points, whose third visit joins all they list)
+        if (na > 0 && na <= kCcExactMaxNodes) {
+            struct Run {
+                int o, v, len;
+                int32_t t;
+                bool regular;
+            };
+            auto run_of_node = [&](int j) -> Run {
+                Run r;
+                r.o = (j < nv) ? vbeg[j] : extras[j - nv];
+                r.v = (j < nv) ? j : voxel_of_slot(r.o);
+                int w = (r.o + 1) >> 5;
+                unsigned m = (w < nw) ? ((unsigned)rstart[w] & ~((1u << ((r.o + 1) & 31)) - 1u)) : 0u;
+                while (!m && ++w < nw) m = (unsigned)rstart[w];
+                r.len = (m ? min((w << 5) + __ffs((int)m) - 1, n) : n) - r.o;
+                r.t = triple[j];
+                const int ri = (r.t & 2047) - 2, si = ((r.t >> 11) & 2047) - 2, ai = ((r.t >> 22) & 1023) - 2;
+                r.regular = ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == K.k[r.v]);
+                return r;
+            };
+            // run records + the listed voxels of every affected node (32-bit rows of 32) in the scan's box scratch when it fits
+            char* scratch = (char*)(((uintptr_t)(A.cl_bbox + 7 * (size_t)base) + 15) & ~(uintptr_t)15);
+            const bool tabled = (size_t)na * (16 + 128) + 16 <= (size_t)n * 7 * sizeof(float);
+            int4* runs = (int4*)scratch;
+            uint32_t* nbr = (uint32_t*)(scratch + (size_t)na * 16);
+            for (int x = tid; x < na; x += kCcThreads) {
+                const int j = La[x];
+                if (j < nv) {
+                    Tg[j] = 0x7fffffff;
+                    P1g[j] = vpts[vbeg[j]];
+                }
+                if (tabled) {
+                    const Run r = run_of_node(j);
+                    runs[x] = make_int4(r.o, r.v, r.len | (r.regular ? (int)0x80000000u : 0), r.t);
+                    uint32_t* row = nbr + (size_t)x * 32;
+                    int jj = 0;
+                    cc_for_each_listed(K, r.t, R, S, Az, [&](int u) -> bool {
+                        row[jj++] = (uint32_t)u;
+                        return true;
+                    });
+                    for (; jj < 32; ++jj) row[jj] = 0xffffffffu;
+                }
+            }
+            __syncthreads();
+            auto cached_run = [&](int x) -> Run {
+                if (!tabled) return run_of_node(La[x]);
+                const int4 c = runs[x];
+                Run r;
+                r.o = c.x;
+                r.v = c.y;
+                r.len = c.z & 0x7fffffff;
+                r.regular = c.z < 0;
+                r.t = c.w;
+                return r;
+            };
+            auto walk = [&](int x, int32_t t, auto f) {  // f(u) in list order; false stops
+                if (tabled) {
+                    const uint32_t* row = nbr + (size_t)x * 32;
+                    for (int e = 0; e < 27; ++e) {
+                        const uint32_t u = row[e];
+                        if (u == 0xffffffffu || !f((int)u)) return;
+                    }
+                } else {
+                    cc_for_each_listed(K, t, R, S, Az, f);
+                }
+            };
+            auto labelled_voxel = [&](int u, int i) -> bool { return Tg[u] < i; };
+            for (int round = 0; round < 1024; ++round) {
+                for (int x = tid; x < na; x += kCcThreads)
+                    if (La[x] < nv) Tng[La[x]] = 0x7fffffff;
+                __syncthreads();
+                for (int x = tid; x < na; x += kCcThreads) {
+                    const Run r = cached_run(x);
+                    const int nev = r.regular ? min(r.len, 3) : r.len;
+                    for (int p0 = 0; p0 < nev; p0 += 3) {
+                        int ie[3], qe[3];
+                        bool cs[3];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            ie[e] = (p0 + e < nev) ? vpts[r.o + p0 + e] : 0x7fffffff;
+                            cs[e] = p0 + e < nev && (round == 0 || labelled_voxel(r.v, ie[e]));
+                            qe[e] = -1;
+                        }
+                        int jj = 0;
+                        walk(x, r.t, [&](int u) -> bool {
+                            const int p1 = P1g[u];
+#pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                if (qe[e] < 0 && ie[e] != 0x7fffffff && (labelled_voxel(u, ie[e]) || p1 < ie[e])) qe[e] = jj;
+                            ++jj;
+                            return true;
+                        });
+                        jj = 0;
+                        walk(x, r.t, [&](int u) -> bool {
+                            const int p1 = P1g[u];
+                            int te = 0x7fffffff;
+#pragma unroll
+                            for (int e = 2; e >= 0; --e)
+                                if (ie[e] != 0x7fffffff && (cs[e] || qe[e] < 0 || jj > qe[e] || (jj == qe[e] && p1 < ie[e]))) te = ie[e];
+                            if (te != 0x7fffffff && te < cc_ld(&Tng[u])) atomicMin(&Tng[u], te);
+                            ++jj;
+                            return true;
+                        });
+                    }
+                }
+                __syncthreads();
+                bool changed = false;
+                for (int x = tid; x < na; x += kCcThreads) {
+                    const int j = La[x];
+                    if (j >= nv) continue;
+                    const int tv = cc_ld(&Tng[j]);
+                    changed |= tv != Tg[j];
+                    Tg[j] = tv;
+                }
+                if (!__syncthreads_or(changed ? 1 : 0)) break;
+            }
+            // q of every listed node at its last point, then the unions of these components from scratch
+            int* qnode = A.tk_uniq + base + n_extra;  // [na] (behind the extras list)
+            const bool q_fits = n_extra + na <= n;
+            for (int x = tid; x < na; x += kCcThreads) {
+                const Run r = cached_run(x);
+                const int i = vpts[r.o + r.len - 1];
+                int q = -1, jj = 0;
+                if (!labelled_voxel(r.v, i))
+                    walk(x, r.t, [&](int u) -> bool {
+                        if (labelled_voxel(u, i) || P1g[u] < i) {
+                            q = jj;
+                            return false;
+                        }
+                        ++jj;
+                        return true;
+                    });
+                if (q_fits) qnode[x] = max(q, 0);
+            }
+            __syncthreads();
+            if (q_fits) {
+                for (int x = tid; x < na; x += kCcThreads) {
+                    const int j = La[x];
+                    parent[j] = j;
+                    atomicAnd(&found[j >> 5], ~(1 << (j & 31)));
+                    if (j < nv) atomicAnd(&touched[j >> 5], ~(1 << (j & 31)));
+                }
+                __syncthreads();
+                for (int x = tid; x < na; x += kCcThreads) {
+                    const int j = La[x];
+                    const int q = qnode[x];
+                    int jj = 0;
+                    walk(x, triple[j], [&](int u) -> bool {
+                        if (jj >= q) {
+                            cc_set(touched, u);
+                            if (u != j) cc_union(parent, j, u);
+                        }
+                        ++jj;
+                        return true;
+                    });
+                    if (jj > 0) cc_set(found, j);
+                }
+                __syncthreads();
+                for (int x = tid; x < na; x += kCcThreads) {
+                    const int j = La[x];
+                    if (j < nv) continue;
+                    const int v = voxel_of_slot(extras[j - nv]);
+                    if (cc_bit(touched, v)) cc_union(parent, j, v);
+                }
+                __syncthreads();
+            }
+        }
+    }
     // canonical name of a component: the smallest apri index among the openers of its nodes (every other member of a
     // node sits behind its opener in an ascending point list)
     int* minpt = FAST ? lkeys : A.cl_count + base;  // the key table is not needed any more
