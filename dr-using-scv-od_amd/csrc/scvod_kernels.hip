@@ -2671,14 +2671,22 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         for (int j = tid; j < nn; j += kCcThreads)
             if (j >= nv || !cc_bit(regular, j)) aff[cc_find(parent, j)] = 1;
         __syncthreads();
+        // (a sample of every eighth node first: components far beyond the bound are not even listed)
+        int sampled = 0;
+        for (int j0 = 0; j0 < nn; j0 += kCcThreads * 8) {
+            const int j = j0 + tid * 8;
+            sampled += __syncthreads_count(j < nn && aff[cc_find(parent, j)] != 0);
+        }
         int na = 0;
-        for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
-            const int j = j0 + tid;
-            const bool a = j < nn && aff[cc_find(parent, j)] != 0;
-            int total;
-            const int ex = block_excl_scan<kCcThreads>(a ? 1 : 0, total, wsum);
-            if (a) La[na + ex] = j;
-            na += total;
+        if (sampled * 8 <= 2 * kCcExactMaxNodes) {
+            for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
+                const int j = j0 + tid;
+                const bool a = j < nn && aff[cc_find(parent, j)] != 0;
+                int total;
+                const int ex = block_excl_scan<kCcThreads>(a ? 1 : 0, total, wsum);
+                if (a) La[na + ex] = j;
+                na += total;
+            }
         }
         __syncthreads();
         // (components of tens of thousands of nodes -- an irregular return on a facade of a 128-beam scan -- are left as they
