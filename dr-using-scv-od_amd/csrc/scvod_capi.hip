@@ -13,6 +13,7 @@
 
 #include "../../include/scvod.h"
 #include "scvod_kernels.h"
+#include "scvod_chain.h"
 
 using namespace scvod;
 
@@ -65,6 +66,21 @@ struct scvod_ctx {
     UploadSlot up_ring[4];
     int up_next_slot = 0;
     bool track_valid = false;
+    // sequential tracking chain (scvod_chain.hip)
+    int track_mode = SCVOD_TRACK_CHAIN;
+    int chain_seg = 24, chain_warm = 16;     // steps per segment, warm-up steps in front of it
+    int32_t* d_chain_scans = nullptr;        // [cap_scans]
+    ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
+    int32_t* d_chain_fw = nullptr;           // [cap_scans + 1]
+    int32_t* d_chain_stats = nullptr;        // [8]
+    std::vector<int32_t> up_chain_scans, up_chain_fw, up_chain_walkers;
+    void* chain_ws = nullptr;                // walkers' workspace (own allocation, grows on demand)
+    size_t chain_ws_bytes = 0;
+    ChainWs chain_geom;
+    int chain_geom_pts = -1;                 // max_scan_pts the geometry was laid out for
+    bool chain_ran = false;                  // the last scvod_batch_track ran the chain (stats are meaningful)
+    bool chain_ws_clean = false;
+    int chain_ws_layout_pts = -1;
     bool tables_valid = false;   // successor tables (vox_track) built for the current clustering
     std::vector<int32_t> tk_stage;    // host staging of scvod_batch_fetch_track
     // streaming ingest (scvod_sequence_ingest): two device chunk buffers, a copy stream, pinned offsets
@@ -219,6 +235,9 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.tk_cursor = c->t_pair;
     A.tk_mbegin = k.take<int32_t>(N + 1);  // (published by the clustering: not shared with the one-shot probe's scratch)
     A.vox_track = k.take<int4>(N);
+    A.vox_rep = k.take<int32_t>(N);
+    A.tk_crep = k.take<int32_t>(N);
+    A.tk_prep = k.take<int32_t>(N);
     A.cl_state = k.take<int8_t>(N);
     A.tk_members = k.take<int32_t>(N);
     A.tk_pairs = k.take<int2>(N);
@@ -229,6 +248,10 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.pt_mapcls = k.take<uint8_t>(N);
     c->d_next_scan = k.take<int32_t>(B);
     c->d_ext = k.take<const int4*>(B);
+    c->d_chain_scans = k.take<int32_t>(B);
+    c->d_chain_walkers = k.take<ChainWalker>(B);
+    c->d_chain_fw = k.take<int32_t>(B + 1);
+    c->d_chain_stats = k.take<int32_t>(8);
     *total = align_up(k.off, 256);
 }
 
@@ -373,8 +396,9 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->tables_valid = false;
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
-    if (mx == 0) {
+    if (mx == 0) {  // every scan empty: no kernel runs (neither here nor in the clustering / tracking launches): clean per-scan words
         HIPCHK(c, hipMemsetAsync(c->A.counts, 0, sizeof(int32_t) * 8 * n_scans, st));
+        HIPCHK(c, hipMemsetAsync(c->A.tk_scan, 0, sizeof(int32_t) * 4 * n_scans, st));
     }
     c->batch_valid = true;
     c->voxels_valid = (do_voxels != 0);
@@ -597,6 +621,89 @@ int upload_if_changed(scvod_ctx* c, std::vector<T>& held, const T* src, size_t n
     return n ? staged_upload(c, held.data(), n * sizeof(T), dst, st) : SCVOD_OK;
 }
 
+// ---- sequential tracking chain: plan (chains of the successor table cut into segments) and workspace ----
+size_t chain_layout(ChainWs& g, int max_scan_pts) {
+    const size_t nv = (size_t)(max_scan_pts > 0 ? max_scan_pts : 1);
+    const size_t cap_pool = nv * 2 > 65536 ? nv * 2 : 65536;
+    const size_t cap_ent = nv / 4 + 1024;
+    g.cap_pool = (int32_t)cap_pool;
+    g.cap_ent = (int32_t)cap_ent;
+    g.cap_nv = (int32_t)nv;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        off = align_up(off, 256);
+        const size_t o = off;
+        off += bytes;
+        return o;
+    };
+    g.off_hdr = take(16 * 4);
+    for (int i = 0; i < 3; ++i) {
+        g.off_ent[i] = take(2 * cap_ent * sizeof(int4));
+        g.off_parts[i] = take(cap_ent * 4);
+        g.off_pool[i] = take(cap_pool * sizeof(float4));
+    }
+    g.off_chit = take(cap_pool * 4);
+    g.off_evr = take(cap_ent * sizeof(int2));
+    g.off_suniq = take((cap_pool + nv) * 4);
+    g.off_spairs = take((cap_pool + nv) * sizeof(int2));
+    g.off_vlab = take(nv * 8);
+    g.off_lcnt = take((nv + cap_ent) * 8);
+    g.off_lfwd = take((nv + cap_ent) * 8);
+    g.off_newent = take(cap_ent * 4);
+    g.off_cmeta = take(cap_ent * sizeof(int4));
+    g.off_cparts = take(cap_ent * 4);
+    g.off_links = take(cap_ent * sizeof(int4));
+    g.off_dsz = take(2 * cap_ent * 4);
+    g.off_eidx = take(2 * cap_ent * 4);
+    g.off_rp = take(nv * sizeof(int2));
+    g.stride = align_up(off, 4096);
+    return g.stride;
+}
+
+// Chains = maximal runs scan -> successor -> ... inside the batch; every chain is cut into segments of `seg` steps, each
+// walked by one workgroup that warms up `warm` steps earlier (scvod_chain.hip).  Returns the number of walkers, or a
+// negative status when a scan is the successor of two scans (no sequence looks like that).
+int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int32_t>& scans, std::vector<int32_t>& fw,
+                std::vector<int32_t>& walkers) {
+    const int B = (int)next.size();
+    std::vector<int32_t> pred(B, -1);
+    for (int s = 0; s < B; ++s)
+        if (next[s] >= 0) {
+            if (pred[next[s]] != -1) return fail(c, SCVOD_ERR_INVALID, "scan %d is the successor of scans %d and %d", next[s], pred[next[s]], s);
+            if (next[s] == s) return fail(c, SCVOD_ERR_INVALID, "scan %d is its own successor", s);
+            pred[next[s]] = s;
+        }
+    scans.clear();
+    fw.assign(1, 0);
+    walkers.clear();
+    std::vector<char> seen(B, 0);
+    const int seg = c->chain_seg > 0 ? c->chain_seg : 1, warm = c->chain_warm > 0 ? c->chain_warm : 0;
+    int n_chains = 0;
+    for (int h = 0; h < B; ++h) {
+        if (pred[h] != -1 || next[h] < 0) continue;  // not a head, or a head without a successor in the batch
+        const int first = (int)scans.size();
+        int n = 0;
+        for (int s = h; s >= 0 && !seen[s]; s = next[s] >= 0 ? next[s] : -1) {
+            seen[s] = 1;
+            scans.push_back(s);
+            ++n;
+        }
+        const int steps = n - 1;
+        for (int a = 0; a < steps; a += seg) {
+            const int b = a + seg < steps ? a + seg : steps;
+            const int t0 = a - warm > 0 ? a - warm : 0;
+            const int32_t w[8] = {first, n, a, b, t0, n_chains, 0, 0};
+            walkers.insert(walkers.end(), w, w + 8);
+        }
+        fw.push_back((int32_t)(walkers.size() / 8));
+        ++n_chains;
+    }
+    // (a cycle has no head: its scans keep their first-order result; rejected here to be explicit)
+    for (int s = 0; s < B; ++s)
+        if (next[s] >= 0 && !seen[s]) return fail(c, SCVOD_ERR_INVALID, "the successor table holds a cycle through scan %d", s);
+    return (int)(walkers.size() / 8);
+}
+
 }  // namespace
 
 // internal bridge for scvod_map.hip (not part of the public header)
@@ -757,6 +864,7 @@ void scvod_destroy(scvod_ctx* c) {
         if (u.ev) hipEventDestroy(u.ev);
     }
     if (c->arena_base) hipFree(c->arena_base);
+    if (c->chain_ws) hipFree(c->chain_ws);
     if (c->stage) hipHostFree(c->stage);
     for (void* b : c->nn_buf)
         if (b) hipFree(b);
@@ -848,6 +956,10 @@ int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offset
     hipStream_t st = c->stream;
     c->last_stream = st;
     c->tim_used = 0;
+    // the one-shot probe writes t_T and scratch that scvod_batch_track's results alias: forget the cached upload of T and
+    // the batch's tracking result (a following scvod_batch_track uploads and decides again)
+    c->up_T.clear();
+    c->track_valid = false;
     float4* d_pts = c->t_pts;
     if (n_pts) HIPCHK(c, hipMemcpyAsync(d_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_pts, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_begin, h_offsets, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
@@ -1013,12 +1125,98 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     J.n_ext = n_ext;
     J.T = c->t_T;
     J.occupancy = c->params.occupancy;
-    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, c->tables_valid ? 2 : 3, st, timer_hook, c);
+    ChainJob CJ;
+    memset(&CJ, 0, sizeof(CJ));
+    c->chain_ran = false;
+    if (c->track_mode == SCVOD_TRACK_CHAIN && c->A.max_scan_pts > 0) {
+        std::vector<int32_t> scans, fw, walkers;
+        const int nw = plan_chains(c, next, scans, fw, walkers);
+        if (nw < 0) return nw;
+        if (nw > 0) {
+            if (c->chain_geom_pts != c->A.max_scan_pts) {
+                chain_layout(c->chain_geom, c->A.max_scan_pts);
+                c->chain_geom_pts = c->A.max_scan_pts;
+            }
+            const size_t need = (size_t)nw * c->chain_geom.stride;
+            if (need > c->chain_ws_bytes) {  // first call / larger job: the only allocation, outside any steady-state step
+                HIPCHK(c, hipDeviceSynchronize());
+                if (c->chain_ws) hipFree(c->chain_ws);
+                c->chain_ws = nullptr;
+                c->chain_ws_bytes = 0;
+                HIPCHK(c, hipMalloc(&c->chain_ws, need));
+                c->chain_ws_bytes = need;
+                c->chain_ws_clean = false;
+            }
+            // the stamped override words compare against a per-walker epoch that only grows: a zeroed workspace is a valid one
+            if (!c->chain_ws_clean || c->chain_ws_layout_pts != c->A.max_scan_pts) {
+                HIPCHK(c, hipMemsetAsync(c->chain_ws, 0, c->chain_ws_bytes, st));
+                c->chain_ws_clean = true;
+                c->chain_ws_layout_pts = c->A.max_scan_pts;
+            }
+            if ((rc = upload_if_changed(c, c->up_chain_scans, scans.data(), scans.size(), c->d_chain_scans, st))) return rc;
+            if ((rc = upload_if_changed(c, c->up_chain_fw, fw.data(), fw.size(), c->d_chain_fw, st))) return rc;
+            if ((rc = upload_if_changed(c, c->up_chain_walkers, walkers.data(), walkers.size(), (void*)c->d_chain_walkers, st))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->d_chain_stats, 0, 8 * sizeof(int32_t), st));
+            CJ.chain_scans = c->d_chain_scans;
+            CJ.walkers = c->d_chain_walkers;
+            CJ.chain_first_walker = c->d_chain_fw;
+            CJ.n_walkers = nw;
+            CJ.n_chains = (int)fw.size() - 1;
+            CJ.ws = c->chain_geom;
+            CJ.ws.base = (unsigned char*)c->chain_ws;
+            CJ.stats = c->d_chain_stats;
+            CJ.words = (c->A.max_scan_pts + 31) / 32 + 1;
+            const size_t lds_bits = 88 * 1024;  // next to the 64 KB of sampled keys
+            int ev = (int)(lds_bits / ((size_t)CJ.words * 4));
+            CJ.n_eval_waves = ev < 1 ? 1 : (ev > 16 ? 16 : ev);
+            if ((size_t)CJ.words * 4 > lds_bits) return fail(c, SCVOD_ERR_CAPACITY, "scan too large for the chain's LDS bitset");
+            c->chain_ran = true;
+        }
+    }
+    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, c->tables_valid ? 2 : 3, st, timer_hook, c, c->chain_ran ? &CJ : nullptr);
     HIPCHK(c, hipGetLastError());
     c->tables_valid = true;
     c->track_valid = true;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
+}
+
+int scvod_set_track_mode(scvod_ctx* c, int32_t mode, int32_t segment_steps, int32_t warmup_steps) {
+    if (!c || (mode != SCVOD_TRACK_CHAIN && mode != SCVOD_TRACK_FIRST_ORDER)) return fail(c, SCVOD_ERR_INVALID, "unknown tracking mode");
+    if (segment_steps < 0 || warmup_steps < 0) return fail(c, SCVOD_ERR_INVALID, "negative segment / warm-up length");
+    c->track_mode = mode;
+    if (segment_steps > 0) c->chain_seg = segment_steps;
+    if (segment_steps > 0 || warmup_steps > 0) c->chain_warm = warmup_steps;
+    c->track_valid = false;
+    return SCVOD_OK;
+}
+
+// error bits / counters of the chain of the last scvod_batch_track (synchronises its stream)
+static int chain_status(scvod_ctx* c, int32_t out[8]) {
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!c->chain_ran) return SCVOD_OK;
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    HIPCHK(c, hipMemcpy(out, c->d_chain_stats, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out[0])
+        return fail(c, SCVOD_ERR_CAPACITY, "tracking chain overflow (bits %d: 1 appended clouds > %d points, 2 more than %d clusters, 4 created labels, 8 table > bitset)",
+                    out[0], c->chain_geom.cap_pool, c->chain_geom.cap_ent);
+    return SCVOD_OK;
+}
+
+int scvod_batch_track_stats(scvod_ctx* c, int32_t* h_out8) {
+    if (!c || !h_out8) return SCVOD_ERR_INVALID;
+    if (!c->track_valid) return fail(c, SCVOD_ERR_STATE, "no tracking result for the last batch");
+    int32_t st[8];
+    const int rc = chain_status(c, st);
+    h_out8[0] = c->chain_ran ? SCVOD_TRACK_CHAIN : SCVOD_TRACK_FIRST_ORDER;
+    h_out8[1] = (int32_t)(c->up_chain_walkers.size() / 8) * (c->chain_ran ? 1 : 0);
+    h_out8[2] = st[2];
+    h_out8[3] = st[1];
+    h_out8[4] = st[0];
+    h_out8[5] = c->chain_seg;
+    h_out8[6] = c->chain_warm;
+    h_out8[7] = 0;
+    return rc;
 }
 
 int scvod_batch_track_tables(scvod_ctx* c, void* stream) {
@@ -1056,12 +1254,16 @@ int scvod_batch_fetch_track(scvod_ctx* c, int32_t s, scvod_track_result* out) {
     if (rc) return rc;
     if (s < 0 || s >= c->A.n_scans) return fail(c, SCVOD_ERR_INVALID, "scan %d out of range", s);
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    {
+        int32_t cst[8];
+        if ((rc = chain_status(c, cst))) return rc;
+    }
     const Arena& A = c->A;
     const size_t base = (size_t)c->h_scan_off[s];
     const int n = c->h_counts[(size_t)s * 8 + 4];
     int32_t sc[4];
     HIPCHK(c, hipMemcpy(sc, A.tk_scan + (size_t)s * 4, sizeof(sc), hipMemcpyDeviceToHost));
-    const int ncl = sc[0];
+    const int ncl = sc[0] < 0 ? 0 : (sc[0] > n ? n : sc[0]);
     memset(out, 0, sizeof(*out));
     out->n_apri = n;
     out->n_clusters = ncl;
@@ -1158,10 +1360,6 @@ int scvod_sequence_ingest(scvod_ctx* c, const float* h_xyzi, const int32_t* h_sc
     if (off_need > c->ingest_off_cap) {
         HIPCHK(c, hipDeviceSynchronize());
         if (c->ingest_off) hipHostFree(c->ingest_off);
-    for (UploadSlot& u : c->up_ring) {
-        if (u.pinned) hipHostFree(u.pinned);
-        if (u.ev) hipEventDestroy(u.ev);
-    }
         c->ingest_off = nullptr;
         c->ingest_off_cap = 0;
         HIPCHK(c, hipHostMalloc((void**)&c->ingest_off, sizeof(int32_t) * off_need, hipHostMallocDefault));

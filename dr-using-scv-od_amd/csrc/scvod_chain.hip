@@ -1,0 +1,738 @@
+// scvod_chain.hip -- the SEQUENTIAL chain of SSC::tracking on the device (gfx950, wave64).
+//
+// Reference: SSC::segDF runs tracking(frame i, frame i + 1) in order (/root/reference/src/ssc.cpp:1449-1451) and every call
+// mutates the successor before the next call walks it as `pre`:
+//   * one label, ratio >= occupancy, successor cluster a car  -> the walked cluster's TRANSFORMED cloud is appended to the
+//     successor cluster's cloud (ssc.cpp:1378-1384): the next call re-bins those points too (they are transformed again);
+//   * one label, ratio < occupancy, successor cluster not a car -> the hit voxels are split off into a new cluster
+//     (ssc.cpp:1351-1372): later clusters of the same call see the new label and the reduced |occupy_voxels|;
+//   * several labels -> the car clusters hit at or above the ratio are fused into one new car cluster (ssc.cpp:1396-1419):
+//     its cloud is cloud_use of the fused members (appended clouds are dropped), it is walked by the next call after the
+//     original clusters (name = max_name++).
+// scvod_track.hip takes every cluster against the successor's FRESH segmentation (first order, all pairs in parallel) and
+// leaves, per car cluster, the sorted unique hit list, remap_name and the first-order state.  This file replays the chain
+// on top of that: a walker (one workgroup) steps through the frames of a sequence in order, carries the appended clouds
+// (a pool of points re-transformed at every step with the explicit fp32 products of utility.h:401-404), evaluates only
+// what the first-order pass could not know -- clusters that carry appended points, fused clusters, and clusters whose hit
+// labels an earlier cluster of the same call re-labelled -- and applies the re-labelling through stamped override words
+// (no table is copied or cleared per step).  cluster_set is walked in ascending canonical name, created clusters after
+// the original ones in creation order (the reference's order is that of ITS names in ITS unordered_map: DESIGN.md 2).
+//
+// The chain is sequential per sequence (552 steps for seq 05 with skip_ 5), so it is cut into SEGMENTS walked
+// concurrently: the walker of steps [a, b) starts `warm` steps earlier from the fresh state of that frame; appended
+// points live a dozen frames, so its state at step a normally equals the true one.  That is CHECKED, not assumed: a
+// second kernel compares the state the previous segment really ended in with the warm-up's snapshot (entries, parts,
+// every carried coordinate, bit for bit) and re-walks the segment from the true state when they differ.  The result is
+// the sequential chain's, whatever the warm-up length.
+#include "scvod_chain.h"
+
+namespace scvod {
+
+namespace {
+
+constexpr int kChThreads = 1024;
+constexpr int kChWaves = kChThreads / 64;
+constexpr int kChSamples = 16384;  // sampled successor keys in LDS (64 KB)
+
+typedef unsigned long long u64;
+
+struct Wk {  // a walker's workspace
+    int32_t* hdr;
+    int4* ent[3];
+    int32_t* parts[3];
+    float4* pool[3];
+    int32_t* chit;
+    int2* evr;
+    int32_t* suniq;
+    int2* spairs;
+    u64* vlab;
+    u64* lcnt;
+    u64* lfwd;
+    int32_t* newent;
+    int4* cmeta;
+    int32_t* cparts;
+    int4* links;
+    int32_t* dsz;
+    int32_t* eidx;
+    int2* rp;
+};
+
+__device__ __forceinline__ Wk wk_of(const ChainWs& S, int w) {
+    unsigned char* b = S.base + (size_t)w * S.stride;
+    Wk k;
+    k.hdr = (int32_t*)(b + S.off_hdr);
+    for (int i = 0; i < 3; ++i) {
+        k.ent[i] = (int4*)(b + S.off_ent[i]);
+        k.parts[i] = (int32_t*)(b + S.off_parts[i]);
+        k.pool[i] = (float4*)(b + S.off_pool[i]);
+    }
+    k.chit = (int32_t*)(b + S.off_chit);
+    k.evr = (int2*)(b + S.off_evr);
+    k.suniq = (int32_t*)(b + S.off_suniq);
+    k.spairs = (int2*)(b + S.off_spairs);
+    k.vlab = (u64*)(b + S.off_vlab);
+    k.lcnt = (u64*)(b + S.off_lcnt);
+    k.lfwd = (u64*)(b + S.off_lfwd);
+    k.newent = (int32_t*)(b + S.off_newent);
+    k.cmeta = (int4*)(b + S.off_cmeta);
+    k.cparts = (int32_t*)(b + S.off_cparts);
+    k.links = (int4*)(b + S.off_links);
+    k.dsz = (int32_t*)(b + S.off_dsz);
+    k.eidx = (int32_t*)(b + S.off_eidx);
+    k.rp = (int2*)(b + S.off_rp);
+    return k;
+}
+
+// header words of a walker
+enum { H_EPOCH = 0, H_END_SLOT = 1, H_HAS_SNAP = 2, H_NENT = 4 /* [3] */, H_NCARRIED = 8 /* [3] */, H_NPARTS = 12 /* [3] */ };
+
+__device__ __forceinline__ int wmin_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int wmax_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ int wsum_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// volatile views: the override words are written and read back by different lanes of one wave inside a step
+__device__ __forceinline__ u64 ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int ld32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st32(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+struct StepEnv {  // the successor as the current step sees it
+    const int4* tab;        // fresh records {key, label, |occupy_voxels|, type}
+    const int32_t* rep;     // fresh label ids
+    int nv;
+    uint32_t epoch;
+    u64* vlab;
+    u64* lcnt;
+    u64* lfwd;
+};
+__device__ __forceinline__ bool stamped(u64 w, uint32_t epoch) { return (uint32_t)(w >> 32) == epoch; }
+
+// label id a voxel of the successor carries NOW (split voxels are overridden one by one, fused labels are forwarded)
+__device__ __forceinline__ int cur_label(const StepEnv& E, int u) {
+    const u64 o = ld64(&E.vlab[u]);
+    int id = stamped(o, E.epoch) ? (int)(uint32_t)o : E.rep[u];
+    while (id >= 0) {
+        const u64 f = ld64(&E.lfwd[id]);
+        if (!stamped(f, E.epoch)) break;
+        id = (int)(uint32_t)f;
+    }
+    return id;
+}
+// |occupy_voxels| (low 28 bits) and type (bits 28..29) of a label NOW
+__device__ __forceinline__ uint32_t cur_cnttype(const StepEnv& E, int id) {
+    const u64 c = ld64(&E.lcnt[id]);
+    if (stamped(c, E.epoch)) return (uint32_t)c;
+    const int4 r = E.tab[id];  // id < nv: a voxel of that label
+    return (uint32_t)r.z | ((uint32_t)r.w << 28);
+}
+__device__ __forceinline__ bool label_dirty(const StepEnv& E, int id) {
+    return stamped(ld64(&E.lcnt[id]), E.epoch) || stamped(ld64(&E.lfwd[id]), E.epoch);
+}
+
+__device__ __forceinline__ int lower_bound_i(const int32_t* a, int n, int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+struct Shared {
+    int32_t skeys[kChSamples];
+    int32_t wsum[kChWaves + 1];
+    int32_t bc[8];  // broadcast words
+};
+
+// copies state `src` of walker workspace A to state `dst` of workspace B (all threads)
+__device__ void copy_state(const Wk& A, int src, const Wk& B, int dst) {
+    const int ne = A.hdr[H_NENT + src], nc = A.hdr[H_NCARRIED + src], np = A.hdr[H_NPARTS + src];
+    for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) B.ent[dst][i] = A.ent[src][i];
+    for (int i = threadIdx.x; i < np; i += kChThreads) B.parts[dst][i] = A.parts[src][i];
+    for (int i = threadIdx.x; i < nc; i += kChThreads) B.pool[dst][i] = A.pool[src][i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        B.hdr[H_NENT + dst] = ne;
+        B.hdr[H_NCARRIED + dst] = nc;
+        B.hdr[H_NPARTS + dst] = np;
+    }
+    __syncthreads();
+}
+
+// bit-for-bit comparison of two states (all threads); returns true when they are equal
+__device__ bool same_state(const Wk& A, int sa, const Wk& B, int sb) {
+    const int ne = A.hdr[H_NENT + sa], nc = A.hdr[H_NCARRIED + sa], np = A.hdr[H_NPARTS + sa];
+    int diff = (ne != B.hdr[H_NENT + sb]) || (nc != B.hdr[H_NCARRIED + sb]) || (np != B.hdr[H_NPARTS + sb]);
+    if (!diff) {
+        for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) {
+            const int4 x = A.ent[sa][i], y = B.ent[sb][i];
+            diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+        }
+        for (int i = threadIdx.x; i < np; i += kChThreads) diff |= A.parts[sa][i] != B.parts[sb][i];
+        for (int i = threadIdx.x; i < nc; i += kChThreads) {
+            const float4 x = A.pool[sa][i], y = B.pool[sb][i];
+            diff |= (__float_as_uint(x.x) != __float_as_uint(y.x)) | (__float_as_uint(x.y) != __float_as_uint(y.y)) |
+                    (__float_as_uint(x.z) != __float_as_uint(y.z));
+        }
+    }
+    return __syncthreads_or(diff) == 0;
+}
+
+// the freshly segmented car clusters of scan s as a state: one entry per cluster, nothing carried
+__device__ void fresh_state(const Arena& A, const Wk& K, int slot, int s, int cap_ent, int32_t* stats) {
+    const int base = A.scan_off[s];
+    int ncar = A.tk_scan[s * 4 + 0];
+    if (ncar > cap_ent) {
+        if (threadIdx.x == 0) atomicOr(&stats[0], 2);
+        ncar = cap_ent;
+    }
+    __shared__ int32_t fs_wsum[kChWaves + 1];
+    int run = 0;
+    for (int o0 = 0; o0 < ncar; o0 += kChThreads) {
+        const int o = o0 + threadIdx.x;
+        int own = 0;
+        if (o < ncar) own = A.cl_count[(size_t)base + A.tk_clusters[(size_t)base + o]];
+        int total;
+        const int ex = block_excl_scan<kChThreads>(own, total, fs_wsum);
+        if (o < ncar) {
+            K.ent[slot][2 * o] = make_int4(o, 1, 0, 0);
+            K.ent[slot][2 * o + 1] = make_int4(own, run + ex, 0, 0);
+            K.parts[slot][o] = o;
+        }
+        run += total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        K.hdr[H_NENT + slot] = ncar;
+        K.hdr[H_NCARRIED + slot] = 0;
+        K.hdr[H_NPARTS + slot] = ncar;
+    }
+    __syncthreads();
+}
+
+// One step of the chain: SSC::tracking(frame si, frame sj) on the state in slot `cur`; leaves the successor's state (as the
+// next `pre`) in slot cur ^ 1.  write_out: states / dynamic counters of frame si are the chain's result (not warm-up).
+__device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
+                           uint32_t* bits_all, int cur, int si, int sj, bool write_out, int from_apri) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base_i = A.scan_off[si], base_j = A.scan_off[sj];
+    const int nv = A.counts[sj * 8 + 6];
+    const int ncar_j = min(A.tk_scan[sj * 4 + 0], C.ws.cap_ent);
+    const int4* tab = A.vox_track + base_j;
+    const int nent = K.hdr[H_NENT + cur];
+    const int ncarried = K.hdr[H_NCARRIED + cur];
+    const int4* ent = K.ent[cur];
+    const int32_t* parts = K.parts[cur];
+    float4* pool = K.pool[cur];
+    const int nxt = cur ^ 1;
+    StepEnv E;
+    E.tab = tab;
+    E.rep = A.vox_rep + base_j;
+    E.nv = nv;
+    E.vlab = K.vlab;
+    E.lcnt = K.lcnt;
+    E.lfwd = K.lfwd;
+    if (tid == 0) K.hdr[H_EPOCH] = K.hdr[H_EPOCH] + 1;
+    __syncthreads();
+    E.epoch = (uint32_t)K.hdr[H_EPOCH];
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = J.T[12 * si + i];
+
+    // ---- phase 1: the carried points move into the successor's frame and are looked up there ----
+    if (ncarried > 0) {
+        int shift = 0;
+        while (((nv + (1 << shift) - 1) >> shift) > kChSamples) ++shift;
+        const int ns = (nv + (1 << shift) - 1) >> shift;
+        for (int j = tid; j < ns; j += kChThreads) sh.skeys[j] = tab[(size_t)j << shift].x;
+        __syncthreads();
+        for (int c = tid; c < ncarried; c += kChThreads) {
+            const float4 q = pool[c];
+            // Utility::transformCloud (utility.h:401-404): explicit fp32 dot products, no FMA
+            const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
+            const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
+            const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
+            pool[c] = make_float4(x, y, z, q.w);
+            Apri a;
+            apri_of_point(P.bin, x, y, z, q.w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
+            const int key = a.voxel_idx;
+            int lo = 0, hi = ns;  // first sample > key
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sh.skeys[mid] <= key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            int slot = -1;
+            if (lo > 0) {
+                int a0 = (lo - 1) << shift;
+                const int a1 = min(a0 + (1 << shift), nv);
+                for (; a0 < a1; ++a0) {
+                    const int4 rec = tab[a0];
+                    if (rec.x >= key) {
+                        if (rec.x == key && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
+                        break;
+                    }
+                }
+            }
+            K.chit[c] = slot;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: entries the first-order pass could not decide (appended points, fused clusters): sorted unique hit list
+    // (sampleVec) through a bitset over the successor's table, then remap_name against the FRESH labels ----
+    {
+        const int words = C.words;
+        const int nw = (nv + 31) >> 5;
+        if (nw > words) {  // table larger than the bitsets were sized for: flagged, the entries count as hitting nothing
+            if (tid == 0) atomicOr(&C.stats[0], 8);
+            for (int k = tid; k < nent; k += kChThreads) K.evr[k] = make_int2(0, 0);
+        } else if (wave < C.n_eval_waves) {
+            uint32_t* bits = bits_all + (size_t)wave * words;
+            int cx = 0;
+            for (int k = 0; k < nent; ++k) {
+                const int4 e0 = ent[2 * k];
+                if (e0.y == 1 && e0.w == 0) continue;  // one original cluster, nothing appended: scvod_track.hip's result stands
+                if ((cx++ % C.n_eval_waves) != wave) continue;
+                const int4 e1 = ent[2 * k + 1];
+                int wlo = 0x7fffffff, whi = -1;
+                for (int p = 0; p < e0.y; ++p) {
+                    const int root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
+                    const int mb = A.tk_mbegin[(size_t)base_i + root];
+                    const int nu = A.tk_nuniq[(size_t)base_i + root];
+                    for (int j = lane; j < nu; j += 64) {
+                        const int slot = A.tk_uniq[(size_t)base_i + mb + j];
+                        atomicOr(&bits[slot >> 5], 1u << (slot & 31));
+                        wlo = min(wlo, slot >> 5);
+                        whi = max(whi, slot >> 5);
+                    }
+                }
+                for (int c = lane; c < e0.w; c += 64) {
+                    const int slot = K.chit[e0.z + c];
+                    if (slot >= 0) {
+                        atomicOr(&bits[slot >> 5], 1u << (slot & 31));
+                        wlo = min(wlo, slot >> 5);
+                        whi = max(whi, slot >> 5);
+                    }
+                }
+                wlo = wmin_i(wlo);
+                whi = wmax_i(whi);
+                wave_sync();
+                int32_t* uq = K.suniq + e1.y + e0.z;  // region of own points + carried points of the entry
+                int2* pr = K.spairs + e1.y + e0.z;
+                int U = 0;
+                for (int w0 = wlo; w0 <= whi; w0 += 64) {
+                    const int w = w0 + lane;
+                    uint32_t word = 0u;
+                    if (w <= whi) {
+                        word = bits[w];
+                        bits[w] = 0u;
+                    }
+                    const int c = __popc(word);
+                    const int inc = wave_incl_scan(c);
+                    int o = U + inc - c;
+                    while (word) {
+                        const int b = __ffs(word) - 1;
+                        word &= word - 1;
+                        uq[o++] = (w << 5) + b;
+                    }
+                    U += __shfl(inc, 63);
+                }
+                wave_sync();
+                int npairs = 0, curid = -1;
+                for (;;) {
+                    int mn = 0x7fffffff;
+                    for (int j = lane; j < U; j += 64) {
+                        const int id = E.rep[uq[j]];
+                        if (id > curid) mn = min(mn, id);
+                    }
+                    mn = wmin_i(mn);
+                    if (mn == 0x7fffffff) break;
+                    int cnt = 0;
+                    for (int j = lane; j < U; j += 64) cnt += E.rep[uq[j]] == mn ? 1 : 0;
+                    cnt = wsum_i(cnt);
+                    if (lane == 0) pr[npairs] = make_int2(mn, cnt);
+                    ++npairs;
+                    curid = mn;
+                }
+                if (lane == 0) K.evr[k] = make_int2(npairs, U);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: the clusters in walking order, one wave: decision against the successor AS IT IS NOW, re-labelling ----
+    int nl = 0, n_newlab = 0, n_created = 0, n_cparts = 0;
+    if (wave == 0) {
+        int n_dirty = 0, ndc = 0, ndp = 0;
+        const int32_t* car_j = A.tk_clusters + base_j;
+        for (int k = 0; k < nent; ++k) {
+            const int4 e0 = ent[2 * k];
+            const int4 e1 = ent[2 * k + 1];
+            const bool simple = (e0.y == 1 && e0.w == 0);
+            int np, nu;
+            const int32_t* uq;
+            const int2* pr;        // simple: {label name, count} + ids in prid; otherwise {id, count}
+            const int32_t* prid;
+            if (simple) {
+                const int root = A.tk_clusters[(size_t)base_i + parts[e0.x]];
+                const int mb = A.tk_mbegin[(size_t)base_i + root];
+                np = A.tk_npairs[(size_t)base_i + root];
+                nu = A.tk_nuniq[(size_t)base_i + root];
+                uq = A.tk_uniq + (size_t)base_i + mb;
+                pr = A.tk_pairs + (size_t)base_i + mb;
+                prid = A.tk_prep + (size_t)base_i + mb;
+            } else {
+                const int2 r = K.evr[k];
+                np = r.x;
+                nu = r.y;
+                uq = K.suniq + e1.y + e0.z;
+                pr = K.spairs + e1.y + e0.z;
+                prid = nullptr;
+            }
+            bool stale = false;
+            if (n_dirty) {
+                for (int p = lane; p < np; p += 64) stale |= label_dirty(E, prid ? prid[p] : pr[p].x);
+                stale = __any(stale);
+            }
+            if (stale) {  // an earlier cluster of this call re-labelled something this one hits: remap_name over the current labels
+                int np2 = 0, curid = -1;
+                for (;;) {
+                    int mn = 0x7fffffff;
+                    for (int j = lane; j < nu; j += 64) {
+                        const int id = cur_label(E, uq[j]);
+                        if (id > curid) mn = min(mn, id);
+                    }
+                    mn = wmin_i(mn);
+                    if (mn == 0x7fffffff) break;
+                    int cnt = 0;
+                    for (int j = lane; j < nu; j += 64) cnt += cur_label(E, uq[j]) == mn ? 1 : 0;
+                    cnt = wsum_i(cnt);
+                    if (lane == 0) K.rp[np2] = make_int2(mn, cnt);
+                    ++np2;
+                    curid = mn;
+                }
+                wave_sync();
+                np = np2;
+                pr = K.rp;
+                prid = nullptr;
+            }
+            int state = -1;
+            if (np == 0) {
+                state = 1;  // ssc.cpp:1323-1326
+            } else if (np == 1) {
+                const int L = prid ? prid[0] : pr[0].x;
+                const int c = pr[0].y;
+                const uint32_t ct = cur_cnttype(E, L);
+                const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
+                const float ratio = (float)c / (float)nvx;  // ssc.cpp:1336
+                if (ratio < J.occupancy) {
+                    if (typ == 2) {
+                        state = 1;  // ssc.cpp:1337-1349
+                    } else {       // ssc.cpp:1351-1372: the hit voxels leave the label for a new cluster of the same type
+                        state = 0;
+                        const int Y = nv + n_newlab;
+                        if (n_newlab < C.ws.cap_ent) {
+                            for (int j = lane; j < nu; j += 64)
+                                if (cur_label(E, uq[j]) == L) st64(&E.vlab[uq[j]], ((u64)E.epoch << 32) | (uint32_t)Y);
+                            if (lane == 0) {
+                                st64(&E.lcnt[L], ((u64)E.epoch << 32) | (uint32_t)(nvx - c) | ((uint32_t)typ << 28));
+                                st64(&E.lcnt[Y], ((u64)E.epoch << 32) | (uint32_t)c | ((uint32_t)typ << 28));
+                                st32(&K.newent[n_newlab], -1);
+                            }
+                            ++n_newlab;
+                            ++n_dirty;
+                        } else if (lane == 0) {
+                            atomicOr(&C.stats[0], 4);
+                        }
+                        wave_sync();
+                    }
+                } else if (typ == 2) {  // ssc.cpp:1377-1384: static, its transformed cloud joins the successor cluster's cloud
+                    state = 0;
+                    int dst;
+                    if (L < nv) {
+                        const int o = lower_bound_i(car_j, ncar_j, tab[L].y);
+                        dst = o;
+                    } else {
+                        dst = ncar_j + ld32(&K.newent[L - nv]);
+                    }
+                    if (nl < C.ws.cap_ent) {
+                        if (lane == 0) K.links[nl] = make_int4(k, dst, e1.x + e0.w, 0);
+                        ++nl;
+                    } else if (lane == 0) {
+                        atomicOr(&C.stats[0], 2);
+                    }
+                }
+            } else {  // ssc.cpp:1396-1419: the car clusters hit at or above the ratio fuse into one new car cluster
+                state = 0;
+                if (n_newlab < C.ws.cap_ent && n_created < C.ws.cap_ent) {
+                    const int N = nv + n_newlab;
+                    const int q = n_created;
+                    const int cbeg = n_cparts;
+                    int cntN = 0;
+                    for (int p = 0; p < np; ++p) {
+                        const int L = prid ? prid[p] : pr[p].x;
+                        const int c = pr[p].y;
+                        const uint32_t ct = cur_cnttype(E, L);
+                        const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
+                        if (typ != 2 || !((float)c / (float)nvx >= J.occupancy)) continue;
+                        if (L < nv) {
+                            const int o = lower_bound_i(car_j, ncar_j, tab[L].y);
+                            if (n_cparts < C.ws.cap_ent) {
+                                if (lane == 0) st32(&K.cparts[n_cparts], o);
+                                ++n_cparts;
+                            }
+                        } else {
+                            const int4 m = K.cmeta[ld32(&K.newent[L - nv])];
+                            for (int z = 0; z < m.y; ++z) {
+                                if (n_cparts < C.ws.cap_ent) {
+                                    if (lane == 0) st32(&K.cparts[n_cparts], ld32(&K.cparts[m.x + z]));
+                                    ++n_cparts;
+                                }
+                            }
+                        }
+                        if (lane == 0) st64(&E.lfwd[L], ((u64)E.epoch << 32) | (uint32_t)N);
+                        cntN += nvx;
+                        wave_sync();
+                    }
+                    if (lane == 0) {
+                        st64(&E.lcnt[N], ((u64)E.epoch << 32) | (uint32_t)(cntN & 0x0fffffff) | (2u << 28));
+                        st32(&K.newent[n_newlab], q);
+                        K.cmeta[q] = make_int4(cbeg, n_cparts - cbeg, N, 0);
+                    }
+                    ++n_newlab;
+                    ++n_created;
+                    ++n_dirty;
+                    wave_sync();
+                } else if (lane == 0) {
+                    atomicOr(&C.stats[0], 4);
+                }
+            }
+            if (write_out) {
+                for (int p = lane; p < e0.y; p += 64) {
+                    const int root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
+                    A.cl_state[(size_t)base_i + root] = (int8_t)state;
+                }
+                if (state == 1) {
+                    ++ndc;
+                    ndp += e1.x;
+                }
+            }
+        }
+        if (write_out && lane == 0) {
+            A.tk_scan[si * 4 + 2] = ndc;
+            A.tk_scan[si * 4 + 3] = ndp;
+        }
+        wave_sync();
+
+        // ---- the successor as the next `pre`: its car clusters that are still there in ascending name, then the created ones in
+        // creation order; every one with the clouds appended to it ----
+        const int ntot = ncar_j + n_created;
+        for (int e = lane; e < ntot; e += 64) K.dsz[e] = 0;
+        wave_sync();
+        if (lane == 0)
+            for (int l = 0; l < nl; ++l) {
+                const int4 L = K.links[l];
+                K.dsz[L.y] += L.z;
+            }
+        wave_sync();
+        int4* nent_rec = K.ent[nxt];
+        int32_t* nparts = K.parts[nxt];
+        int run_e = 0, run_c = 0, run_p = 0, run_o = 0;
+        for (int eb = 0; eb < ntot; eb += 64) {
+            const int e = eb + lane;
+            bool alive = false;
+            int pc = 0, own = 0, csz = 0, pbeg_src = 0;
+            if (e < ncar_j) {
+                const int id = A.tk_crep[(size_t)base_j + e];
+                alive = id >= 0 && !stamped(ld64(&E.lfwd[id]), E.epoch);
+                pc = 1;
+                own = A.cl_count[(size_t)base_j + car_j[e]];
+            } else if (e < ntot) {
+                const int4 m = K.cmeta[e - ncar_j];
+                alive = !stamped(ld64(&E.lfwd[m.z]), E.epoch);
+                pc = m.y;
+                pbeg_src = m.x;
+                for (int z = 0; z < m.y; ++z) own += A.cl_count[(size_t)base_j + car_j[ld32(&K.cparts[m.x + z])]];
+            }
+            if (e < ntot) csz = K.dsz[e];
+            if (!alive) pc = own = csz = 0;
+            const int ie = wave_incl_scan(alive ? 1 : 0), ic = wave_incl_scan(csz), ip = wave_incl_scan(pc), io = wave_incl_scan(own);
+            if (e < ntot) K.eidx[e] = alive ? run_e + ie - 1 : -1;
+            if (alive) {
+                const int idx = run_e + ie - 1;
+                if (idx < C.ws.cap_ent && run_p + ip <= C.ws.cap_ent) {
+                    nent_rec[2 * idx] = make_int4(run_p + ip - pc, pc, run_c + ic - csz, csz);
+                    nent_rec[2 * idx + 1] = make_int4(own, run_o + io - own, 0, 0);
+                    if (e < ncar_j) {
+                        nparts[run_p + ip - pc] = e;
+                    } else {
+                        for (int z = 0; z < pc; ++z) nparts[run_p + ip - pc + z] = ld32(&K.cparts[pbeg_src + z]);
+                    }
+                }
+            }
+            run_e += __shfl(ie, 63);
+            run_c += __shfl(ic, 63);
+            run_p += __shfl(ip, 63);
+            run_o += __shfl(io, 63);
+        }
+        bool overflow = run_c > C.ws.cap_pool || run_e > C.ws.cap_ent || run_p > C.ws.cap_ent;
+        if (overflow) {  // the state does not fit: flagged, the chain continues without the appended clouds
+            if (lane == 0) atomicOr(&C.stats[0], run_c > C.ws.cap_pool ? 1 : 2);
+            run_c = 0;
+            run_e = min(run_e, C.ws.cap_ent);
+            run_p = min(run_p, C.ws.cap_ent);
+        }
+        wave_sync();
+        if (lane == 0) {
+            // offsets of the appended clouds inside their cluster's region: in walking order of the sources
+            for (int e = 0; e < ntot; ++e) K.dsz[e] = 0;  // cursors
+            for (int l = 0; l < nl; ++l) {
+                int4 L = K.links[l];
+                const int idx = K.eidx[L.y];
+                if (idx < 0 || overflow) {
+                    L.w = -1;  // fused later in the same call (cloud_use only, ssc.cpp:1412) or dropped
+                } else {
+                    L.w = nent_rec[2 * idx].z + K.dsz[L.y];
+                    K.dsz[L.y] += L.z;
+                }
+                K.links[l] = L;
+            }
+            if (overflow)
+                for (int i = 0; i < run_e; ++i) {
+                    int4 r = nent_rec[2 * i];
+                    r.z = r.w = 0;
+                    nent_rec[2 * i] = r;
+                }
+            K.hdr[H_NENT + nxt] = run_e;
+            K.hdr[H_NCARRIED + nxt] = run_c;
+            K.hdr[H_NPARTS + nxt] = run_p;
+            sh.bc[0] = nl;
+        }
+    }
+    __syncthreads();
+    nl = sh.bc[0];
+
+    // ---- phase 4: the appended clouds: cloud_use of the walked cluster's parts, transformed, then what it carried ----
+    float4* npool = K.pool[nxt];
+    for (int l = 0; l < nl; ++l) {
+        const int4 L = K.links[l];
+        if (L.w < 0) continue;
+        const int4 e0 = ent[2 * L.x];
+        int off = L.w;
+        for (int p = 0; p < e0.y; ++p) {
+            const int root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
+            const int mb = A.tk_mbegin[(size_t)base_i + root];
+            const int cnt = A.cl_count[(size_t)base_i + root];
+            for (int m = tid; m < cnt; m += kChThreads) {
+                const int i = A.tk_members[(size_t)base_i + mb + m];
+                float4 q;
+                if (!from_apri) {
+                    q = A.pts[base_i + A.apri_src[(size_t)base_i + i]];
+                } else {
+                    const scvod_apri& a = A.apri[(size_t)base_i + i];
+                    q = make_float4(a.x, a.y, a.z, a.intensity);
+                }
+                const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
+                const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
+                const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
+                npool[off + m] = make_float4(x, y, z, q.w);
+            }
+            off += cnt;
+        }
+        for (int c = tid; c < e0.w; c += kChThreads) npool[off + c] = pool[e0.z + c];
+    }
+    __syncthreads();
+}
+
+// walks steps [t_begin, t_end) of a chain on workspace K starting from the state in slot `cur`; returns the slot of the final state
+__device__ int walk(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
+                    uint32_t* bits, const ChainWalker& W, int cur, int t_begin, int t_end, int out_from, int snap_at, int from_apri) {
+    const int32_t* frames = C.chain_scans + W.first;
+    for (int t = t_begin; t < t_end; ++t) {
+        if (t == snap_at) {
+            copy_state(K, cur, K, 2);
+            if (threadIdx.x == 0) K.hdr[H_HAS_SNAP] = 1;
+        }
+        chain_step(P, A, J, C, K, sh, bits, cur, frames[t], frames[t + 1], t >= out_from, from_apri);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+}  // namespace
+
+// speculative pass: one workgroup per segment, warm-up from the fresh state of an earlier frame
+__global__ __launch_bounds__(kChThreads) void k_tk_chain(DevParams P, Arena A, TrackBatch J, ChainJob C, int from_apri) {
+    __shared__ Shared sh;
+    extern __shared__ uint32_t ch_bits[];
+    const ChainWalker W = C.walkers[blockIdx.x];
+    const Wk K = wk_of(C.ws, blockIdx.x);
+    for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
+    if (threadIdx.x == 0) K.hdr[H_HAS_SNAP] = 0;
+    __syncthreads();
+    fresh_state(A, K, 0, C.chain_scans[W.first + W.t0], C.ws.cap_ent, C.stats);
+    const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.t0, W.b, W.a, W.t0 < W.a ? W.a : -1, from_apri);
+    if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
+}
+
+// verification pass: one workgroup per chain; a segment whose warm-up did not reproduce the state its predecessor really
+// ended in is walked again from that state
+__global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena A, TrackBatch J, ChainJob C, int from_apri) {
+    __shared__ Shared sh;
+    extern __shared__ uint32_t ch_bits[];
+    for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
+    __syncthreads();
+    const int w0 = C.chain_first_walker[blockIdx.x], w1 = C.chain_first_walker[blockIdx.x + 1];
+    for (int w = w0 + 1; w < w1; ++w) {
+        const ChainWalker W = C.walkers[w];
+        const Wk K = wk_of(C.ws, w), Kp = wk_of(C.ws, w - 1);
+        const int pend = Kp.hdr[H_END_SLOT];
+        bool ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, pend, K, 2);
+        if (threadIdx.x == 0) atomicAdd(&C.stats[2], 1);
+        if (ok) continue;
+        if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
+        copy_state(Kp, pend, K, 0);
+        const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.a, W.b, W.a, -1, from_apri);
+        if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
+        __syncthreads();
+    }
+}
+
+void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st,
+                        TimerHook th, void* tu) {
+    if (C.n_walkers <= 0) return;
+    const size_t dyn = (size_t)C.n_eval_waves * C.words * 4;
+    hipFuncSetAttribute((const void*)k_tk_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipFuncSetAttribute((const void*)k_tk_chain_fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (th) th(tu, "tk_chain", 1);
+    hipLaunchKernelGGL(k_tk_chain, dim3(C.n_walkers), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
+    if (th) th(tu, "tk_chain", 0);
+    if (th) th(tu, "tk_chain_fix", 1);
+    hipLaunchKernelGGL(k_tk_chain_fix, dim3(C.n_chains), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
+    if (th) th(tu, "tk_chain_fix", 0);
+}
+
+}  // namespace scvod

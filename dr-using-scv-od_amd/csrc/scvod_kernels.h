@@ -119,6 +119,10 @@ struct Arena {
     int4* vox_track;          // [N] per voxel: {key, label = cluster root of its points or -1, |occupy_voxels| of that
                               //     cluster, its type}: the table the probe of the PREVIOUS scan runs against; also the
                               //     boundary message between sequence shards (scvod_batch_export_table)
+    int32_t* vox_rep;         // [N] per voxel: lowest voxel slot of the scan that carries the same label (-1: unlabelled): the
+                              //     label's id in the sequential tracking chain (scvod_chain.hip)
+    int32_t* tk_crep;         // [N] per scan: that id for each car cluster, in the order of tk_clusters
+    int32_t* tk_prep;         // [N] per cluster region, parallel to tk_pairs: the id of the pair's label
     int8_t* cl_state;         // [N] per cluster root: Cluster::state (-1 untouched, 0 static, 1 dynamic)
     int32_t* tk_mbegin;       // [N] per car root: first slot of its members in tk_members (scan-local)
     int32_t* tk_cursor;       // [N] per car root: scatter cursor
@@ -193,8 +197,9 @@ void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream
 void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
+struct ChainJob;
 void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
-                        TimerHook th, void* tu);
+                        TimerHook th, void* tu, const ChainJob* chain = nullptr);
 void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
                float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work, int bounded,

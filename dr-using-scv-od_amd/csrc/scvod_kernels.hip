@@ -3039,6 +3039,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         }
         r[0] = t;
         r[1] = 0;  // (the box is used up: the word counts the cluster's voxels below)
+        r[4] = 0xffffffffu;  // ... and this one takes the lowest voxel slot carrying the cluster's label (its id in the tracking chain)
         A.cl_count[(size_t)base + names[c]] = cnt;  // Cluster::occupy_pts.size(), kept at the cluster's canonical name
     }
     __syncthreads();
@@ -3053,21 +3054,27 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         const int cid = cid_of_voxel(v);
         if (cid < 0) continue;
         uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
-        if (r[0]) atomicAdd(&r[1], 1u);
+        if (r[0]) {
+            atomicAdd(&r[1], 1u);
+            atomicMin(&r[4], (uint32_t)v);
+        }
     }
     __syncthreads();
     for (int v = tid; v < nv; v += kCcThreads) {
         const int cid = cid_of_voxel(v);
         int4 rec = make_int4(A.vox_key[(size_t)base + v], -1, 0, 0);
+        int rep = -1;
         if (cid >= 0) {
             const uint32_t* r = cid < kCcBoxes ? bb + 7 * cid : ov + 7 * (size_t)(cid - kCcBoxes);
             if (r[0]) {
                 rec.y = names[cid];
                 rec.z = (int)r[1];
                 rec.w = (int)r[0];
+                rep = (int)r[4];
             }
         }
         A.vox_track[(size_t)base + v] = rec;
+        A.vox_rep[(size_t)base + v] = rep;
     }
     // ---- member lists of the car clusters (what SSC::tracking walks, ssc.cpp:1274-1321): the car roots in ascending order
     // (tk_clusters), exclusive offsets of their sizes (tk_mbegin at the root), and -- in the per-point pass below -- every
@@ -3110,6 +3117,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         scnt[rank] = (int)r[6];
         scid[rank] = cid;
         A.tk_clusters[(size_t)base + rank] = mine;
+        A.tk_crep[(size_t)base + rank] = (int)r[4];
     }
     __syncthreads();
     {

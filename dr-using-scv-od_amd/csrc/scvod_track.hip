@@ -16,7 +16,7 @@
 //
 // Everything stays in HBM: cluster names and types come from scvod_batch_cluster / scvod_batch_cluster_types, the member
 // lists of the car clusters are built here (counting sort by cluster root), no host round trip inside a call.
-#include "scvod_dev.h"
+#include "scvod_chain.h"
 
 namespace scvod {
 
@@ -46,15 +46,18 @@ __device__ __forceinline__ void wave_group(int key, int& leader, int& rank, int&
 
 struct NextTable {
     const int4* tab;  // records {key, label, cluster voxels, cluster type}, ascending key
+    const int32_t* rep;  // per record: lowest slot carrying the same label (tables of the batch only; nullptr for a boundary table)
     int nv;
 };
 __device__ __forceinline__ NextTable next_table_of(const Arena& A, const TrackBatch& J, int s) {
     NextTable t;
     t.tab = nullptr;
+    t.rep = nullptr;
     t.nv = -1;  // no successor
     const int nxt = J.next_scan[s];
     if (nxt >= 0) {
         t.tab = A.vox_track + A.scan_off[nxt];
+        t.rep = A.vox_rep + A.scan_off[nxt];
         t.nv = A.counts[nxt * 8 + 6];
     } else if (nxt <= -2 && (-2 - nxt) < J.n_ext) {
         const int4* e = J.ext_tables[-2 - nxt];
@@ -255,19 +258,25 @@ __global__ __launch_bounds__(64 * kTkWaves) void k_tk_decide(Arena A, TrackBatch
             }
             mn = wave_min_i(mn);
             if (mn == 0x7fffffff) break;
-            int cnt = 0, nvx = 0, typ = 0;
+            int cnt = 0, nvx = 0, typ = 0, rep = -1;
             for (int j = lane; j < U; j += 64) {
-                const int4 rec = N.tab[A.tk_uniq[(size_t)base + k0 + j]];
+                const int slot = A.tk_uniq[(size_t)base + k0 + j];
+                const int4 rec = N.tab[slot];
                 if (rec.y == mn) {
                     ++cnt;
                     nvx = rec.z;
                     typ = rec.w;
+                    if (N.rep) rep = N.rep[slot];
                 }
             }
             nvx = wave_max_i(nvx);
             typ = wave_max_i(typ);
+            rep = wave_max_i(rep);
             cnt = wave_sum_i(cnt);
-            if (lane == 0) A.tk_pairs[(size_t)base + k0 + npairs] = make_int2(mn, cnt);
+            if (lane == 0) {
+                A.tk_pairs[(size_t)base + k0 + npairs] = make_int2(mn, cnt);
+                A.tk_prep[(size_t)base + k0 + npairs] = rep;
+            }
             if (npairs == 0) {
                 one_count = cnt;
                 one_nvox = nvx;
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void k_tk_export(Arena A, int s, int4* out, lo
 // phases: 1 = successor tables only (labels, cluster sizes: what scvod_batch_export_table hands to another shard),
 // 2 = member lists, probe, decision, per-point bytes (needs phase 1 of the same clustering), 3 = both
 void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
-                        TimerHook th, void* tu) {
+                        TimerHook th, void* tu, const ChainJob* chain) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
@@ -367,6 +376,9 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
         }
     }
     TH_END("tk_decide");
+    // the reference's sequential chain on top of the first-order results (scvod_chain.hip): states and dynamic counters of
+    // every frame that has a successor in the batch become those of SSC::segDF's loop
+    if (chain) launch_track_chain(P, A, J, *chain, from_apri, st, th, tu);
     TH_BEGIN("tk_dyn");
     if (!from_apri) hipMemsetAsync(A.pt_mapcls, 0, (size_t)A.total_pts, st);
     hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A, from_apri);

@@ -396,5 +396,7 @@ void SSC::segDF() {
         reset();
         id += skip;
     }
+    if (pose_vec.size() < frame_set.size())  // the reference would read past pose_vec (ssc.cpp:1450); every other loader error throws here
+        throw std::runtime_error("SSC::segDF: " + std::to_string(pose_vec.size()) + " poses for " + std::to_string(frame_set.size()) + " frames");
     for (int i = 0; i + 1 < (int)frame_set.size(); i++) tracking(frame_set[i], frame_set[i + 1], pose_vec[i], pose_vec[i + 1]);
 }

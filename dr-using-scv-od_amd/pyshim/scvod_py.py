@@ -124,6 +124,8 @@ def load_lib():
         "scvod_batch_track": (C.c_int, [vp, vp, vp, vp, i32, vp, i32]),
         "scvod_batch_fetch_track": (C.c_int, [vp, i32, C.POINTER(TrackResult)]),
         "scvod_batch_export_table": (C.c_int, [vp, i32, vp, i64, vp]),
+        "scvod_set_track_mode": (C.c_int, [vp, i32, i32, i32]),
+        "scvod_batch_track_stats": (C.c_int, [vp, vp]),
         "scvod_batch_track_tables": (C.c_int, [vp, vp]),
         "scvod_map_create": (C.c_int, [C.c_int, i64, f32, C.POINTER(vp)]),
         "scvod_map_destroy": (None, [vp]),
@@ -157,7 +159,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
@@ -380,6 +382,16 @@ class Ctx:
                     cluster_size=arr(r.cluster_size, ncl, np.int32), cluster_state=arr(r.cluster_state, ncl, np.int32),
                     n_unique=arr(r.n_unique, ncl, np.int32), pair_begin=pb, pair_label=arr(r.pair_label, npair, np.int32),
                     pair_count=arr(r.pair_count, npair, np.int32), pt_dyn=arr(r.pt_dyn, r.n_apri, np.uint8))
+
+    def set_track_mode(self, chain=True, segment_steps=0, warmup_steps=0):
+        """chain=True: the reference's sequential tracking chain (default); False: first-order decisions.  0 keeps a length."""
+        self._chk(self.lib.scvod_set_track_mode(self.h, 1 if chain else 0, int(segment_steps), int(warmup_steps)))
+
+    def batch_track_stats(self):
+        out = np.zeros(8, np.int32)
+        self._chk(self.lib.scvod_batch_track_stats(self.h, out.ctypes.data_as(C.c_void_p)))
+        return dict(chain=bool(out[0]), segments=int(out[1]), verified=int(out[2]), rewalked=int(out[3]), error_bits=int(out[4]),
+                    segment_steps=int(out[5]), warmup_steps=int(out[6]))
 
     def batch_track_tables(self, stream=None):
         self._chk(self.lib.scvod_batch_track_tables(self.h, C.c_void_p(stream or 0)))

@@ -260,9 +260,9 @@ int scvod_batch_fetch(scvod_ctx* ctx, int32_t s, scvod_scan_result* out);
  *                the next block of the sequence): how a block's last scan is tracked across a shard boundary.
  * Per cluster: the transformed points are re-binned without range/FOV rejection (ssc.cpp:1280-1286) and looked up in the
  * successor's table; hits are grouped by label and de-duplicated (remap_name, ssc.cpp:1304-1321); Cluster::state follows
- * ssc.cpp:1323-1397 with the successor in its freshly segmented state (FIRST-ORDER decision: the re-labelling a previous
- * pair would have applied to the successor, ssc.cpp:1354-1372 / 1399-1419, is not replayed; SSC::tracking of the host
- * facade does that sequential bookkeeping on top of scvod_track_probe).  Per apri point a SCVOD_DYN_* byte.
+ * ssc.cpp:1323-1397, first against the successor in its freshly segmented state (all pairs in parallel), then -- mode
+ * SCVOD_TRACK_CHAIN, the default -- with the re-labelling / cloud appending of ssc.cpp:1354-1372, 1378-1384, 1399-1419
+ * replayed in sequence order on the device (scvod_set_track_mode below).  Per apri point a SCVOD_DYN_* byte.
  * No host synchronisation inside the call; h_T / h_next_scan / h_ext_tables are copied (and re-uploaded only when they
  * differ from the previous call). */
 #define SCVOD_DYN_STATIC 0      /* member of a cluster that is not dynamic                                        */
@@ -270,6 +270,29 @@ int scvod_batch_fetch(scvod_ctx* ctx, int32_t s, scvod_scan_result* out);
 #define SCVOD_DYN_UNCLUSTERED 2 /* its cluster was erased by the bounding-box refine (listed static, ssc.cpp:450-454) */
 int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_scan, const void* const* h_ext_tables,
                       int32_t n_ext, void* stream, int32_t sync);
+
+/* What scvod_batch_track decides (default SCVOD_TRACK_CHAIN).
+ *   SCVOD_TRACK_CHAIN        the reference's SEQUENTIAL chain (SSC::segDF, src/ssc.cpp:1449-1451): tracking(i, i + 1) appends
+ *                            the transformed cloud of a static car cluster to its successor cluster (ssc.cpp:1378-1384),
+ *                            splits hit voxels off a non-car cluster (ssc.cpp:1351-1372) or fuses the car clusters it
+ *                            hits (ssc.cpp:1396-1419) BEFORE tracking(i + 1, i + 2) walks that frame.  Cluster states, the
+ *                            per-point bytes and the dynamic counters of every scan with a successor in the batch are
+ *                            those of that loop, cluster_set walked in ascending canonical name (created clusters after
+ *                            the original ones, in creation order).  On the device the chain of each sequence is cut into
+ *                            segments of `segment_steps` steps walked concurrently, each warmed up `warmup_steps` steps
+ *                            earlier; a segment whose warm-up did not reproduce the state its predecessor really ended
+ *                            in is walked again from that state, so the result never depends on the two lengths (0 keeps
+ *                            the current values; defaults 24 / 16).  A scan tracked against an EXTERNAL table ends its
+ *                            chain: across shard boundaries the decision is first-order -- keep a sequence on one shard.
+ *   SCVOD_TRACK_FIRST_ORDER  every cluster against its successor's fresh segmentation (all pairs independent).
+ * n_unique / pair_* of scvod_track_result always describe a cluster's OWN points against the fresh successor. */
+#define SCVOD_TRACK_CHAIN 1
+#define SCVOD_TRACK_FIRST_ORDER 0
+int scvod_set_track_mode(scvod_ctx* ctx, int32_t mode, int32_t segment_steps, int32_t warmup_steps);
+/* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
+ * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.
+ * Returns SCVOD_ERR_CAPACITY when a chain state did not fit the walkers' workspace (the result is then invalid). */
+int scvod_batch_track_stats(scvod_ctx* ctx, int32_t* h_out8);
 
 /* Tracking result of scan `s` of the last scvod_batch_track.  Pointers are host memory owned by the ctx, valid until the
  * next fetch.  Clusters are the `car` clusters of the scan in ascending canonical name (smallest apri index). */

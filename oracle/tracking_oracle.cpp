@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -103,15 +104,36 @@ float getPolarAngle(const P3& p) {
 }
 float getAzimuth(const P3& p) { return rad2deg_f((float)atan2f(p.z, (float)pointDistance2d(p))); }
 
+// ordered: walk frame_pre_.cluster_set in ascending cluster name instead of the container's order (the reference's order
+// is the one of ITS names and ITS libstdc++, neither reproducible: DESIGN.md section 2); stats (optional): counters of
+// the branches taken, see oracle_sequence_tracking_stats.
 int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, const float pose_pre[6], const float pose_next[6], int car,
-             int& name) {
+             int& name, bool ordered = false, long long* stats = nullptr) {
     int32_t R, S, A, bins;
     oracle_grid_dims(&P, &R, &S, &A, &bins);
     float T[12];
     oracle_pose_delta(pose_pre, pose_next, T);
     int dynamic_num = 0;
-    for (auto& c : frame_pre_.cluster_set) {
+    std::vector<std::pair<const int, ClusterT>*> walk;
+    for (auto& c : frame_pre_.cluster_set) walk.push_back(&c);
+    if (ordered) std::sort(walk.begin(), walk.end(), [](auto* a, auto* b) { return a->first < b->first; });
+    for (auto* cp : walk) {
+        auto& c = *cp;
         if (c.second.type != car) continue;
+        if (stats) {
+            stats[0]++;
+            stats[1] += (long long)c.second.occupy_pts.size();
+            stats[2] += (long long)c.second.cloud.size();
+            if (getenv("ORACLE_TRACK_AGES")) {  // experiment: the caller stored the frame index in `intensity`
+                float now = -1e30f;
+                for (auto& p : c.second.cloud) now = std::max(now, p.intensity);
+                for (auto& p : c.second.cloud) {
+                    int age = (int)(now - p.intensity);
+                    if (age > stats[10]) stats[10] = age;
+                    stats[11 + std::min(age, 52)]++;
+                }
+            }
+        }
         if (c.second.track_id == -1) {
             c.second.track_id = name;
             name++;
@@ -150,6 +172,7 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
         if (remap_name.size() == 0) {
             c.second.state = 1;
             dynamic_num++;
+            if (stats) stats[3]++;
         } else if (remap_name.size() == 1) {
             auto it = remap_name.begin();
             float ratio = (float)it->second.size() / (float)frame_next_.cluster_set[it->first].occupy_voxels.size();
@@ -157,7 +180,9 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
                 if (frame_next_.cluster_set[it->first].type == car) {
                     c.second.state = 1;
                     dynamic_num++;
+                    if (stats) stats[4]++;
                 } else {
+                    if (stats) stats[5]++;
                     c.second.state = 0;
                     c.second.type = frame_next_.cluster_set[it->first].type;
                     ClusterT cluster_new;
@@ -177,13 +202,17 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
                 }
             } else {
                 if (frame_next_.cluster_set[it->first].type == car) {
+                    if (stats) stats[6]++;
                     c.second.state = 0;
                     frame_next_.cluster_set[it->first].track_id = c.second.track_id;
                     auto& dst = frame_next_.cluster_set[it->first].cloud;
                     dst.insert(dst.end(), cluster.begin(), cluster.end());
+                } else if (stats) {
+                    stats[7]++;
                 }
             }
         } else {
+            if (stats) stats[8]++;
             c.second.state = 0;
             ClusterT cluster_new;
             cluster_new.track_id = c.second.track_id;
@@ -195,6 +224,7 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
                     auto& src = frame_next_.cluster_set[re.first];
                     cluster_new.occupy_pts.insert(cluster_new.occupy_pts.end(), src.occupy_pts.begin(), src.occupy_pts.end());
                     cluster_new.occupy_voxels.insert(cluster_new.occupy_voxels.end(), src.occupy_voxels.begin(), src.occupy_voxels.end());
+                    if (stats) stats[9]++;
                     frame_next_.cluster_set.erase(re.first);
                 }
             }
@@ -279,9 +309,17 @@ int decide_independent(const scvod_params& P, int R, int S, const ClusterT& c, F
     }
     return state;
 }
+
+long long* g_track_stats = nullptr;
 }  // namespace
 
 extern "C" {
+
+// Branch counters of the next oracle_sequence_tracking calls (chain 1 / 3), or NULL to stop counting.  stats[10]:
+// {car clusters walked, their own points, points of their accumulated clouds, dynamic: no label hit, dynamic: one car
+// label below `occupancy`, split off a non-car cluster, cloud appended to a car cluster, one non-car label at or above
+// `occupancy` (state untouched), several labels (fuse), clusters fused}.
+void oracle_track_stats(long long* stats) { g_track_stats = stats; }
 
 // Builds frames a and b from their apri vectors (toy segmentation), runs tracking(a, b) and reports:
 //   states: for every cluster of frame a with state != -1, sorted by name: {name, state, |occupy_voxels|}
@@ -389,8 +427,8 @@ int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri,
                 kv.second.state = decide_independent(P, R, S, kv.second, frames[i + 1], T, car, remap_name);
                 dyn += kv.second.state == 1;
             }
-        } else if (chain) {
-            dyn += tracking(P, frames[i], frames[i + 1], poses + 6 * i, poses + 6 * (i + 1), car, name);
+        } else if (chain) {  // 1: container order; 3: ascending cluster name (the order the device path defines)
+            dyn += tracking(P, frames[i], frames[i + 1], poses + 6 * i, poses + 6 * (i + 1), car, name, chain == 3, g_track_stats);
         } else {
             FrameT fresh;
             build_frame_seg(P, apri + offs[i + 1], offs[i + 2] - offs[i + 1], pt_cluster + offs[i + 1], pt_type + offs[i + 1], fresh);
@@ -440,6 +478,12 @@ int oracle_time_sequence(const scvod_params* params, const float* xyzi, const in
         std::vector<int32_t> cl(n_a ? n_a : 1), ty(n_a ? n_a : 1);
         int32_t mx = 0;
         oracle_cluster(params, apri.data(), n_a, cl.data(), &mx);
+        {   // canonical cluster names (smallest apri index of the cluster) instead of the running numbers 5, 6, 7 ...: the
+            // names only order the walk of SSC::tracking, and this is the order the product defines
+            std::unordered_map<int, int> first;
+            for (int i = 0; i < n_a; ++i) first.emplace(cl[i], i);
+            for (int i = 0; i < n_a; ++i) cl[i] = first[cl[i]];
+        }
         auto t4 = clk::now();
         oracle_cluster_types(params, apri.data(), n_a, cl.data(), car, other, ty.data());
         // Frame as recognize leaves it: labels, occupy lists, types (the voxel table of build_frame is reused)
@@ -480,7 +524,7 @@ int oracle_time_sequence(const scvod_params* params, const float* xyzi, const in
     }
     auto t6 = clk::now();
     int name = 0, dyn = 0;
-    for (int i = 0; i + 1 < n_scans; ++i) dyn += tracking(P, frames[i], frames[i + 1], poses + 6 * i, poses + 6 * (i + 1), car, name);
+    for (int i = 0; i + 1 < n_scans; ++i) dyn += tracking(P, frames[i], frames[i + 1], poses + 6 * i, poses + 6 * (i + 1), car, name, true);
     stage_s[5] = secs(t6, clk::now());
     cs += 17 * (int64_t)dyn;
     if (in_label) {

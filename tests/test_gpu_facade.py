@@ -151,10 +151,11 @@ def test_sequence_driver_end_to_end(scvod):
 
 @pytest.mark.parametrize("kind,preset,skip,count", [("PARK", "parkinglot", 1, 50), ("K64", "semantickitti", 5, 50)])
 def test_dynamic_removal_quality_matches_the_reference_chain(scvod, oracle, kind, preset, skip, count):
-    """BASELINE.json: dynamic-removal precision / recall within +-0.5 pt of the reference.  The device path (first-order
-    decision per cluster, scvod_batch_track) and the oracle's restatement of the reference's sequential chain
-    (oracle_time_sequence: clusterAndCreateFrame, box rules, SSC::tracking with its re-labelling) on the same 50 labelled
-    frames (every skip-th scan, the reference's skip_): PR and RR as tool/analysis.py:186-187 defines them."""
+    """BASELINE.json: dynamic-removal precision / recall within +-0.5 pt of the reference -- here: IDENTICAL.  The device path
+    (scvod_batch_track replays the reference's sequential chain) and the oracle's restatement of that chain
+    (oracle_time_sequence: Patchwork, binning, clusterAndCreateFrame, box rules, SSC::tracking with its re-labelling) on the
+    same 50 labelled frames (every skip-th scan, the reference's skip_): every per-point label equal, hence the same PR
+    and RR (tool/analysis.py:186-187)."""
     import quality
     import synth
     P = scvod.make_params(preset)
@@ -177,7 +178,8 @@ def test_dynamic_removal_quality_matches_the_reference_chain(scvod, oracle, kind
     stages, ref_lab, _ = oracle.time_sequence(P, x, offs, poses)
     q = quality.compare(scvod, ctx, x, offs, poses, gt, ref_lab, voxelsize=0.2)
     assert q["num_gt_dynamic"] > 1000
-    assert abs(q["delta_PR"]) <= 0.5 and abs(q["delta_RR"]) <= 0.5, q
+    assert q["labels_equal_fraction"] == 1.0, q
+    assert q["device"]["marked_dynamic"] == q["reference_chain"]["marked_dynamic"]
+    assert q["delta_PR"] == 0.0 and q["delta_RR"] == 0.0, q
     assert q["device"]["PR"] > 95.0
-    assert q["labels_equal_fraction"] > 0.99
     ctx.close()

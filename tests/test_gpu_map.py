@@ -7,10 +7,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _tracked_batch(scvod, P, kind, seq, first, count):
+def _tracked_batch(scvod, P, kind, seq, first, count, chain=True):
     import synth
     pts, offs, poses, _ = synth.make_batch(seq, first, count, kind)
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    ctx.set_track_mode(chain=chain)
     d = pts.cuda()
     ctx.batch_process(d, offs)
     ctx.batch_cluster()
@@ -100,7 +101,7 @@ def test_shards_merge_into_the_single_shard_map(scvod):
     import torch
     P = scvod.make_params("semantickitti")
     count, cut = 6, 3
-    ctx, d, x, offs, poses = _tracked_batch(scvod, P, "K64", 5, 2000, count)
+    ctx, d, x, offs, poses = _tracked_batch(scvod, P, "K64", 5, 2000, count, chain=False)  # (a cut ends a chain)
     whole = scvod.StaticMap(1 << 21)
     whole.accumulate(ctx, poses)
     wk, wv = _sorted_records(whole)
@@ -113,6 +114,7 @@ def test_shards_merge_into_the_single_shard_map(scvod):
         T[s] = ca.pose_delta(poses[s], poses[s + 1])
     da, db = d[:offs[cut]].contiguous(), d[offs[cut]:].contiguous()
     for c, dd, oo in ((ca, da, oa), (cb, db, ob)):
+        c.set_track_mode(chain=False)
         c.batch_process(dd, oo)
         c.batch_cluster()
         c.batch_cluster_types()

@@ -423,6 +423,7 @@ def test_batch_track_decision_parity(scvod, oracle, kind, preset, seq, first):
     T = np.zeros((count, 12), np.float32)
     for s in range(count - 1):
         T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.set_track_mode(chain=False)  # the per-pair decision; the sequential chain has its own tests below
     ctx.batch_track(T)
     tr = [ctx.batch_fetch_track(s) for s in range(count)]
     n_dyn = n_stat = n_multi = 0
@@ -442,6 +443,101 @@ def test_batch_track_decision_parity(scvod, oracle, kind, preset, seq, first):
     ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
     dyn, _ = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), np.asarray(poses, np.float32), chain=2)
     assert np.array_equal(np.concatenate([t["pt_dyn"] for t in tr]), dyn)
+    ctx.close()
+
+
+def _assert_chain_equal(ctx, oracle, P, res, names, types, poses, order_free=True):
+    """per-point bytes and dynamic-cluster count of the ctx's last scvod_batch_track (chain mode, scan s -> s + 1) against
+    the oracle's literal restatement of SSC::segDF's tracking loop, cluster_set walked in ascending name (chain=3)"""
+    count = len(res)
+    tr = [ctx.batch_fetch_track(s) for s in range(count)]
+    apri = np.concatenate([r["apri"] for r in res])
+    ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
+    nm, ty = np.concatenate(names), np.concatenate(types)
+    dyn, nd = oracle.sequence_tracking(P, apri, ao, nm, ty, np.asarray(poses, np.float32), chain=3)
+    got = np.concatenate([t["pt_dyn"] for t in tr])
+    assert np.array_equal(got, dyn), f"{int((got != dyn).sum())} of {len(dyn)} per-point bytes differ from the sequential chain"
+    assert sum(t["n_dynamic_clusters"] for t in tr) == nd
+    assert sum(t["n_dynamic_points"] for t in tr) == int((dyn == 1).sum())
+    return dyn, nd
+
+
+@pytest.mark.parametrize("kind,preset,skip,count,first", [("K64", "semantickitti", 5, 50, 300), ("PARK", "parkinglot", 1, 60, 30),
+                                                         ("OS128", "os128_fine", 5, 50, 700)])
+def test_tracking_chain_equals_the_reference_chain(scvod, oracle, kind, preset, skip, count, first):
+    """north_star: per-point dynamic/static labels bit-exact.  scvod_batch_track in its default mode replays SSC::segDF's
+    SEQUENTIAL loop (ssc.cpp:1449-1451: every call re-labels / splits / fuses the successor's clusters and appends clouds
+    before the next call walks them) on the device.  >= 50 frames (every skip-th scan, the reference's skip_) of each
+    workload: np.array_equal with the oracle's literal chain -- walked in ascending cluster name (chain=3, the order the
+    product defines) and in the oracle's own unordered_map order (chain=1); with segment / warm-up lengths that force
+    the verification pass to walk segments again, the result must not move."""
+    import synth
+    import torch
+    P = _params(scvod, preset)
+    scans = [synth.make_scan(5, first + k * skip, kind) for k in range(count)]
+    x = np.concatenate([sc[0].numpy() for sc in scans])
+    offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int32)
+    poses = np.asarray([sc[2] for sc in scans], np.float32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    d = torch.from_numpy(x).cuda()
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    res = [ctx.batch_fetch(s) for s in range(count)]
+    names = [ctx.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(count)]
+    types = [ctx.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(count)]
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)  # defaults: segments of 24 steps, 16 warm-up steps
+    st = ctx.batch_track_stats()
+    assert st["chain"] and st["segments"] == -(-(count - 1) // st["segment_steps"]) and st["error_bits"] == 0
+    dyn, nd = _assert_chain_equal(ctx, oracle, P, res, names, types, poses)
+    assert nd > 0 and 0 < int((dyn == 1).sum())
+    # the oracle's container order gives the same labels on these sequences (the order only matters when two clusters of one
+    # call touch the same successor cluster)
+    apri = np.concatenate([r["apri"] for r in res])
+    ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
+    dyn1, nd1 = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), poses, chain=1)
+    assert np.array_equal(dyn1, dyn) and nd1 == nd
+    # the chain is not the first-order decision: the sample must contain clusters the appended clouds / re-labelling flip
+    dyn2, _ = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), poses, chain=2)
+    assert int((dyn2 != dyn).sum()) > 0
+    for seg, warm in ((5, 0), (7, 3), (64, 0)):
+        ctx.set_track_mode(chain=True, segment_steps=seg, warmup_steps=warm)
+        ctx.batch_track(T)
+        st = ctx.batch_track_stats()
+        assert st["segments"] == -(-(count - 1) // seg) and st["verified"] == st["segments"] - 1
+        if warm == 0:
+            assert st["rewalked"] == st["segments"] - 1  # no snapshot to compare with: every later segment is walked from the true state
+        _assert_chain_equal(ctx, oracle, P, res, names, types, poses)
+    ctx.close()
+
+
+def test_tracking_chain_of_interleaved_subsequences(scvod, oracle):
+    """bench.py's layout: consecutive scans in the batch, scan i tracked against scan i + skip -- `skip` interleaved chains in
+    one call.  Every sub-sequence must come out as if it had been tracked on its own."""
+    import synth
+    P = _params(scvod, "semantickitti")
+    skip, count = 3, 36
+    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, "K64", 5, 1100, count)
+    nxt = np.array([s + skip if s + skip < count else -1 for s in range(count)], np.int32)
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - skip):
+        T[s] = ctx.pose_delta(poses[s], poses[s + skip])
+    ctx.set_track_mode(chain=True, segment_steps=4, warmup_steps=6)
+    ctx.batch_track(T, next_scan=nxt)
+    st = ctx.batch_track_stats()
+    assert st["segments"] == skip * 3 and st["error_bits"] == 0
+    tr = [ctx.batch_fetch_track(s) for s in range(count)]
+    for q in range(skip):
+        sub = list(range(q, count, skip))
+        apri = np.concatenate([res[s]["apri"] for s in sub])
+        ao = np.concatenate([[0], np.cumsum([res[s]["n_apri"] for s in sub])]).astype(np.int32)
+        dyn, nd = oracle.sequence_tracking(P, apri, ao, np.concatenate([names[s] for s in sub]), np.concatenate([types[s] for s in sub]),
+                                           np.asarray([poses[s] for s in sub], np.float32), chain=3)
+        assert np.array_equal(np.concatenate([tr[s]["pt_dyn"] for s in sub]), dyn), q
+        assert sum(tr[s]["n_dynamic_clusters"] for s in sub) == nd
     ctx.close()
 
 
@@ -488,6 +584,7 @@ def test_batch_track_with_thousands_of_car_clusters(scvod, oracle):
     T = np.zeros((3, 12), np.float32)
     for s in range(2):
         T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.set_track_mode(chain=False)
     ctx.batch_track(T)
     tr = [ctx.batch_fetch_track(s) for s in range(3)]
     for s in range(2):
@@ -496,6 +593,10 @@ def test_batch_track_with_thousands_of_car_clusters(scvod, oracle):
         _assert_track_equal(tr[s], o)
         assert tr[s]["n_car_points"] == int((types[s] == 2).sum())
     assert (tr[0]["cluster_state"] == 1).sum() > 100 and (tr[0]["cluster_state"] == 0).sum() > 1000
+    # the sequential chain over the same three frames: thousands of walked clusters and appended clouds per step
+    ctx.set_track_mode(chain=True)
+    ctx.batch_track(T)
+    _assert_chain_equal(ctx, oracle, P, res, names, types, poses)
     ctx.close()
 
 
@@ -511,6 +612,7 @@ def test_batch_track_across_a_shard_boundary(scvod, oracle):
     T = np.zeros((count, 12), np.float32)
     for s in range(count - 1):
         T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.set_track_mode(chain=False)  # an external table ends a chain: the boundary mechanism is the first-order decision's
     ctx.batch_track(T)
     whole = [ctx.batch_fetch_track(s) for s in range(count)]
     ctx.close()
@@ -521,6 +623,7 @@ def test_batch_track_across_a_shard_boundary(scvod, oracle):
     cb.batch_process(db, ob)
     cb.batch_cluster()
     cb.batch_cluster_types()
+    cb.set_track_mode(chain=False)
     cb.batch_track(T[cut:])
     msg = torch.zeros((res[cut]["n_voxels"] + 1, 4), dtype=torch.int32, device="cuda")
     cb.batch_export_table(0, msg)
@@ -535,6 +638,7 @@ def test_batch_track_across_a_shard_boundary(scvod, oracle):
     ca.batch_cluster()
     ca.batch_cluster_types()
     nxt = np.array([1, -1, 3, -2], np.int32)
+    ca.set_track_mode(chain=False)
     ca.batch_track(T[:cut], next_scan=nxt, ext_tables=[msg])
     ta = [ca.batch_fetch_track(s) for s in range(cut)]
     for s in (0, 2, 3):

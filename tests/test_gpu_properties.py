@@ -98,7 +98,12 @@ def test_full_size_batches(scvod, kind, preset, count):
         seen += t["n_clusters"]
     assert seen > 0
     ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (count, 1))
-    ctx.batch_track(ident, next_scan=np.arange(count, dtype=np.int32))
+    import ctypes as C
+    nself = np.arange(count, dtype=np.int32)
+    assert ctx.lib.scvod_batch_track(ctx.h, ident.ctypes.data_as(C.c_void_p), nself.ctypes.data_as(C.c_void_p), None, 0, None, 1) == -1, \
+        "a scan cannot be its own successor in the sequential chain"
+    ctx.set_track_mode(chain=False)
+    ctx.batch_track(ident, next_scan=nself)
     for s in (0, count - 1):
         t = ctx.batch_fetch_track(s)
         assert t["n_dynamic_clusters"] <= max(1, t["n_clusters"] // 10) and (t["cluster_state"] == 0).sum() >= 0.8 * t["n_clusters"]
