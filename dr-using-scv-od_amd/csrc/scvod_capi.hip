@@ -69,6 +69,7 @@ struct scvod_ctx {
     // sequential tracking chain (scvod_chain.hip)
     int track_mode = SCVOD_TRACK_CHAIN;
     int chain_seg = 24, chain_warm = 16;     // steps per segment, warm-up steps in front of it
+    bool chain_generic = false;              // testing: every step through the generic (HBM-resident) step function
     int32_t* d_chain_scans = nullptr;        // [cap_scans]
     ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
     int32_t* d_chain_fw = nullptr;           // [cap_scans + 1]
@@ -1166,10 +1167,11 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             CJ.ws.base = (unsigned char*)c->chain_ws;
             CJ.stats = c->d_chain_stats;
             CJ.words = (c->A.max_scan_pts + 31) / 32 + 1;
-            const size_t lds_bits = 88 * 1024;  // next to the 64 KB of sampled keys
+            const size_t lds_bits = 72 * 1024;  // next to the 80 KB of per-step tables
             int ev = (int)(lds_bits / ((size_t)CJ.words * 4));
             CJ.n_eval_waves = ev < 1 ? 1 : (ev > 16 ? 16 : ev);
             if ((size_t)CJ.words * 4 > lds_bits) return fail(c, SCVOD_ERR_CAPACITY, "scan too large for the chain's LDS bitset");
+            CJ.force_generic = c->chain_generic ? 1 : 0;
             c->chain_ran = true;
         }
     }
@@ -1182,8 +1184,11 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
 }
 
 int scvod_set_track_mode(scvod_ctx* c, int32_t mode, int32_t segment_steps, int32_t warmup_steps) {
-    if (!c || (mode != SCVOD_TRACK_CHAIN && mode != SCVOD_TRACK_FIRST_ORDER)) return fail(c, SCVOD_ERR_INVALID, "unknown tracking mode");
+    if (!c || (mode != SCVOD_TRACK_CHAIN && mode != SCVOD_TRACK_FIRST_ORDER && mode != SCVOD_TRACK_CHAIN_GENERIC))
+        return fail(c, SCVOD_ERR_INVALID, "unknown tracking mode");
     if (segment_steps < 0 || warmup_steps < 0) return fail(c, SCVOD_ERR_INVALID, "negative segment / warm-up length");
+    c->chain_generic = (mode == SCVOD_TRACK_CHAIN_GENERIC);
+    if (mode == SCVOD_TRACK_CHAIN_GENERIC) mode = SCVOD_TRACK_CHAIN;
     c->track_mode = mode;
     if (segment_steps > 0) c->chain_seg = segment_steps;
     if (segment_steps > 0 || warmup_steps > 0) c->chain_warm = warmup_steps;
@@ -1216,6 +1221,9 @@ int scvod_batch_track_stats(scvod_ctx* c, int32_t* h_out8) {
     h_out8[5] = c->chain_seg;
     h_out8[6] = c->chain_warm;
     h_out8[7] = 0;
+#ifdef SCVOD_PROFILE
+    fprintf(stderr, "[chain phases, 10 ns ticks summed over walkers x steps] fetch %d  carried %d  eval %d  walk+state %d  copy %d\n", st[3], st[4], st[5], st[6], st[7]);
+#endif
     return rc;
 }
 

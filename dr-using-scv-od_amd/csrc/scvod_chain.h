@@ -32,6 +32,7 @@ struct ChainJob {
     int32_t* stats;       // [0] error bits (1 pool, 2 entries, 4 created labels, 8 bitset words), [1] segments walked again, [2] segments compared
     int32_t words;        // bitset words of an evaluating wave
     int32_t n_eval_waves;
+    int32_t force_generic;  // testing: every step through the HBM-resident generic path
 };
 
 void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st,

@@ -84,7 +84,7 @@ __device__ __forceinline__ Wk wk_of(const ChainWs& S, int w) {
 }
 
 // header words of a walker
-enum { H_EPOCH = 0, H_END_SLOT = 1, H_HAS_SNAP = 2, H_NENT = 4 /* [3] */, H_NCARRIED = 8 /* [3] */, H_NPARTS = 12 /* [3] */ };
+enum { H_EPOCH = 0, H_END_SLOT = 1, H_HAS_SNAP = 2, H_SNAP_OK = 3, H_NENT = 4 /* [3] */, H_NCARRIED = 8 /* [3] */, H_NPARTS = 12 /* [3] */ };
 
 __device__ __forceinline__ int wmin_i(int v) {
 #pragma unroll
@@ -158,14 +158,48 @@ __device__ __forceinline__ int lower_bound_i(const int32_t* a, int n, int key) {
     return lo;
 }
 
+#ifdef SCVOD_PROFILE
+#define CH_MARK(i)                                                   \
+    do {                                                             \
+        if (threadIdx.x == 0) {                                      \
+            const long long now__ = wall_clock64();                  \
+            atomicAdd(&C.stats[3 + (i)], (int)(now__ - ch_t0__));    \
+            ch_t0__ = now__;                                         \
+        }                                                            \
+    } while (0)
+#define CH_T0 long long ch_t0__ = wall_clock64()
+#else
+#define CH_MARK(i)
+#define CH_T0
+#endif
+
+constexpr int kLdsEnt = 512;      // clusters of a step whose records live in LDS (fast path)
+constexpr int kSmSamples = 8192;  // sampled successor keys of the fast path (32 KB)
+
+struct ShSmall {
+    int32_t skeys[kSmSamples];
+    int4 fr[kLdsEnt];           // {remap_name.size(), unique hits, id of the first label, its hit count} against the FRESH successor
+    int4 fx[kLdsEnt];           // {|occupy_voxels| + type of that label (fresh), root of a one-cluster entry / -1, cloud points, own points}
+    int32_t fuo[kLdsEnt];       // one-cluster entry: tk_mbegin of its root; otherwise offset of the entry's region in suniq / spairs
+    int32_t nown[2 * kLdsEnt];  // successor: points of car cluster e
+    int32_t ncrep[2 * kLdsEnt]; // successor: label id of car cluster e
+    int32_t dsz[2 * kLdsEnt];   // points appended to successor cluster e (then its cursor)
+    int32_t eidx[2 * kLdsEnt];  // successor cluster e -> entry of the next state, -1 gone
+    int32_t ncb[2 * kLdsEnt];   // entry of the next state -> first carried point
+    int4 lk[kLdsEnt];           // appended clouds: {walked entry, successor cluster, points, offset in the next pool / -1}
+    int32_t lpre[kLdsEnt + 1];  // their exclusive point offsets (copy phase)
+};
 struct Shared {
-    int32_t skeys[kChSamples];
+    union {
+        int32_t skeys[kChSamples];
+        ShSmall sm;
+    };
     int32_t wsum[kChWaves + 1];
     int32_t bc[8];  // broadcast words
 };
 
 // copies state `src` of walker workspace A to state `dst` of workspace B (all threads)
-__device__ void copy_state(const Wk& A, int src, const Wk& B, int dst) {
+__device__ __forceinline__ void copy_state(const Wk& A, int src, const Wk& B, int dst) {
     const int ne = A.hdr[H_NENT + src], nc = A.hdr[H_NCARRIED + src], np = A.hdr[H_NPARTS + src];
     for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) B.ent[dst][i] = A.ent[src][i];
     for (int i = threadIdx.x; i < np; i += kChThreads) B.parts[dst][i] = A.parts[src][i];
@@ -180,26 +214,26 @@ __device__ void copy_state(const Wk& A, int src, const Wk& B, int dst) {
 }
 
 // bit-for-bit comparison of two states (all threads); returns true when they are equal
-__device__ bool same_state(const Wk& A, int sa, const Wk& B, int sb) {
+__device__ __forceinline__ bool same_state(const Wk& A, int sa, const Wk& B, int sb) {
     const int ne = A.hdr[H_NENT + sa], nc = A.hdr[H_NCARRIED + sa], np = A.hdr[H_NPARTS + sa];
     int diff = (ne != B.hdr[H_NENT + sb]) || (nc != B.hdr[H_NCARRIED + sb]) || (np != B.hdr[H_NPARTS + sb]);
     if (!diff) {
         for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) {
             const int4 x = A.ent[sa][i], y = B.ent[sb][i];
-            diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+            diff |= (int)(x.x != y.x) | (int)(x.y != y.y) | (int)(x.z != y.z) | (int)(x.w != y.w);
         }
         for (int i = threadIdx.x; i < np; i += kChThreads) diff |= A.parts[sa][i] != B.parts[sb][i];
         for (int i = threadIdx.x; i < nc; i += kChThreads) {
             const float4 x = A.pool[sa][i], y = B.pool[sb][i];
-            diff |= (__float_as_uint(x.x) != __float_as_uint(y.x)) | (__float_as_uint(x.y) != __float_as_uint(y.y)) |
-                    (__float_as_uint(x.z) != __float_as_uint(y.z));
+            diff |= (int)(__float_as_uint(x.x) != __float_as_uint(y.x)) | (int)(__float_as_uint(x.y) != __float_as_uint(y.y)) |
+                    (int)(__float_as_uint(x.z) != __float_as_uint(y.z));
         }
     }
     return __syncthreads_or(diff) == 0;
 }
 
 // the freshly segmented car clusters of scan s as a state: one entry per cluster, nothing carried
-__device__ void fresh_state(const Arena& A, const Wk& K, int slot, int s, int cap_ent, int32_t* stats) {
+__device__ __forceinline__ void fresh_state(const Arena& A, const Wk& K, int slot, int s, int cap_ent, int32_t* stats) {
     const int base = A.scan_off[s];
     int ncar = A.tk_scan[s * 4 + 0];
     if (ncar > cap_ent) {
@@ -230,10 +264,359 @@ __device__ void fresh_state(const Arena& A, const Wk& K, int slot, int s, int ca
     __syncthreads();
 }
 
+
+// transform (utility.h:401-404) + unfiltered re-bin (ssc.cpp:1280-1286) + look-up of the carried points; their new
+// coordinates replace the old ones.  skeys: `ns` keys of the table sampled every 2^shift records.
+__device__ __forceinline__ void carried_probe(const DevParams& P, const Wk& K, float4* pool, int ncarried, const float* T, const int4* tab, int nv,
+                                              const int32_t* skeys, int ns, int shift) {
+#ifndef CH_U
+#define CH_U 4
+#endif
+    constexpr int U = CH_U;  // four points per thread and round: their loads, searches and table reads overlap
+    for (int c0 = threadIdx.x; c0 < ncarried; c0 += kChThreads * U) {
+        float4 q[U];
+        int key[U], lo[U], hi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[u] = pool[min(c0 + u * kChThreads, ncarried - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
+            const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
+            const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
+            q[u] = make_float4(x, y, z, q[u].w);
+            Apri a;
+            apri_of_point(P.bin, x, y, z, q[u].w, a);
+            key[u] = a.voxel_idx;
+            lo[u] = 0;  // first sample > key
+            hi[u] = ns;
+        }
+        bool more = ns > 0;
+        while (more) {
+            more = false;
+            int sk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) sk[u] = skeys[min((lo[u] + hi[u]) >> 1, ns - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (lo[u] < hi[u]) {
+                    const int mid = (lo[u] + hi[u]) >> 1;
+                    if (sk[u] <= key[u])
+                        lo[u] = mid + 1;
+                    else
+                        hi[u] = mid;
+                    more |= lo[u] < hi[u];
+                }
+            }
+        }
+        int4 first[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) first[u] = tab[min(max(lo[u] - 1, 0) << shift, max(nv - 1, 0))];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * kChThreads;
+            if (c >= ncarried) continue;
+            int slot = -1;
+            if (lo[u] > 0) {
+                int a0 = (lo[u] - 1) << shift;
+                const int a1 = min(a0 + (1 << shift), nv);
+                int4 rec = first[u];
+                for (;;) {
+                    if (rec.x >= key[u]) {
+                        if (rec.x == key[u] && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
+                        break;
+                    }
+                    if (++a0 >= a1) break;
+                    rec = tab[a0];
+                }
+            }
+            pool[c] = q[u];
+            K.chit[c] = slot;
+        }
+    }
+}
+
+// One wave: sorted unique hit list (sampleVec, ssc.cpp:1319-1321) of an entry whose cloud is more than one original cluster's
+// own points -- the unique lists of its parts (scvod_track.hip) and the hits of its carried points -- through a bitset
+// over the successor's table, then remap_name against the FRESH labels.  Returns {labels, unique hits}; lists at uq / pr.
+__device__ __forceinline__ int2 eval_entry(const Arena& A, const Wk& K, const StepEnv& E, int base_i, const int32_t* parts, const int4 e0, uint32_t* bits,
+                           int32_t* uq, int2* pr) {
+    const int lane = threadIdx.x & 63;
+    int wlo = 0x7fffffff, whi = -1;
+    for (int p = 0; p < e0.y; ++p) {
+        const int root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
+        const int mb = A.tk_mbegin[(size_t)base_i + root];
+        const int nu = A.tk_nuniq[(size_t)base_i + root];
+        const int32_t* src = A.tk_uniq + (size_t)base_i + mb;
+        for (int j0 = lane; j0 < nu; j0 += 256) {
+            int sl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl[u] = (j0 + 64 * u < nu) ? src[j0 + 64 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sl[u] >= 0) {
+                    atomicOr(&bits[sl[u] >> 5], 1u << (sl[u] & 31));
+                    wlo = min(wlo, sl[u] >> 5);
+                    whi = max(whi, sl[u] >> 5);
+                }
+        }
+    }
+    {
+        const int32_t* src = K.chit + e0.z;
+        for (int j0 = lane; j0 < e0.w; j0 += 256) {
+            int sl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl[u] = (j0 + 64 * u < e0.w) ? src[j0 + 64 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sl[u] >= 0) {
+                    atomicOr(&bits[sl[u] >> 5], 1u << (sl[u] & 31));
+                    wlo = min(wlo, sl[u] >> 5);
+                    whi = max(whi, sl[u] >> 5);
+                }
+        }
+    }
+    wlo = wmin_i(wlo);
+    whi = wmax_i(whi);
+    wave_sync();
+    // sorted unique slots over the words touched (cleared on the way); the labels are grouped in the same pass: lane t holds
+    // the t-th distinct label id met so far and its count (a cluster hits a handful of labels; more than 64 fall back below)
+    int U = 0;
+    int tid_ = -1, tcnt = 0, ntab = 0;
+#ifdef CH_NO_TABLE
+    bool table_ok = false;
+#else
+    bool table_ok = true;
+#endif
+    for (int w0 = wlo; w0 <= whi; w0 += 64) {
+        const int w = w0 + lane;
+        uint32_t word = 0u;
+        if (w <= whi) {
+            word = bits[w];
+            bits[w] = 0u;
+        }
+        const int c = __popc(word);
+        const int inc = wave_incl_scan(c);
+        int o = U + inc - c;
+        // labels of this lane's slots (one word: neighbouring voxels, mostly one label)
+        uint32_t rest = word;
+        while (__any(rest != 0u)) {
+            int id = -1;
+            int slot = -1;
+            if (rest) {
+                const int b = __ffs(rest) - 1;
+                rest &= rest - 1;
+                slot = (w << 5) + b;
+                uq[o++] = slot;
+                id = E.rep[slot];
+            }
+            bool todo = id >= 0;
+            while (__any(todo)) {
+                const int firstl = __ffsll((long long)__ballot(todo)) - 1;
+                const int k0 = __shfl(id, firstl);
+                const bool mine = todo && id == k0;
+                const int cntk = __popcll(__ballot(mine));
+                if (mine) todo = false;
+                const unsigned long long hit = __ballot(tid_ == k0);
+                if (hit) {
+                    if (tid_ == k0) tcnt += cntk;
+                } else if (ntab < 64) {
+                    if (lane == ntab) {
+                        tid_ = k0;
+                        tcnt = cntk;
+                    }
+                    ++ntab;
+                } else {
+                    table_ok = false;
+                }
+            }
+        }
+        U += __shfl(inc, 63);
+    }
+    wave_sync();
+    int npairs = 0;
+    if (table_ok) {  // remap_name in ascending label id
+        int rank = 0;
+        for (int t = 0; t < ntab; ++t) rank += (__shfl(tid_, t) < tid_) ? 1 : 0;
+        if (lane < ntab) pr[rank] = make_int2(tid_, tcnt);
+        npairs = ntab;
+    } else {
+        int curid = -1;
+        for (;;) {
+            int mn = 0x7fffffff;
+            for (int j = lane; j < U; j += 64) {
+                const int id = E.rep[uq[j]];
+                if (id > curid) mn = min(mn, id);
+            }
+            mn = wmin_i(mn);
+            if (mn == 0x7fffffff) break;
+            int cnt = 0;
+            for (int j = lane; j < U; j += 64) cnt += E.rep[uq[j]] == mn ? 1 : 0;
+            cnt = wsum_i(cnt);
+            if (lane == 0) pr[npairs] = make_int2(mn, cnt);
+            ++npairs;
+            curid = mn;
+        }
+    }
+    wave_sync();
+    return make_int2(npairs, U);
+}
+
+struct EntEval {        // what the walk needs of one cluster: remap_name against the fresh successor
+    int np, nu;
+    const int32_t* uq;  // sorted unique hit slots
+    const int2* pr;     // remap_name: {label name, count} with the ids in prid (one original cluster), else {id, count}
+    const int32_t* prid;
+    int L0, c0;         // first label's id and count (np >= 1)
+    uint32_t ct0;       // its fresh |occupy_voxels| + type, valid when have0
+    bool have0;
+    int size;           // points of the cluster's cloud (own + carried)
+};
+struct StepCounters {
+    int n_dirty, nl, n_newlab, n_created, n_cparts;
+};
+
+// SSC::tracking's decision and re-labelling for ONE walked cluster against the successor as it is now (ssc.cpp:1323-1421);
+// one wave, every lane runs it with the same arguments.  Returns Cluster::state.  links / dsz_now: where an appended
+// cloud is recorded (LDS on the fast path).
+__device__ __forceinline__ int commit_entry(const StepEnv& E, const TrackBatch& J, const ChainJob& C, const Wk& K, EntEval v, int k, const int32_t* car_j,
+                            int ncar_j, StepCounters& S, int4* links, int32_t* dsz_now) {
+    const int lane = threadIdx.x & 63;
+    const int nv = E.nv;
+    bool stale = false;
+    if (S.n_dirty) {
+        if (v.np == 1) {
+            stale = label_dirty(E, v.L0);
+        } else {
+            for (int p = lane; p < v.np; p += 64) stale |= label_dirty(E, v.prid ? v.prid[p] : v.pr[p].x);
+            stale = __any(stale);
+        }
+    }
+    if (stale) {  // an earlier cluster of this call re-labelled something this one hits: remap_name over the current labels
+        int np2 = 0, curid = -1;
+        for (;;) {
+            int mn = 0x7fffffff;
+            for (int j = lane; j < v.nu; j += 64) {
+                const int id = cur_label(E, v.uq[j]);
+                if (id > curid) mn = min(mn, id);
+            }
+            mn = wmin_i(mn);
+            if (mn == 0x7fffffff) break;
+            int cnt = 0;
+            for (int j = lane; j < v.nu; j += 64) cnt += cur_label(E, v.uq[j]) == mn ? 1 : 0;
+            cnt = wsum_i(cnt);
+            if (lane == 0) K.rp[np2] = make_int2(mn, cnt);
+            if (np2 == 0) {
+                v.L0 = mn;
+                v.c0 = cnt;
+            }
+            ++np2;
+            curid = mn;
+        }
+        wave_sync();
+        v.np = np2;
+        v.pr = K.rp;
+        v.prid = nullptr;
+        v.have0 = false;
+    }
+    int state = -1;
+    if (v.np == 0) {
+        state = 1;  // ssc.cpp:1323-1326
+    } else if (v.np == 1) {
+        const int L = v.L0, c = v.c0;
+        const uint32_t ct = (v.have0 && !S.n_dirty) ? v.ct0 : cur_cnttype(E, L);
+        const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
+        const float ratio = (float)c / (float)nvx;  // ssc.cpp:1336
+        if (ratio < J.occupancy) {
+            if (typ == 2) {
+                state = 1;  // ssc.cpp:1337-1349
+            } else {       // ssc.cpp:1351-1372: the hit voxels leave the label for a new cluster of the same type
+                state = 0;
+                const int Y = nv + S.n_newlab;
+                if (S.n_newlab < C.ws.cap_ent) {
+                    for (int j = lane; j < v.nu; j += 64)
+                        if (cur_label(E, v.uq[j]) == L) st64(&E.vlab[v.uq[j]], ((u64)E.epoch << 32) | (uint32_t)Y);
+                    if (lane == 0) {
+                        st64(&E.lcnt[L], ((u64)E.epoch << 32) | (uint32_t)(nvx - c) | ((uint32_t)typ << 28));
+                        st64(&E.lcnt[Y], ((u64)E.epoch << 32) | (uint32_t)c | ((uint32_t)typ << 28));
+                        st32(&K.newent[S.n_newlab], -1);
+                    }
+                    ++S.n_newlab;
+                    ++S.n_dirty;
+                } else if (lane == 0) {
+                    atomicOr(&C.stats[0], 4);
+                }
+                wave_sync();
+            }
+        } else if (typ == 2) {  // ssc.cpp:1377-1384: static, its transformed cloud joins the successor cluster's cloud
+            state = 0;
+            int dst;
+            if (L < nv)
+                dst = lower_bound_i(car_j, ncar_j, E.tab[L].y);
+            else
+                dst = ncar_j + ld32(&K.newent[L - nv]);
+            if (S.nl < C.ws.cap_ent) {
+                if (lane == 0) {
+                    links[S.nl] = make_int4(k, dst, v.size, 0);
+                    if (dsz_now) dsz_now[dst] += v.size;
+                }
+                ++S.nl;
+            } else if (lane == 0) {
+                atomicOr(&C.stats[0], 2);
+            }
+        }
+    } else {  // ssc.cpp:1396-1419: the car clusters hit at or above the ratio fuse into one new car cluster
+        state = 0;
+        if (S.n_newlab < C.ws.cap_ent && S.n_created < C.ws.cap_ent) {
+            const int N = nv + S.n_newlab;
+            const int q = S.n_created;
+            const int cbeg = S.n_cparts;
+            int cntN = 0;
+            for (int p = 0; p < v.np; ++p) {
+                const int L = v.prid ? v.prid[p] : v.pr[p].x;
+                const int c = v.pr[p].y;
+                const uint32_t ct = cur_cnttype(E, L);
+                const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
+                if (typ != 2 || !((float)c / (float)nvx >= J.occupancy)) continue;
+                if (L < nv) {
+                    const int o = lower_bound_i(car_j, ncar_j, E.tab[L].y);
+                    if (S.n_cparts < C.ws.cap_ent) {
+                        if (lane == 0) st32(&K.cparts[S.n_cparts], o);
+                        ++S.n_cparts;
+                    }
+                } else {
+                    const int4 m = K.cmeta[ld32(&K.newent[L - nv])];
+                    for (int z = 0; z < m.y; ++z) {
+                        if (S.n_cparts < C.ws.cap_ent) {
+                            if (lane == 0) st32(&K.cparts[S.n_cparts], ld32(&K.cparts[m.x + z]));
+                            ++S.n_cparts;
+                        }
+                    }
+                }
+                if (lane == 0) st64(&E.lfwd[L], ((u64)E.epoch << 32) | (uint32_t)N);
+                cntN += nvx;
+                wave_sync();
+            }
+            if (lane == 0) {
+                st64(&E.lcnt[N], ((u64)E.epoch << 32) | (uint32_t)(cntN & 0x0fffffff) | (2u << 28));
+                st32(&K.newent[S.n_newlab], q);
+                K.cmeta[q] = make_int4(cbeg, S.n_cparts - cbeg, N, 0);
+            }
+            ++S.n_newlab;
+            ++S.n_created;
+            ++S.n_dirty;
+            wave_sync();
+        } else if (lane == 0) {
+            atomicOr(&C.stats[0], 4);
+        }
+    }
+    return state;
+}
+
 // One step of the chain: SSC::tracking(frame si, frame sj) on the state in slot `cur`; leaves the successor's state (as the
 // next `pre`) in slot cur ^ 1.  write_out: states / dynamic counters of frame si are the chain's result (not warm-up).
-__device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
-                           uint32_t* bits_all, int cur, int si, int sj, bool write_out, int from_apri) {
+// GENERIC path: any number of clusters, everything through the workspace in HBM.
+__device__ __forceinline__ void chain_step_big(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
+                               uint32_t* bits_all, int cur, int si, int sj, bool write_out, int from_apri) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base_i = A.scan_off[si], base_j = A.scan_off[sj];
     const int nv = A.counts[sj * 8 + 6];
@@ -266,43 +649,11 @@ __device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch&
         const int ns = (nv + (1 << shift) - 1) >> shift;
         for (int j = tid; j < ns; j += kChThreads) sh.skeys[j] = tab[(size_t)j << shift].x;
         __syncthreads();
-        for (int c = tid; c < ncarried; c += kChThreads) {
-            const float4 q = pool[c];
-            // Utility::transformCloud (utility.h:401-404): explicit fp32 dot products, no FMA
-            const float x = T[0] * q.x + T[1] * q.y + T[2] * q.z + T[3];
-            const float y = T[4] * q.x + T[5] * q.y + T[6] * q.z + T[7];
-            const float z = T[8] * q.x + T[9] * q.y + T[10] * q.z + T[11];
-            pool[c] = make_float4(x, y, z, q.w);
-            Apri a;
-            apri_of_point(P.bin, x, y, z, q.w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
-            const int key = a.voxel_idx;
-            int lo = 0, hi = ns;  // first sample > key
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (sh.skeys[mid] <= key)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            int slot = -1;
-            if (lo > 0) {
-                int a0 = (lo - 1) << shift;
-                const int a1 = min(a0 + (1 << shift), nv);
-                for (; a0 < a1; ++a0) {
-                    const int4 rec = tab[a0];
-                    if (rec.x >= key) {
-                        if (rec.x == key && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
-                        break;
-                    }
-                }
-            }
-            K.chit[c] = slot;
-        }
+        carried_probe(P, K, pool, ncarried, T, tab, nv, sh.skeys, ns, shift);
     }
     __syncthreads();
 
-    // ---- phase 2: entries the first-order pass could not decide (appended points, fused clusters): sorted unique hit list
-    // (sampleVec) through a bitset over the successor's table, then remap_name against the FRESH labels ----
+    // ---- phase 2: entries the first-order pass could not decide (appended points, fused clusters) ----
     {
         const int words = C.words;
         const int nw = (nv + 31) >> 5;
@@ -317,219 +668,44 @@ __device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch&
                 if (e0.y == 1 && e0.w == 0) continue;  // one original cluster, nothing appended: scvod_track.hip's result stands
                 if ((cx++ % C.n_eval_waves) != wave) continue;
                 const int4 e1 = ent[2 * k + 1];
-                int wlo = 0x7fffffff, whi = -1;
-                for (int p = 0; p < e0.y; ++p) {
-                    const int root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
-                    const int mb = A.tk_mbegin[(size_t)base_i + root];
-                    const int nu = A.tk_nuniq[(size_t)base_i + root];
-                    for (int j = lane; j < nu; j += 64) {
-                        const int slot = A.tk_uniq[(size_t)base_i + mb + j];
-                        atomicOr(&bits[slot >> 5], 1u << (slot & 31));
-                        wlo = min(wlo, slot >> 5);
-                        whi = max(whi, slot >> 5);
-                    }
-                }
-                for (int c = lane; c < e0.w; c += 64) {
-                    const int slot = K.chit[e0.z + c];
-                    if (slot >= 0) {
-                        atomicOr(&bits[slot >> 5], 1u << (slot & 31));
-                        wlo = min(wlo, slot >> 5);
-                        whi = max(whi, slot >> 5);
-                    }
-                }
-                wlo = wmin_i(wlo);
-                whi = wmax_i(whi);
-                wave_sync();
-                int32_t* uq = K.suniq + e1.y + e0.z;  // region of own points + carried points of the entry
-                int2* pr = K.spairs + e1.y + e0.z;
-                int U = 0;
-                for (int w0 = wlo; w0 <= whi; w0 += 64) {
-                    const int w = w0 + lane;
-                    uint32_t word = 0u;
-                    if (w <= whi) {
-                        word = bits[w];
-                        bits[w] = 0u;
-                    }
-                    const int c = __popc(word);
-                    const int inc = wave_incl_scan(c);
-                    int o = U + inc - c;
-                    while (word) {
-                        const int b = __ffs(word) - 1;
-                        word &= word - 1;
-                        uq[o++] = (w << 5) + b;
-                    }
-                    U += __shfl(inc, 63);
-                }
-                wave_sync();
-                int npairs = 0, curid = -1;
-                for (;;) {
-                    int mn = 0x7fffffff;
-                    for (int j = lane; j < U; j += 64) {
-                        const int id = E.rep[uq[j]];
-                        if (id > curid) mn = min(mn, id);
-                    }
-                    mn = wmin_i(mn);
-                    if (mn == 0x7fffffff) break;
-                    int cnt = 0;
-                    for (int j = lane; j < U; j += 64) cnt += E.rep[uq[j]] == mn ? 1 : 0;
-                    cnt = wsum_i(cnt);
-                    if (lane == 0) pr[npairs] = make_int2(mn, cnt);
-                    ++npairs;
-                    curid = mn;
-                }
-                if (lane == 0) K.evr[k] = make_int2(npairs, U);
+                const int2 r = eval_entry(A, K, E, base_i, parts, e0, bits, K.suniq + e1.y + e0.z, K.spairs + e1.y + e0.z);
+                if (lane == 0) K.evr[k] = r;
             }
         }
     }
     __syncthreads();
 
     // ---- phase 3: the clusters in walking order, one wave: decision against the successor AS IT IS NOW, re-labelling ----
-    int nl = 0, n_newlab = 0, n_created = 0, n_cparts = 0;
     if (wave == 0) {
-        int n_dirty = 0, ndc = 0, ndp = 0;
+        StepCounters S = {0, 0, 0, 0, 0};
+        int ndc = 0, ndp = 0;
         const int32_t* car_j = A.tk_clusters + base_j;
         for (int k = 0; k < nent; ++k) {
             const int4 e0 = ent[2 * k];
             const int4 e1 = ent[2 * k + 1];
-            const bool simple = (e0.y == 1 && e0.w == 0);
-            int np, nu;
-            const int32_t* uq;
-            const int2* pr;        // simple: {label name, count} + ids in prid; otherwise {id, count}
-            const int32_t* prid;
-            if (simple) {
+            EntEval v;
+            if (e0.y == 1 && e0.w == 0) {
                 const int root = A.tk_clusters[(size_t)base_i + parts[e0.x]];
                 const int mb = A.tk_mbegin[(size_t)base_i + root];
-                np = A.tk_npairs[(size_t)base_i + root];
-                nu = A.tk_nuniq[(size_t)base_i + root];
-                uq = A.tk_uniq + (size_t)base_i + mb;
-                pr = A.tk_pairs + (size_t)base_i + mb;
-                prid = A.tk_prep + (size_t)base_i + mb;
+                v.np = A.tk_npairs[(size_t)base_i + root];
+                v.nu = A.tk_nuniq[(size_t)base_i + root];
+                v.uq = A.tk_uniq + (size_t)base_i + mb;
+                v.pr = A.tk_pairs + (size_t)base_i + mb;
+                v.prid = A.tk_prep + (size_t)base_i + mb;
             } else {
                 const int2 r = K.evr[k];
-                np = r.x;
-                nu = r.y;
-                uq = K.suniq + e1.y + e0.z;
-                pr = K.spairs + e1.y + e0.z;
-                prid = nullptr;
+                v.np = r.x;
+                v.nu = r.y;
+                v.uq = K.suniq + e1.y + e0.z;
+                v.pr = K.spairs + e1.y + e0.z;
+                v.prid = nullptr;
             }
-            bool stale = false;
-            if (n_dirty) {
-                for (int p = lane; p < np; p += 64) stale |= label_dirty(E, prid ? prid[p] : pr[p].x);
-                stale = __any(stale);
-            }
-            if (stale) {  // an earlier cluster of this call re-labelled something this one hits: remap_name over the current labels
-                int np2 = 0, curid = -1;
-                for (;;) {
-                    int mn = 0x7fffffff;
-                    for (int j = lane; j < nu; j += 64) {
-                        const int id = cur_label(E, uq[j]);
-                        if (id > curid) mn = min(mn, id);
-                    }
-                    mn = wmin_i(mn);
-                    if (mn == 0x7fffffff) break;
-                    int cnt = 0;
-                    for (int j = lane; j < nu; j += 64) cnt += cur_label(E, uq[j]) == mn ? 1 : 0;
-                    cnt = wsum_i(cnt);
-                    if (lane == 0) K.rp[np2] = make_int2(mn, cnt);
-                    ++np2;
-                    curid = mn;
-                }
-                wave_sync();
-                np = np2;
-                pr = K.rp;
-                prid = nullptr;
-            }
-            int state = -1;
-            if (np == 0) {
-                state = 1;  // ssc.cpp:1323-1326
-            } else if (np == 1) {
-                const int L = prid ? prid[0] : pr[0].x;
-                const int c = pr[0].y;
-                const uint32_t ct = cur_cnttype(E, L);
-                const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
-                const float ratio = (float)c / (float)nvx;  // ssc.cpp:1336
-                if (ratio < J.occupancy) {
-                    if (typ == 2) {
-                        state = 1;  // ssc.cpp:1337-1349
-                    } else {       // ssc.cpp:1351-1372: the hit voxels leave the label for a new cluster of the same type
-                        state = 0;
-                        const int Y = nv + n_newlab;
-                        if (n_newlab < C.ws.cap_ent) {
-                            for (int j = lane; j < nu; j += 64)
-                                if (cur_label(E, uq[j]) == L) st64(&E.vlab[uq[j]], ((u64)E.epoch << 32) | (uint32_t)Y);
-                            if (lane == 0) {
-                                st64(&E.lcnt[L], ((u64)E.epoch << 32) | (uint32_t)(nvx - c) | ((uint32_t)typ << 28));
-                                st64(&E.lcnt[Y], ((u64)E.epoch << 32) | (uint32_t)c | ((uint32_t)typ << 28));
-                                st32(&K.newent[n_newlab], -1);
-                            }
-                            ++n_newlab;
-                            ++n_dirty;
-                        } else if (lane == 0) {
-                            atomicOr(&C.stats[0], 4);
-                        }
-                        wave_sync();
-                    }
-                } else if (typ == 2) {  // ssc.cpp:1377-1384: static, its transformed cloud joins the successor cluster's cloud
-                    state = 0;
-                    int dst;
-                    if (L < nv) {
-                        const int o = lower_bound_i(car_j, ncar_j, tab[L].y);
-                        dst = o;
-                    } else {
-                        dst = ncar_j + ld32(&K.newent[L - nv]);
-                    }
-                    if (nl < C.ws.cap_ent) {
-                        if (lane == 0) K.links[nl] = make_int4(k, dst, e1.x + e0.w, 0);
-                        ++nl;
-                    } else if (lane == 0) {
-                        atomicOr(&C.stats[0], 2);
-                    }
-                }
-            } else {  // ssc.cpp:1396-1419: the car clusters hit at or above the ratio fuse into one new car cluster
-                state = 0;
-                if (n_newlab < C.ws.cap_ent && n_created < C.ws.cap_ent) {
-                    const int N = nv + n_newlab;
-                    const int q = n_created;
-                    const int cbeg = n_cparts;
-                    int cntN = 0;
-                    for (int p = 0; p < np; ++p) {
-                        const int L = prid ? prid[p] : pr[p].x;
-                        const int c = pr[p].y;
-                        const uint32_t ct = cur_cnttype(E, L);
-                        const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
-                        if (typ != 2 || !((float)c / (float)nvx >= J.occupancy)) continue;
-                        if (L < nv) {
-                            const int o = lower_bound_i(car_j, ncar_j, tab[L].y);
-                            if (n_cparts < C.ws.cap_ent) {
-                                if (lane == 0) st32(&K.cparts[n_cparts], o);
-                                ++n_cparts;
-                            }
-                        } else {
-                            const int4 m = K.cmeta[ld32(&K.newent[L - nv])];
-                            for (int z = 0; z < m.y; ++z) {
-                                if (n_cparts < C.ws.cap_ent) {
-                                    if (lane == 0) st32(&K.cparts[n_cparts], ld32(&K.cparts[m.x + z]));
-                                    ++n_cparts;
-                                }
-                            }
-                        }
-                        if (lane == 0) st64(&E.lfwd[L], ((u64)E.epoch << 32) | (uint32_t)N);
-                        cntN += nvx;
-                        wave_sync();
-                    }
-                    if (lane == 0) {
-                        st64(&E.lcnt[N], ((u64)E.epoch << 32) | (uint32_t)(cntN & 0x0fffffff) | (2u << 28));
-                        st32(&K.newent[n_newlab], q);
-                        K.cmeta[q] = make_int4(cbeg, n_cparts - cbeg, N, 0);
-                    }
-                    ++n_newlab;
-                    ++n_created;
-                    ++n_dirty;
-                    wave_sync();
-                } else if (lane == 0) {
-                    atomicOr(&C.stats[0], 4);
-                }
-            }
+            v.L0 = v.np >= 1 ? (v.prid ? v.prid[0] : v.pr[0].x) : -1;
+            v.c0 = v.np >= 1 ? v.pr[0].y : 0;
+            v.ct0 = 0;
+            v.have0 = false;
+            v.size = e1.x + e0.w;
+            const int state = commit_entry(E, J, C, K, v, k, car_j, ncar_j, S, K.links, nullptr);
             if (write_out) {
                 for (int p = lane; p < e0.y; p += 64) {
                     const int root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
@@ -546,6 +722,7 @@ __device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch&
             A.tk_scan[si * 4 + 3] = ndp;
         }
         wave_sync();
+        const int nl = S.nl, n_created = S.n_created;
 
         // ---- the successor as the next `pre`: its car clusters that are still there in ascending name, then the created ones in
         // creation order; every one with the clouds appended to it ----
@@ -633,7 +810,7 @@ __device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch&
         }
     }
     __syncthreads();
-    nl = sh.bc[0];
+    const int nl = sh.bc[0];
 
     // ---- phase 4: the appended clouds: cloud_use of the walked cluster's parts, transformed, then what it carried ----
     float4* npool = K.pool[nxt];
@@ -667,8 +844,339 @@ __device__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch&
     __syncthreads();
 }
 
+// The same step when the walked clusters and the successor's car clusters fit the LDS tables (nent <= kLdsEnt,
+// ncar_j + nent <= 2 kLdsEnt: every street scan): all threads fetch what the walk needs of every cluster at once -- the
+// first-order remap_name head, the fresh |occupy_voxels| and type of its first label -- so that the sequential walk of one
+// wave runs on LDS and touches HBM only where a re-labelling happened; the appended clouds are copied in one flat pass.
+__device__ __forceinline__ void chain_step_small(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
+                                 uint32_t* bits_all, int cur, int si, int sj, bool write_out, int from_apri) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ShSmall& M = sh.sm;
+    const int base_i = A.scan_off[si], base_j = A.scan_off[sj];
+    const int nv = A.counts[sj * 8 + 6];
+    const int ncar_j = A.tk_scan[sj * 4 + 0];
+    const int4* tab = A.vox_track + base_j;
+    const int nent = K.hdr[H_NENT + cur];
+    const int ncarried = K.hdr[H_NCARRIED + cur];
+    const int4* ent = K.ent[cur];
+    const int32_t* parts = K.parts[cur];
+    float4* pool = K.pool[cur];
+    const int nxt = cur ^ 1;
+    const int32_t* car_j = A.tk_clusters + base_j;
+    StepEnv E;
+    E.tab = tab;
+    E.rep = A.vox_rep + base_j;
+    E.nv = nv;
+    E.vlab = K.vlab;
+    E.lcnt = K.lcnt;
+    E.lfwd = K.lfwd;
+    float T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = J.T[12 * si + i];
+
+    // ---- A: everything the step reads of the two frames, fetched by all threads at once ----
+    CH_T0;
+    int shift = 0;
+    while (((nv + (1 << shift) - 1) >> shift) > kSmSamples) ++shift;
+    const int ns = (nv + (1 << shift) - 1) >> shift;
+    if (ncarried > 0)
+        for (int j = tid; j < ns; j += kChThreads) M.skeys[j] = tab[(size_t)j << shift].x;
+    int any_complex = 0;
+    for (int k = tid; k < nent; k += kChThreads) {
+        const int4 e0 = ent[2 * k], e1 = ent[2 * k + 1];
+        if (e0.y == 1 && e0.w == 0) {
+            const int root = A.tk_clusters[(size_t)base_i + parts[e0.x]];
+            const int mb = A.tk_mbegin[(size_t)base_i + root];
+            const int np = A.tk_npairs[(size_t)base_i + root];
+            int L0 = -1, c0 = 0;
+            uint32_t ct0 = 0;
+            if (np >= 1) {
+                L0 = A.tk_prep[(size_t)base_i + mb];
+                c0 = A.tk_pairs[(size_t)base_i + mb].y;
+                const int4 r = tab[L0];
+                ct0 = (uint32_t)r.z | ((uint32_t)r.w << 28);
+            }
+            M.fr[k] = make_int4(np, A.tk_nuniq[(size_t)base_i + root], L0, c0);
+            M.fx[k] = make_int4((int)ct0, root, e1.x, e1.x);
+            M.fuo[k] = mb;
+        } else {
+            M.fr[k] = make_int4(0, 0, -1, 0);
+            M.fx[k] = make_int4(0, -1, e1.x + e0.w, e1.x);
+            M.fuo[k] = e1.y + e0.z;
+            any_complex = 1;
+        }
+    }
+    for (int e = tid; e < ncar_j; e += kChThreads) {
+        M.nown[e] = A.cl_count[(size_t)base_j + car_j[e]];
+        M.ncrep[e] = A.tk_crep[(size_t)base_j + e];
+    }
+    for (int e = tid; e < ncar_j + nent; e += kChThreads) M.dsz[e] = 0;
+    if (tid == 0) K.hdr[H_EPOCH] = K.hdr[H_EPOCH] + 1;
+    any_complex = __syncthreads_or(any_complex);
+    E.epoch = (uint32_t)K.hdr[H_EPOCH];
+    CH_MARK(0);
+
+    // ---- B: the carried points ----
+    if (ncarried > 0) {
+        carried_probe(P, K, pool, ncarried, T, tab, nv, M.skeys, ns, shift);
+        __syncthreads();
+    }
+    CH_MARK(1);
+
+    // ---- C: clusters that carry appended points / fused clusters: their remap_name against the fresh successor ----
+    if (any_complex) {
+        const int nw = max((nv + 31) >> 5, 1);
+        const int total_words = C.words * C.n_eval_waves;
+        const int n_eval = min(kChWaves, total_words / nw);
+        if (n_eval < 1) {
+            if (tid == 0) atomicOr(&C.stats[0], 8);
+        } else if (wave < n_eval) {
+            uint32_t* bits = bits_all + (size_t)wave * nw;
+            int cx = 0;
+            for (int k = 0; k < nent; ++k) {
+                if (M.fx[k].y >= 0) continue;
+                if ((cx++ % n_eval) != wave) continue;
+                const int4 e0 = ent[2 * k];
+                int32_t* uq = K.suniq + M.fuo[k];
+                int2* pr = K.spairs + M.fuo[k];
+                const int2 r = eval_entry(A, K, E, base_i, parts, e0, bits, uq, pr);
+                if (lane == 0) {
+                    int L0 = -1, c0 = 0;
+                    uint32_t ct0 = 0;
+                    if (r.x >= 1) {
+                        const int2 p0 = pr[0];
+                        L0 = p0.x;
+                        c0 = p0.y;
+                        const int4 t = tab[L0];
+                        ct0 = (uint32_t)t.z | ((uint32_t)t.w << 28);
+                    }
+                    M.fr[k] = make_int4(r.x, r.y, L0, c0);
+                    M.fx[k].x = (int)ct0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    CH_MARK(2);
+
+    // ---- D: the walk (one wave, LDS) and the successor's next state ----
+    if (wave == 0) {
+        StepCounters S = {0, 0, 0, 0, 0};
+        int ndc = 0, ndp = 0;
+        for (int k = 0; k < nent; ++k) {
+            const int4 fr = M.fr[k], fx = M.fx[k];
+            const int uo = M.fuo[k];
+            EntEval v;
+            v.np = fr.x;
+            v.nu = fr.y;
+            if (fx.y >= 0) {
+                v.uq = A.tk_uniq + (size_t)base_i + uo;
+                v.pr = A.tk_pairs + (size_t)base_i + uo;
+                v.prid = A.tk_prep + (size_t)base_i + uo;
+            } else {
+                v.uq = K.suniq + uo;
+                v.pr = K.spairs + uo;
+                v.prid = nullptr;
+            }
+            v.L0 = fr.z;
+            v.c0 = fr.w;
+            v.ct0 = (uint32_t)fx.x;
+            v.have0 = true;
+            v.size = fx.z;
+            const int state = commit_entry(E, J, C, K, v, k, car_j, ncar_j, S, M.lk, M.dsz);
+            if (write_out) {
+                if (fx.y >= 0) {
+                    if (lane == 0) A.cl_state[(size_t)base_i + fx.y] = (int8_t)state;
+                } else {
+                    const int4 e0 = ent[2 * k];
+                    for (int p = lane; p < e0.y; p += 64) A.cl_state[(size_t)base_i + A.tk_clusters[(size_t)base_i + parts[e0.x + p]]] = (int8_t)state;
+                }
+                if (state == 1) {
+                    ++ndc;
+                    ndp += fx.w;
+                }
+            }
+        }
+        if (write_out && lane == 0) {
+            A.tk_scan[si * 4 + 2] = ndc;
+            A.tk_scan[si * 4 + 3] = ndp;
+        }
+        wave_sync();
+        const int nl = S.nl, n_created = S.n_created;
+        const int ntot = ncar_j + n_created;
+        int4* nent_rec = K.ent[nxt];
+        int32_t* nparts = K.parts[nxt];
+        int run_e = 0, run_c = 0, run_p = 0, run_o = 0;
+        for (int eb = 0; eb < ntot; eb += 64) {
+            const int e = eb + lane;
+            bool alive = false;
+            int pc = 0, own = 0, csz = 0, pbeg_src = 0;
+            if (e < ncar_j) {
+                const int id = M.ncrep[e];
+                alive = id >= 0 && (S.n_dirty == 0 || !stamped(ld64(&E.lfwd[id]), E.epoch));
+                pc = 1;
+                own = M.nown[e];
+            } else if (e < ntot) {
+                const int4 m = K.cmeta[e - ncar_j];
+                alive = !stamped(ld64(&E.lfwd[m.z]), E.epoch);
+                pc = m.y;
+                pbeg_src = m.x;
+                for (int z = 0; z < m.y; ++z) own += M.nown[ld32(&K.cparts[m.x + z])];
+            }
+            if (e < ntot) csz = M.dsz[e];
+            if (!alive) pc = own = csz = 0;
+            const int ie = wave_incl_scan(alive ? 1 : 0), ic = wave_incl_scan(csz), ip = wave_incl_scan(pc), io = wave_incl_scan(own);
+            if (e < ntot) M.eidx[e] = alive ? run_e + ie - 1 : -1;
+            if (alive) {
+                const int idx = run_e + ie - 1;
+                M.ncb[idx] = run_c + ic - csz;
+                nent_rec[2 * idx] = make_int4(run_p + ip - pc, pc, run_c + ic - csz, csz);
+                nent_rec[2 * idx + 1] = make_int4(own, run_o + io - own, 0, 0);
+                if (e < ncar_j) {
+                    nparts[run_p + ip - pc] = e;
+                } else {
+                    for (int z = 0; z < pc; ++z) nparts[run_p + ip - pc + z] = ld32(&K.cparts[pbeg_src + z]);
+                }
+            }
+            run_e += __shfl(ie, 63);
+            run_c += __shfl(ic, 63);
+            run_p += __shfl(ip, 63);
+            run_o += __shfl(io, 63);
+        }
+        const bool overflow = run_c > C.ws.cap_pool;  // (entries and parts: <= 2 kLdsEnt <= cap_ent)
+        if (overflow) {  // the appended clouds do not fit: flagged, the chain continues without them
+            if (lane == 0) atomicOr(&C.stats[0], 1);
+            for (int i = lane; i < run_e; i += 64) {
+                int4 r = nent_rec[2 * i];
+                r.z = r.w = 0;
+                nent_rec[2 * i] = r;
+            }
+            run_c = 0;
+        }
+        wave_sync();
+        for (int e = lane; e < ntot; e += 64) M.dsz[e] = 0;  // cursors
+        wave_sync();
+        if (lane == 0) {
+            int tot = 0;
+            for (int l = 0; l < nl; ++l) {
+                int4 L = M.lk[l];
+                const int idx = M.eidx[L.y];
+                M.lpre[l] = tot;
+                if (idx < 0 || overflow) {
+                    L.w = -1;  // fused later in the same call (cloud_use only, ssc.cpp:1412) or dropped
+                } else {
+                    L.w = M.ncb[idx] + M.dsz[L.y];
+                    M.dsz[L.y] += L.z;
+                    tot += L.z;
+                }
+                M.lk[l] = L;
+            }
+            M.lpre[nl] = tot;
+            K.hdr[H_NENT + nxt] = run_e;
+            K.hdr[H_NCARRIED + nxt] = run_c;
+            K.hdr[H_NPARTS + nxt] = run_p;
+            sh.bc[0] = nl;
+            sh.bc[1] = tot;
+        }
+    }
+    __syncthreads();
+    CH_MARK(3);
+
+    // ---- F: the appended clouds in one flat pass: cloud_use of the walked cluster (transformed), then what it carried ----
+    const int nl = sh.bc[0], total = sh.bc[1];
+    float4* npool = K.pool[nxt];
+#ifndef CH_UF
+#define CH_UF 4
+#endif
+    constexpr int UF = CH_UF;  // four points per thread and round: the three dependent gathers of each overlap
+    for (int t0 = tid; t0 < total; t0 += kChThreads * UF) {
+        int dsti[UF], idx[UF];   // destination in the next pool; member slot (own point) or pool index (carried point)
+        bool own[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int t = t0 + u * kChThreads;
+            dsti[u] = -1;
+            idx[u] = 0;
+            own[u] = false;
+            if (t >= total) continue;
+            int lo = 0, hi = nl;  // the last link whose offset is <= t: the one that holds point t (links that copy nothing repeat an offset)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (M.lpre[mid] <= t)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int4 L = M.lk[lo];
+            int r = t - M.lpre[lo];
+            dsti[u] = L.w + r;
+            const int4 fx = M.fx[L.x];
+            if (fx.y >= 0) {  // one original cluster, nothing carried: all of the link is own points
+                own[u] = true;
+                idx[u] = M.fuo[L.x] + r;
+            } else if (r < fx.w) {
+                const int4 e0 = ent[2 * L.x];
+                int root = 0;
+                for (int p = 0; p < e0.y; ++p) {
+                    root = A.tk_clusters[(size_t)base_i + parts[e0.x + p]];
+                    const int cnt = A.cl_count[(size_t)base_i + root];
+                    if (r < cnt) break;
+                    r -= cnt;
+                }
+                own[u] = true;
+                idx[u] = A.tk_mbegin[(size_t)base_i + root] + r;
+            } else {
+                idx[u] = ent[2 * L.x].z + (r - fx.w);
+            }
+        }
+        int mi[UF];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) mi[u] = own[u] ? A.tk_members[(size_t)base_i + idx[u]] : 0;
+        float4 q[UF];
+        if (!from_apri) {
+#pragma unroll
+            for (int u = 0; u < UF; ++u) mi[u] = own[u] ? A.apri_src[(size_t)base_i + mi[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < UF; ++u) q[u] = own[u] ? A.pts[base_i + mi[u]] : pool[idx[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                if (own[u]) {
+                    const scvod_apri& a = A.apri[(size_t)base_i + mi[u]];
+                    q[u] = make_float4(a.x, a.y, a.z, a.intensity);
+                } else {
+                    q[u] = pool[idx[u]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            if (dsti[u] < 0) continue;
+            if (own[u]) {
+                const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
+                const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
+                const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
+                q[u] = make_float4(x, y, z, q[u].w);
+            }
+            npool[dsti[u]] = q[u];
+        }
+    }
+    __syncthreads();
+    CH_MARK(4);
+}
+
+__device__ __forceinline__ void chain_step(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
+                                           uint32_t* bits_all, int cur, int si, int sj, bool write_out, int from_apri) {
+    const int nent = K.hdr[H_NENT + cur];
+    const int ncar_j = A.tk_scan[sj * 4 + 0];
+    if (nent <= kLdsEnt && ncar_j + nent <= 2 * kLdsEnt && !C.force_generic)
+        chain_step_small(P, A, J, C, K, sh, bits_all, cur, si, sj, write_out, from_apri);
+    else
+        chain_step_big(P, A, J, C, K, sh, bits_all, cur, si, sj, write_out, from_apri);
+}
+
 // walks steps [t_begin, t_end) of a chain on workspace K starting from the state in slot `cur`; returns the slot of the final state
-__device__ int walk(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
+__device__ __forceinline__ int walk(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
                     uint32_t* bits, const ChainWalker& W, int cur, int t_begin, int t_end, int out_from, int snap_at, int from_apri) {
     const int32_t* frames = C.chain_scans + W.first;
     for (int t = t_begin; t < t_end; ++t) {
@@ -698,20 +1206,43 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain(DevParams P, Arena A, T
     if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
 }
 
-// verification pass: one workgroup per chain; a segment whose warm-up did not reproduce the state its predecessor really
-// ended in is walked again from that state
+// verification, part 1: one workgroup per segment compares the state its predecessor ended in with its warm-up's snapshot
+__global__ __launch_bounds__(kChThreads) void k_tk_chain_cmp(ChainJob C) {
+    const int w = blockIdx.x;
+    const ChainWalker W = C.walkers[w];
+    const Wk K = wk_of(C.ws, w);
+    int ok = 1;
+    if (W.a > 0) {  // (the first segment of a chain starts from the true state)
+        const Wk Kp = wk_of(C.ws, w - 1);
+        ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, Kp.hdr[H_END_SLOT], K, 2);
+    }
+    if (threadIdx.x == 0) K.hdr[H_SNAP_OK] = ok;
+}
+
+// verification, part 2: one workgroup per chain; a segment whose warm-up did not reproduce the state its predecessor really
+// ended in is walked again from that state (and its successor compared again with the new end state)
 __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena A, TrackBatch J, ChainJob C, int from_apri) {
     __shared__ Shared sh;
     extern __shared__ uint32_t ch_bits[];
+    const int w0 = C.chain_first_walker[blockIdx.x], w1 = C.chain_first_walker[blockIdx.x + 1];
+    int all_ok = 1;
+    for (int w = w0 + 1 + (int)threadIdx.x; w < w1; w += kChThreads) all_ok &= wk_of(C.ws, w).hdr[H_SNAP_OK];
+    all_ok = __syncthreads_and(all_ok);
+    if (threadIdx.x == 0) atomicAdd(&C.stats[2], w1 - w0 - 1);
+    if (all_ok) return;
     for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
     __syncthreads();
-    const int w0 = C.chain_first_walker[blockIdx.x], w1 = C.chain_first_walker[blockIdx.x + 1];
+    bool prev_rewalked = false;
     for (int w = w0 + 1; w < w1; ++w) {
         const ChainWalker W = C.walkers[w];
         const Wk K = wk_of(C.ws, w), Kp = wk_of(C.ws, w - 1);
         const int pend = Kp.hdr[H_END_SLOT];
-        bool ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, pend, K, 2);
-        if (threadIdx.x == 0) atomicAdd(&C.stats[2], 1);
+        bool ok;
+        if (prev_rewalked)  // the predecessor's end state changed: compare again
+            ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, pend, K, 2);
+        else
+            ok = K.hdr[H_SNAP_OK] != 0;
+        prev_rewalked = !ok;
         if (ok) continue;
         if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
         copy_state(Kp, pend, K, 0);
@@ -731,6 +1262,7 @@ void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J,
     hipLaunchKernelGGL(k_tk_chain, dim3(C.n_walkers), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
     if (th) th(tu, "tk_chain", 0);
     if (th) th(tu, "tk_chain_fix", 1);
+    hipLaunchKernelGGL(k_tk_chain_cmp, dim3(C.n_walkers), dim3(kChThreads), 0, st, C);
     hipLaunchKernelGGL(k_tk_chain_fix, dim3(C.n_chains), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
     if (th) th(tu, "tk_chain_fix", 0);
 }

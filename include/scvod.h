@@ -288,6 +288,7 @@ int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_sc
  * n_unique / pair_* of scvod_track_result always describe a cluster's OWN points against the fresh successor. */
 #define SCVOD_TRACK_CHAIN 1
 #define SCVOD_TRACK_FIRST_ORDER 0
+#define SCVOD_TRACK_CHAIN_GENERIC 3 /* testing: the chain with every step through the kernel's generic (HBM-resident) step */
 int scvod_set_track_mode(scvod_ctx* ctx, int32_t mode, int32_t segment_steps, int32_t warmup_steps);
 /* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
  * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.

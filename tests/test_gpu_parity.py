@@ -504,7 +504,7 @@ def test_tracking_chain_equals_the_reference_chain(scvod, oracle, kind, preset, 
     dyn2, _ = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), poses, chain=2)
     assert int((dyn2 != dyn).sum()) > 0
     for seg, warm in ((5, 0), (7, 3), (64, 0)):
-        ctx.set_track_mode(chain=True, segment_steps=seg, warmup_steps=warm)
+        ctx.set_track_mode(chain=True, segment_steps=seg, warmup_steps=warm, generic_step=(seg == 7))  # (both step functions of the kernel)
         ctx.batch_track(T)
         st = ctx.batch_track_stats()
         assert st["segments"] == -(-(count - 1) // seg) and st["verified"] == st["segments"] - 1
