@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/scvod.h"
+#include <algorithm>
 #include "scvod_kernels.h"
 #include "scvod_chain.h"
 
@@ -68,7 +69,8 @@ struct scvod_ctx {
     bool track_valid = false;
     // sequential tracking chain (scvod_chain.hip)
     int track_mode = SCVOD_TRACK_CHAIN;
-    int chain_seg = 24, chain_warm = 16;     // steps per segment, warm-up steps in front of it
+    int chain_seg = 0, chain_warm = 12;      // steps per segment (0: from the job, ~250 segments), warm-up steps in front of it
+    int chain_seg_used = 0;
     bool chain_generic = false;              // testing: every step through the generic (HBM-resident) step function
     int32_t* d_chain_scans = nullptr;        // [cap_scans]
     ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
@@ -395,6 +397,8 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->types_valid = false;
     c->track_valid = false;
     c->tables_valid = false;
+    // marks per input point for the static map (car-cluster member / dynamic / list marks): clean for every new batch
+    if (mx > 0 && do_patchwork != 2 && do_patchwork != 3) HIPCHK(c, hipMemsetAsync(c->A.pt_mapcls, 0, (size_t)total, st));
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     if (mx == 0) {  // every scan empty: no kernel runs (neither here nor in the clustering / tracking launches): clean per-scan words
@@ -678,7 +682,16 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
     fw.assign(1, 0);
     walkers.clear();
     std::vector<char> seen(B, 0);
-    const int seg = c->chain_seg > 0 ? c->chain_seg : 1, warm = c->chain_warm > 0 ? c->chain_warm : 0;
+    // segment length: given, or such that the job has about as many segments as the device has CUs (a walker fills one)
+    int seg = c->chain_seg;
+    if (seg <= 0) {
+        long long steps_total = 0;
+        for (int s = 0; s < B; ++s) steps_total += next[s] >= 0 ? 1 : 0;
+        seg = (int)((steps_total + 249) / 250);
+        if (seg < 4) seg = 4;
+    }
+    c->chain_seg_used = seg;
+    const int warm = c->chain_warm > 0 ? c->chain_warm : 0;
     int n_chains = 0;
     for (int h = 0; h < B; ++h) {
         if (pred[h] != -1 || next[h] < 0) continue;  // not a head, or a head without a successor in the batch
@@ -708,6 +721,7 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
 }  // namespace
 
 // internal bridge for scvod_map.hip (not part of the public header)
+extern "C" int scvod__ctx_types_valid(scvod_ctx* c) { return (c->clusters_valid && c->types_valid) ? 1 : 0; }
 extern "C" int scvod__ctx_view(scvod_ctx* c, Arena* arena, int* device, int* track_valid, int* batch_valid, int* n_scans,
                                int* max_scan_pts, int* batch_mode, int* num_min_pts) {
     *batch_mode = c->batch_mode;
@@ -1186,12 +1200,12 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
 int scvod_set_track_mode(scvod_ctx* c, int32_t mode, int32_t segment_steps, int32_t warmup_steps) {
     if (!c || (mode != SCVOD_TRACK_CHAIN && mode != SCVOD_TRACK_FIRST_ORDER && mode != SCVOD_TRACK_CHAIN_GENERIC))
         return fail(c, SCVOD_ERR_INVALID, "unknown tracking mode");
-    if (segment_steps < 0 || warmup_steps < 0) return fail(c, SCVOD_ERR_INVALID, "negative segment / warm-up length");
+    if (segment_steps < 0 || warmup_steps < -1) return fail(c, SCVOD_ERR_INVALID, "negative segment / warm-up length");
     c->chain_generic = (mode == SCVOD_TRACK_CHAIN_GENERIC);
     if (mode == SCVOD_TRACK_CHAIN_GENERIC) mode = SCVOD_TRACK_CHAIN;
     c->track_mode = mode;
-    if (segment_steps > 0) c->chain_seg = segment_steps;
-    if (segment_steps > 0 || warmup_steps > 0) c->chain_warm = warmup_steps;
+    c->chain_seg = segment_steps;                   // 0: chosen per job
+    if (warmup_steps >= 0) c->chain_warm = warmup_steps;  // -1: keep
     c->track_valid = false;
     return SCVOD_OK;
 }
@@ -1218,11 +1232,28 @@ int scvod_batch_track_stats(scvod_ctx* c, int32_t* h_out8) {
     h_out8[2] = st[2];
     h_out8[3] = st[1];
     h_out8[4] = st[0];
-    h_out8[5] = c->chain_seg;
+    h_out8[5] = c->chain_seg_used;
     h_out8[6] = c->chain_warm;
     h_out8[7] = 0;
 #ifdef SCVOD_PROFILE
     fprintf(stderr, "[chain phases, 10 ns ticks summed over walkers x steps] fetch %d  carried %d  eval %d  walk+state %d  copy %d\n", st[3], st[4], st[5], st[6], st[7]);
+    if (c->chain_ran) {
+        const int nw = (int)(c->up_chain_walkers.size() / 8);
+        std::vector<int32_t> hd(16);
+        long long sum = 0;
+        int mn = 0x7fffffff, mx = 0;
+        std::vector<int> all;
+        for (int w = 0; w < nw; ++w) {
+            hipMemcpy(hd.data(), (unsigned char*)c->chain_ws + (size_t)w * c->chain_geom.stride + c->chain_geom.off_hdr, 64, hipMemcpyDeviceToHost);
+            sum += hd[15];
+            mn = hd[15] < mn ? hd[15] : mn;
+            mx = hd[15] > mx ? hd[15] : mx;
+            all.push_back(hd[15]);
+        }
+        std::sort(all.begin(), all.end());
+        fprintf(stderr, "[chain walkers] %d: wall min %.1f us  median %.1f  p90 %.1f  max %.1f  mean %.1f\n", nw, mn * 0.01, all[nw / 2] * 0.01, all[nw * 9 / 10] * 0.01,
+                mx * 0.01, sum * 0.01 / nw);
+    }
 #endif
     return rc;
 }

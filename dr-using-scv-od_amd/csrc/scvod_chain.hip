@@ -1202,8 +1202,14 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain(DevParams P, Arena A, T
     if (threadIdx.x == 0) K.hdr[H_HAS_SNAP] = 0;
     __syncthreads();
     fresh_state(A, K, 0, C.chain_scans[W.first + W.t0], C.ws.cap_ent, C.stats);
+#ifdef SCVOD_PROFILE
+    const long long wt0 = wall_clock64();
+#endif
     const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.t0, W.b, W.a, W.t0 < W.a ? W.a : -1, from_apri);
     if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
+#ifdef SCVOD_PROFILE
+    if (threadIdx.x == 0) K.hdr[15] = (int)(wall_clock64() - wt0);
+#endif
 }
 
 // verification, part 1: one workgroup per segment compares the state its predecessor ended in with its warm-up's snapshot

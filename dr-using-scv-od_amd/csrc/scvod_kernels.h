@@ -17,7 +17,8 @@ constexpr int kVgLutBins = 16384;
 // marks per INPUT point for the static map, which streams the input in order: whether Patchwork kept a point at all follows
 // from its patch id (pid) and that patch's population; k_tk_dyn marks the members of dynamic clusters; the two list marks are
 // only written when a caller asks for a map without the ground or without the range/FOV rejects
-constexpr uint8_t kMapDynamic = 1, kMapGround = 2, kMapRejected = 4;
+constexpr uint8_t kMapDynamic = 1, kMapGround = 2, kMapRejected = 4, kMapCar = 8;  // (kMapCar: member of a `car` cluster, set by the clustering:
+                                                                                    //  the only points a tracking result can take out of the map)
 
 struct Xyz {
     float x, y, z;

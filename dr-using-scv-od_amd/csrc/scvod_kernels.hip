@@ -3158,7 +3158,10 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             const uint32_t t = r[0];
             const int i = i0 + u * kCcThreads + tid;
             A.pt_type[(size_t)base + i] = (uint8_t)t;
-            if (t == 2u) A.tk_members[(size_t)base + r[2] + atomicAdd(&r[3], 1u)] = i;
+            if (t == 2u) {
+                A.tk_members[(size_t)base + r[2] + atomicAdd(&r[3], 1u)] = i;
+                if (!from_apri) A.pt_mapcls[(size_t)base + A.apri_src[(size_t)base + i]] = kMapCar;  // (the batch starts with clean marks)
+            }
         }
     }
     CC_MARK(9);

@@ -142,7 +142,7 @@ __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mas
 // head of a run probes the table in HBM.
 __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
                                                         float inv_leaf, int with_ground, int with_rejected, int have_dyn, int have_pid,
-                                                        int min_pts, int marks, unsigned long long* counters) {
+                                                        int min_pts, int marks, int part, unsigned long long* counters) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.scan_off[s + 1] - base;
@@ -179,6 +179,9 @@ __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __
                 if (keep && marks) {
                     const uint8_t c = cls[u];
                     keep = !((c & kMapDynamic) && have_dyn) && !((c & kMapGround) && !with_ground) && !((c & kMapRejected) && !with_rejected);
+                    // part 1: everything no tracking result can remove (not a car-cluster member); part 2: the car-cluster members
+                    if (part == 1) keep = keep && !(c & kMapCar);
+                    if (part == 2) keep = keep && (c & kMapCar);
                 }
                 if (keep) {
                     const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(256) void k_map_scatter_parts(const MapRec* __restr
 
 // the one place the map code needs the batch context: its arena, parameters and validity flags
 struct scvod_ctx;
+extern "C" int scvod__ctx_types_valid(scvod_ctx* c);
 extern "C" int scvod__ctx_view(scvod_ctx* ctx, Arena* arena, int* device, int* track_valid, int* batch_valid, int* n_scans,
                                int* max_scan_pts, int* batch_mode, int* num_min_pts);
 
@@ -395,7 +399,10 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
     int device = 0, track_valid = 0, batch_valid = 0, n_scans = 0, max_pts = 0, mode = 0, min_pts = 0;
     scvod__ctx_view(ctx, &A, &device, &track_valid, &batch_valid, &n_scans, &max_pts, &mode, &min_pts);
     if (!batch_valid || !A.pts) return mfail(m, SCVOD_ERR_STATE, "scvod_batch_map_accumulate needs a processed batch of input clouds");
-    const int use_dyn = !(flags & SCVOD_MAP_IGNORE_DYNAMIC);
+    const int part = (flags & SCVOD_MAP_PART_UNTRACKED) ? 1 : ((flags & SCVOD_MAP_PART_TRACKED) ? 2 : 0);
+    if ((flags & SCVOD_MAP_PART_UNTRACKED) && (flags & SCVOD_MAP_PART_TRACKED)) return mfail(m, SCVOD_ERR_INVALID, "the two part flags exclude each other");
+    if (part && !scvod__ctx_types_valid(ctx)) return mfail(m, SCVOD_ERR_STATE, "a map part needs scvod_batch_cluster and scvod_batch_cluster_types of the batch");
+    const int use_dyn = !(flags & SCVOD_MAP_IGNORE_DYNAMIC) && part != 1;  // (part 1 holds no point a tracking result concerns)
     if (use_dyn && !track_valid) return mfail(m, SCVOD_ERR_STATE, "no tracking result: run scvod_batch_track or pass SCVOD_MAP_IGNORE_DYNAMIC");
     if (device != m->device) return mfail(m, SCVOD_ERR_INVALID, "map and ctx live on different devices");
     MHIP(m, hipSetDevice(m->device));
@@ -419,12 +426,11 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
     if (max_pts > 0) {
         const int need_lists = (flags & (SCVOD_MAP_NO_GROUND | SCVOD_MAP_NO_REJECTED)) ? 1 : 0;
         if (need_lists) {  // rare: a map without the ground / without the range-FOV rejects needs those two lists marked
-            if (!track_valid) MHIP(m, hipMemsetAsync(A.pt_mapcls, 0, (size_t)A.total_pts, st));  // (tracking clears the marks itself)
             hipLaunchKernelGGL(k_map_mark_lists, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A);
         }
         hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
-                           (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, mode == 1 ? 1 : 0, min_pts, (use_dyn || need_lists) ? 1 : 0, m->counters);
+                           (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, mode == 1 ? 1 : 0, min_pts, (use_dyn || need_lists || part) ? 1 : 0, part, m->counters);
         MHIP(m, hipGetLastError());
     }
     return SCVOD_OK;

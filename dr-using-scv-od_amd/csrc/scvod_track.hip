@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void k_tk_dyn(Arena A, int from_apri) {
         else if (t == 2 && A.cl_state[(size_t)base + A.pt_cluster[(size_t)base + i]] == 1)
             d = SCVOD_DYN_DYNAMIC;
         A.pt_dyn[(size_t)base + i] = d;
-        if (!from_apri && d == SCVOD_DYN_DYNAMIC) A.pt_mapcls[(size_t)base + A.apri_src[(size_t)base + i]] = kMapDynamic;  // (cleared per call)
+        // the static map's mark of a car point: plain store, so that a second tracking run over the same clustering starts clean
+        if (!from_apri && t == 2) A.pt_mapcls[(size_t)base + A.apri_src[(size_t)base + i]] = (uint8_t)(kMapCar | (d == SCVOD_DYN_DYNAMIC ? kMapDynamic : 0));
     }
 }
 
@@ -380,7 +381,6 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     // every frame that has a successor in the batch become those of SSC::segDF's loop
     if (chain) launch_track_chain(P, A, J, *chain, from_apri, st, th, tu);
     TH_BEGIN("tk_dyn");
-    if (!from_apri) hipMemsetAsync(A.pt_mapcls, 0, (size_t)A.total_pts, st);
     hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A, from_apri);
     TH_END("tk_dyn");
 }

@@ -383,8 +383,9 @@ class Ctx:
                     n_unique=arr(r.n_unique, ncl, np.int32), pair_begin=pb, pair_label=arr(r.pair_label, npair, np.int32),
                     pair_count=arr(r.pair_count, npair, np.int32), pt_dyn=arr(r.pt_dyn, r.n_apri, np.uint8))
 
-    def set_track_mode(self, chain=True, segment_steps=0, warmup_steps=0, generic_step=False):
-        """chain=True: the reference's sequential tracking chain (default); False: first-order decisions.  0 keeps a length."""
+    def set_track_mode(self, chain=True, segment_steps=0, warmup_steps=-1, generic_step=False):
+        """chain=True: the reference's sequential tracking chain (default); False: first-order decisions.
+        segment_steps 0: chosen per job; warmup_steps -1: keep the current value."""
         self._chk(self.lib.scvod_set_track_mode(self.h, (3 if generic_step else 1) if chain else 0, int(segment_steps), int(warmup_steps)))
 
     def batch_track_stats(self):

@@ -281,8 +281,9 @@ int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_sc
  *                            the original ones, in creation order).  On the device the chain of each sequence is cut into
  *                            segments of `segment_steps` steps walked concurrently, each warmed up `warmup_steps` steps
  *                            earlier; a segment whose warm-up did not reproduce the state its predecessor really ended
- *                            in is walked again from that state, so the result never depends on the two lengths (0 keeps
- *                            the current values; defaults 24 / 16).  A scan tracked against an EXTERNAL table ends its
+ *                            in is walked again from that state, so the result never depends on the two lengths
+ *                            (segment_steps 0 = chosen per job so that it has about 250 segments, the default;
+ *                            warmup_steps -1 = keep, default 12).  A scan tracked against an EXTERNAL table ends its
  *                            chain: across shard boundaries the decision is first-order -- keep a sequence on one shard.
  *   SCVOD_TRACK_FIRST_ORDER  every cluster against its successor's fresh segmentation (all pairs independent).
  * n_unique / pair_* of scvod_track_result always describe a cluster's OWN points against the fresh successor. */
@@ -400,6 +401,11 @@ typedef struct scvod_map scvod_map;
 #define SCVOD_MAP_NO_GROUND 1       /* leave cloud_out (ground) out                                  */
 #define SCVOD_MAP_NO_REJECTED 2     /* leave cloud_eva_static (range/FOV rejects) out                 */
 #define SCVOD_MAP_IGNORE_DYNAMIC 4  /* raw map: keep the points scvod_batch_track marked dynamic too  */
+/* The map in two parts, so that most of it is accumulated WHILE the batch is tracked (a second stream): tracking can only
+ * remove members of `car` clusters (src/ssc.cpp:1262), everything else is final once scvod_batch_cluster_types ran.
+ * The cell rule is order-independent, so part UNTRACKED + part TRACKED == one call without a part flag, bit for bit. */
+#define SCVOD_MAP_PART_UNTRACKED 8  /* every kept point that is not a member of a car cluster (needs no tracking result) */
+#define SCVOD_MAP_PART_TRACKED 16   /* the car-cluster members scvod_batch_track left static                            */
 int scvod_map_create(int device, int64_t capacity_cells, float leaf, scvod_map** out);
 void scvod_map_destroy(scvod_map* map);
 const char* scvod_map_last_error(const scvod_map* map);

@@ -183,3 +183,48 @@ def test_map_needs_a_tracked_batch(scvod):
     assert m.count() == 0  # 100 points at the origin: r <= 2.7 m, dropped by Patchwork, in neither cloud
     m.close()
     ctx.close()
+
+
+def test_map_in_two_parts_equals_the_map_in_one(scvod):
+    """SCVOD_MAP_PART_UNTRACKED (everything but the members of car clusters: final once the box rules ran, accumulated on a
+    second stream while the batch is tracked) + SCVOD_MAP_PART_TRACKED (the car points tracking left static) must give the
+    records of one unflagged call, bit for bit; the untracked part must not need a tracking result."""
+    import torch
+    P = scvod.make_params("semantickitti")
+    count = 6
+    import synth
+    pts, offs, poses, _ = synth.make_batch(5, 2100, count, "K64")
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    d = pts.cuda()
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    two = scvod.StaticMap(1 << 21)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    two.accumulate(ctx, poses, flags=8, stream=side.cuda_stream)  # before any tracking call
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    torch.cuda.current_stream().wait_stream(side)
+    n1 = two.count()
+    two.accumulate(ctx, poses, flags=16)
+    one = scvod.StaticMap(1 << 21)
+    one.accumulate(ctx, poses)
+    k1, v1 = _sorted_records(one)
+    k2, v2 = _sorted_records(two)
+    assert 0 < n1 < len(k1)
+    assert np.array_equal(k1, k2) and np.array_equal(v1, v2)
+    n_dyn = sum(ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(count))
+    assert n_dyn > 0
+    raw = scvod.StaticMap(1 << 21)
+    raw.accumulate(ctx, poses, flags=4)
+    assert raw.count() > len(k1)  # the dynamic points opened cells of their own
+    import ctypes as C
+    bad = scvod.StaticMap(1 << 16)
+    p = np.ascontiguousarray(poses, np.float32)
+    assert bad.lib.scvod_batch_map_accumulate(ctx.h, bad.h, p.ctypes.data_as(C.c_void_p), 8 | 16, None) == -1
+    for m in (one, two, raw, bad):
+        m.close()
+    ctx.close()

@@ -2,7 +2,7 @@ import sys, os
 sys.path.insert(0,'dr-using-scv-od_amd/pyshim')
 import numpy as np, torch, scvod_py, synth
 P=scvod_py.make_params("semantickitti")
-n=600; skip=5
+n=int(sys.argv[1]) if len(sys.argv)>1 else 600; skip=5
 parts=[];offs=[0];poses=[]
 for i in range(n):
     p,l,pose=synth.make_scan(5,i,"K64",device="cuda"); parts.append(p); offs.append(offs[-1]+p.shape[0]); poses.append(pose)
@@ -12,7 +12,7 @@ nxt=np.array([s+skip if s+skip<n else -1 for s in range(n)],np.int32)
 T=np.zeros((n,12),np.float32)
 for s in range(n-skip): T[s]=ctx.pose_delta(poses[s],poses[s+skip])
 ctx.batch_process(pts,offs); ctx.batch_cluster(); ctx.batch_cluster_types()
-for seg,warm in ((24,16),(12,16)):
+for seg,warm in ((24,16),(11,12)):
     ctx.set_track_mode(True,seg,warm)
     ctx.batch_track(T,next_scan=nxt)
     ctx.set_timing(True)
