@@ -89,9 +89,6 @@ def main():
     ap.add_argument("--track-mode", default="chain", choices=["chain", "first-order"], help="chain: the reference's sequential tracking chain (default); first-order: every pair independent")
     ap.add_argument("--chain-seg", type=int, default=0, help="steps per chain segment (0: library default)")
     ap.add_argument("--chain-warm", type=int, default=-1, help="warm-up steps in front of a segment (-1: library default)")
-    ap.add_argument("--track-mode", default="chain", choices=["chain", "first-order"], help="chain: the reference's sequential tracking chain (default); first-order: every pair independent")
-    ap.add_argument("--chain-seg", type=int, default=0, help="steps per chain segment (0: library default)")
-    ap.add_argument("--chain-warm", type=int, default=-1, help="warm-up steps in front of a segment (-1: library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (use --backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--dump-map", default="", help="rank 0 writes the merged static map (records sorted by cell key) and the per-scan dynamic counts to this .npz")
@@ -152,9 +149,6 @@ def main():
     max_scan = int(np.diff(offs).max())
 
     ctx = scvod_py.Ctx(P, max_points_total=total_pts + 1024, max_scans=n_sc, device=local)
-    if args.track_mode != "chain" or args.chain_seg > 0 or args.chain_warm >= 0:
-        ctx.set_track_mode(chain=args.track_mode == "chain", segment_steps=max(args.chain_seg, 0) or (24 if args.chain_warm >= 0 else 0),
-                           warmup_steps=max(args.chain_warm, 0))
     if args.track_mode != "chain" or args.chain_seg > 0 or args.chain_warm >= 0:
         ctx.set_track_mode(chain=args.track_mode == "chain", segment_steps=max(args.chain_seg, 0), warmup_steps=max(args.chain_warm, -1))
     stream = torch.cuda.current_stream().cuda_stream  # torch.distributed orders its work against this stream
