@@ -3,20 +3,21 @@
 
 Workload at one GPU (BASELINE.json configs[1]): a SemanticKITTI-seq-05-shaped sequence -- 2761 scans of a 64-beam sensor,
 ~118 k returns per scan, config/semantickitti.yaml parameters -- synthetic (no dataset exists in this environment),
-resident in HBM before the timed region starts.  With N GPUs (configs[3]): the scans of seq 05, 00, 02, 08, ... in that
-order, N x 2761 of them, cut into 8 N blocks that are dealt round-robin over the ranks (weak scaling: 2761 scans per rank).
+resident in HBM before the timed region starts.  With N GPUs (configs[3]): N such sequences (seeded like seq 05, 00, 02,
+08, ...), one per rank -- weak scaling.  The unit of sharding is the SEQUENCE: the reference tracks frame i against frame
+i + 1 in order and every call mutates the successor (SSC::segDF, ssc.cpp:1449-1451), a chain the device replays exactly
+and that therefore stays on one rank (pyshim/shard.py).
 
 One "step" = one pass of the whole path over the rank's scans, raw points in, per-point dynamic/static labels and the
 static map out, everything on the device through the C-ABI (libscvod.so):
     Patchwork ground segmentation -> curved-voxel binning -> per-voxel descriptors        scvod_batch_process
     -> curved-voxel clustering -> bounding boxes + type rules                             scvod_batch_cluster(_types)
-    -> successor tables; boundary tables of the blocks' first scans to the left neighbour scvod_batch_track_tables,
-       (RCCL point-to-point; a local no-op at one GPU)                                    scvod_batch_export_table
-    -> scan-vs-next-scan differencing: probe, remap_name, state rule, per-point byte      scvod_batch_track
+    -> scan-vs-next-scan differencing: probe, remap_name, state rule, the reference's     scvod_batch_track
+       SEQUENTIAL re-labelling chain (scan i against scan i + skip_), per-point byte
     -> world-frame static map of the rank's scans                                         scvod_batch_map_accumulate
-    -> (N > 1) the map reduce-scattered over RCCL: records grouped by owner rank,         scvod_map_export_parts / _merge
-       one all-to-all, every rank merges the cells it owns
-value = scans of all ranks / max-over-ranks time.
+    -> (N > 1) the map reduce-scattered over RCCL: records grouped by owner rank in       scvod_map_export_parts_padded,
+       equal padded slots, ONE all_to_all_single, every rank merges the cells it owns     scvod_map_merge
+No host synchronisation inside a step, at any N.  value = scans of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline      HBM roofline: algorithmic bytes of the path over the measured step time; the dominant kernel
@@ -75,9 +76,9 @@ def main():
     ap.add_argument("--scans", type=int, default=2761, help="scans per rank (seq 05 has 2761)")
     ap.add_argument("--kind", default="K64")
     ap.add_argument("--preset", default="semantickitti")
-    ap.add_argument("--blocks-per-rank", type=int, default=8)
+    ap.add_argument("--sequences", type=int, default=0, help="sequences of the job, each --scans long (0: one per rank)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the N > 1 step (map reduce-scatter, device collectives) even at one rank")
     ap.add_argument("--skip", type=int, default=0, help="tracking stride: scan i is differenced against scan i + skip (0: the preset's config skip_, 5 in semantickitti.yaml, 1 in parkinglot.yaml)")
-    ap.add_argument("--table-cap", type=int, default=0, help="records per boundary message (0: from the scans)")
     ap.add_argument("--map-cells", type=int, default=0, help="capacity of the static map in cells (0: from the points)")
     ap.add_argument("--map-leaf", type=float, default=0.2)
     ap.add_argument("--cpu-scans", type=int, default=64, help="bounded sample for the CPU baseline and the PR/RR check")
@@ -112,13 +113,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    multi = dist is not None  # the N > 1 step (also at one rank with --force-dist: RCCL initialised, device collectives executed)
     import scvod_py
     import shard
     import synth
@@ -126,8 +129,8 @@ def main():
     P = scvod_py.make_params(args.preset)
     if args.skip <= 0:
         args.skip = 1 if args.preset == "parkinglot" else 5
-    bpr = max(1, min(args.blocks_per_rank, args.scans // max(args.skip, 1)))  # a block holds at least one tracking stride
-    plan = shard.plan_job(world, args.scans, synth.SEQ_LEN, blocks_per_rank=bpr, skip=args.skip)[rank]
+    job = shard.weak_scaling_sequences(args.sequences or world, args.scans)
+    plan = shard.plan_job(world, job, skip=args.skip)[rank]
     n_sc = len(plan["scans"])
 
     # ---- the rank's scans, resident in HBM ----
@@ -157,20 +160,14 @@ def main():
     for s in range(n_sc):
         if nxt[s] >= 0:
             T[s] = ctx.pose_delta(poses[s], poses[nxt[s]])
-        elif nxt[s] <= -2:  # the successor lives on the right neighbour: its pose is a function of (seq, idx) like everything else
-            q, i = plan["scans"][s]
-            T[s] = ctx.pose_delta(poses[s], np.asarray(synth.pose_of(i + args.skip), np.float32))
-    table_cap = args.table_cap or (1 << max(12, int(np.ceil(np.log2(max_scan * 0.6 + 2)))))
-    send_buf = torch.zeros((len(plan["send_scans"]), table_cap, 4), dtype=torch.int32, device=dev)
-    recv_buf = torch.zeros((plan["n_recv"], table_cap, 4), dtype=torch.int32, device=dev)
-    ext = [recv_buf[e] for e in range(plan["n_recv"])]
     smap = None
     pmap = None
+    part_send = part_recv = None
     if not args.no_map:
         cells = args.map_cells or (1 << int(np.ceil(np.log2(max(total_pts * 0.25, 1 << 22)))))  # load <= ~0.5 on the street scenes
         smap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local)
         # N > 1: the map is reduce-scattered -- every rank ends up owning the cells whose key hashes to it, merged from all ranks
-        pmap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local) if world > 1 else None
+        pmap = scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local) if multi else None
     kt = {}
     info = {}
 
@@ -190,12 +187,7 @@ def main():
         after()
         ctx.batch_cluster_types(stream=stream, sync=False)
         after()
-        ctx.batch_track_tables(stream=stream)
-        after()
-        for m, s in enumerate(plan["send_scans"]):
-            ctx.batch_export_table(s, send_buf[m], stream=stream)
-        shard.exchange_tables(dist, send_buf, recv_buf)
-        ctx.batch_track(T, next_scan=nxt, ext_tables=ext, stream=stream, sync=False)
+        ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         after()
         if smap is not None:
             if timed:
@@ -209,12 +201,10 @@ def main():
                 a = kt.setdefault("map_accumulate", [0.0, 0])
                 a[0] += e0.elapsed_time(e1)
                 a[1] += 1
-            if world > 1:
-                rec, counts = smap.export_parts(world, stream=stream)
+            if multi:  # reduce-scatter of the map: equal padded slots, one all-to-all, no size on the host
+                smap.export_parts_padded(world, part_send, stream=stream)
                 pmap.clear(stream=stream)
-                for part in shard.reduce_scatter_map(dist, rec, counts):
-                    pmap.merge(part, stream=stream)
-                info["map_records_sent"] = int(rec.shape[0]) - counts[rank]
+                pmap.merge(shard.reduce_scatter_map(dist, part_send, part_recv), stream=stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -222,6 +212,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if multi and smap is not None:
+        # slot size of the all-to-all: from one untimed pass (the only host read of a size, outside every timed step)
+        ctx.batch_process(pts, offs, stream=stream, sync=False)
+        ctx.batch_cluster(stream=stream, sync=False)
+        ctx.batch_cluster_types(stream=stream, sync=False)
+        ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
+        smap.clear(stream=stream)
+        smap.accumulate(ctx, poses, stream=stream)
+        _, counts0 = smap.export_parts(world, stream=stream)
+        t_cap = torch.tensor([max(counts0)], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(t_cap, op=dist.ReduceOp.MAX)
+        part_cap = int(int(t_cap.item()) * 1.1) + 1024
+        part_send = torch.empty((world, part_cap, 2), dtype=torch.int64, device=dev)
+        part_recv = torch.empty_like(part_send)
+        info["map_slot_records"] = part_cap
+        info["map_records_sent"] = int(sum(counts0)) - int(counts0[rank])
     for _ in range(args.warmup):
         step()
     # timed region (the number reported): no per-kernel events, asynchronous launches
@@ -240,6 +246,7 @@ def main():
     barrier()
     ctx.set_timing(False)
 
+    chain_stats = ctx.batch_track_stats()  # (raises if a chain state overflowed its workspace)
     cnt = ctx.batch_counts()
     tot_vox = int(cnt[:, 6].sum())
     tot_apri = int(cnt[:, 4].sum())
@@ -248,14 +255,14 @@ def main():
     dyn_frac = sum(t["n_dynamic_points"] for t in tk) / max(1, sum(t["n_apri"] for t in tk))
     tot_car = car_frac * tot_apri
     map_cells = smap.count() if smap is not None else None
-    if smap is not None and world > 1:  # cells of the merged map = sum of the parts the ranks own
+    if smap is not None and multi:  # cells of the merged map = sum of the parts the ranks own
         t_cells = torch.tensor([pmap.count()], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t_cells)
         map_cells = int(t_cells.item())
     if args.dump_map:
         dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(n_sc)], np.int64)
         gathered = [None] * world
-        mine = (pmap if world > 1 else smap).export().cpu().numpy().view(np.uint64)
+        mine = (pmap if multi else smap).export().cpu().numpy().view(np.uint64)
         if dist is not None:
             dist.all_gather_object(gathered, (rank, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist(), mine))
         else:
@@ -379,16 +386,18 @@ def main():
                "value": scans_per_s, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 else
-                                       f"seq 05,00,02,08,...-shaped {args.kind} scans, {int(all_scans)} in total, {bpr * world} blocks round-robin over {world} ranks, {args.preset}.yaml grid"),
+               "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 and len(job) == 1 else
+                                       f"{len(job)} sequences of {args.scans} {args.kind} scans (seeded like seq 05, 00, 02, 08, ...), {int(all_scans)} scans in total, whole sequences per rank, {args.preset}.yaml grid"),
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
-                          "static_map_cells": map_cells, "boundary_tables_per_step": len(plan["send_scans"]),
-                          "rccl_ranks": world, "tracking_stride": args.skip, "sharding": f"{bpr} blocks per rank, block k on rank k % {world}"},
+                          "static_map_cells": map_cells, "tracking": args.track_mode, "tracking_chain": chain_stats,
+                          "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
+                          "tracking_stride": args.skip, "sharding": "whole sequences per rank (longest first to the least loaded rank)"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
-        if world > 1:
-            out["config"]["map_records_gathered_per_rank"] = info.get("map_records_sent")
+        if multi:
+            out["config"]["map_records_sent_per_rank"] = info.get("map_records_sent")
+            out["config"]["map_slot_records"] = info.get("map_slot_records")
         print(json.dumps(out))
     if smap is not None:
         smap.close()

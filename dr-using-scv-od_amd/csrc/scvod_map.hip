@@ -319,6 +319,42 @@ __global__ __launch_bounds__(256) void k_map_scatter_parts(const MapRec* __restr
     }
 }
 
+// the same grouping into FIXED-SIZE slots: group p owns out[p * cap_part, (p + 1) * cap_part); the caller pre-fills the buffer
+// with padding (key ~0).  Cursors start at 0; a group that outgrows its slot is counted in counters[1] (reported at the next
+// synchronising call).  No size has to be known on the host: the all-to-all of a sharded map moves equal-sized slots.
+__global__ __launch_bounds__(256) void k_map_scatter_parts_padded(const MapRec* __restrict__ table, long long capacity, int n_parts,
+                                                                  unsigned long long* part_cursor, MapRec* out, long long cap_part,
+                                                                  unsigned long long* counters) {
+    __shared__ int hist[kMapMaxParts];
+    __shared__ unsigned long long start[kMapMaxParts];
+    int dropped = 0;
+    for (long long t0 = blockIdx.x * 256ll; t0 < capacity; t0 += (long long)gridDim.x * 256) {
+        if (threadIdx.x < kMapMaxParts) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const long long t = t0 + threadIdx.x;
+        MapRec r;
+        r.key = kEmpty;
+        if (t < capacity) r = table[t];
+        int part = -1, rank = 0;
+        if (r.key != kEmpty) {
+            part = map_part(r.key, n_parts);
+            rank = atomicAdd(&hist[part], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < n_parts && hist[threadIdx.x]) start[threadIdx.x] = atomicAdd(&part_cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+        __syncthreads();
+        if (part >= 0) {
+            const long long o = (long long)start[part] + rank;
+            if (o < cap_part)
+                out[(long long)part * cap_part + o] = r;
+            else
+                ++dropped;
+        }
+        __syncthreads();
+    }
+    if (dropped) atomicAdd(&counters[1], (unsigned long long)dropped);
+}
+
 }  // namespace
 }  // namespace scvod
 
@@ -485,6 +521,20 @@ int scvod_map_export_parts(scvod_map* m, int32_t n_parts, void* d_records, int64
                        (long long)cap_records);
     MHIP(m, hipGetLastError());
     MHIP(m, hipStreamSynchronize(st));  // `cur` lives on this stack frame
+    return SCVOD_OK;
+}
+
+int scvod_map_export_parts_padded(scvod_map* m, int32_t n_parts, void* d_records, int64_t cap_per_part, void* d_counts, void* stream) {
+    if (!m || n_parts < 1 || n_parts > kMapMaxParts || !d_records || cap_per_part < 1) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
+    MHIP(m, hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* pc = m->counters + 2;
+    MHIP(m, hipMemsetAsync(pc, 0, 8 * kMapMaxParts, st));
+    MHIP(m, hipMemsetAsync(d_records, 0xff, (size_t)16 * (size_t)n_parts * (size_t)cap_per_part, st));  // padding: key ~0
+    hipLaunchKernelGGL(k_map_scatter_parts_padded, dim3(256 * 8), dim3(256), 0, st, m->table, m->capacity, (int)n_parts, pc, (MapRec*)d_records,
+                       (long long)cap_per_part, m->counters);
+    MHIP(m, hipGetLastError());
+    if (d_counts) MHIP(m, hipMemcpyAsync(d_counts, pc, 8 * (size_t)n_parts, hipMemcpyDeviceToDevice, st));
     return SCVOD_OK;
 }
 

@@ -137,6 +137,7 @@ def load_lib():
         "scvod_map_export": (C.c_int, [vp, vp, i64, C.POINTER(i64), vp]),
         "scvod_map_merge": (C.c_int, [vp, vp, i64, vp]),
         "scvod_map_export_parts": (C.c_int, [vp, i32, vp, i64, vp, vp]),
+        "scvod_map_export_parts_padded": (C.c_int, [vp, i32, vp, i64, vp, vp]),
         "scvod_map_points": (C.c_int, [vp, vp, vp, i64, C.POINTER(i64), vp]),
         "scvod_batch_timings": (C.c_int, [vp, vp, vp, i32]),
         "scvod_set_timing": (C.c_int, [vp, i32]),
@@ -161,7 +162,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
                     "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
-                    "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_merge", "scvod_map_points",
+                    "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
 
 
@@ -532,8 +533,15 @@ class StaticMap:
         counts = [int(v) for v in cnt]
         return rec[:sum(counts)], counts
 
+    def export_parts_padded(self, n_parts, d_records, d_counts=None, stream=None):
+        """d_records: torch int64 device tensor [n_parts, cap, 2], filled group by group, padded with key -1; d_counts: int64
+        device tensor [n_parts] or None.  No host synchronisation (the timed multi-GPU step)."""
+        assert d_records.dim() == 3 and d_records.shape[0] == n_parts and d_records.shape[2] == 2 and d_records.is_contiguous()
+        self._chk(self.lib.scvod_map_export_parts_padded(self.h, int(n_parts), C.c_void_p(d_records.data_ptr()), int(d_records.shape[1]),
+                                                         C.c_void_p(d_counts.data_ptr()) if d_counts is not None else None, C.c_void_p(stream or 0)))
+
     def merge(self, d_records, stream=None):
-        self._chk(self.lib.scvod_map_merge(self.h, C.c_void_p(d_records.data_ptr()), int(d_records.shape[0]), C.c_void_p(stream or 0)))
+        self._chk(self.lib.scvod_map_merge(self.h, C.c_void_p(d_records.data_ptr()), int(d_records.numel() // 2), C.c_void_p(stream or 0)))
 
     def points(self, stream=None):
         """(xyzi float32 [n, 4], records int64 [n, 2]) device tensors, same (unspecified) order"""

@@ -424,6 +424,12 @@ int scvod_map_export(scvod_map* map, void* d_records, int64_t cap_records, int64
  * map instead of everything converging on one root) and merges what it receives into the map of its own part.
  * Synchronises `stream`. */
 int scvod_map_export_parts(scvod_map* map, int32_t n_parts, void* d_records, int64_t cap_records, int64_t* h_counts, void* stream);
+/* The same grouping into FIXED-SIZE slots, without any host synchronisation (the form a timed multi-GPU step uses): group p
+ * is written to d_records[p * cap_per_part .. (p + 1) * cap_per_part), the rest of a slot is padding (key ~0, skipped by
+ * scvod_map_merge); d_counts (device, n_parts x int64, optional) receives the group sizes.  The all-to-all then moves
+ * n_parts equal slots (all_to_all_single on device tensors).  A group that does not fit its slot is counted and reported
+ * by the next scvod_map_export* call as SCVOD_ERR_CAPACITY.  Asynchronous on `stream`. */
+int scvod_map_export_parts_padded(scvod_map* map, int32_t n_parts, void* d_records, int64_t cap_per_part, void* d_counts, void* stream);
 /* inserts records exported by another shard (a record with key ~0 is padding and skipped).  Asynchronous. */
 int scvod_map_merge(scvod_map* map, const void* d_records, int64_t n, void* stream);
 /* the map as points: d_xyzi [cap][4] floats (cell origin + stored offset, intensity), optionally the records beside them */

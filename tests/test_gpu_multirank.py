@@ -1,6 +1,10 @@
-"""The N > 1 job of bench.py on ONE device: two ranks (gloo, device buffers staged through the host) shard 48 scans of a
-sequence in round-robin blocks, exchange the boundary tables, track, accumulate their static maps and reduce them on
-rank 0 -- per-scan dynamic counts and the merged map must equal the single-rank run bit for bit."""
+"""The N > 1 job of bench.py on ONE device.
+(1) two ranks (gloo, device buffers staged through the host) share a job of two sequences -- whole sequences per rank, the
+    sequential tracking chain inside each, the static maps reduce-scattered as padded slots: per-scan dynamic counts and
+    the merged map must equal the single-rank run of the same job bit for bit;
+(2) the RCCL leg the driver will run at 8 ranks, executed at ONE rank: torch.distributed initialised with backend nccl,
+    the step's device collectives (all_to_all_single of the padded map slots, all_reduce of the summary) really run."""
+import json
 import os
 import subprocess
 import sys
@@ -12,27 +16,37 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp, name, extra):
+def _run(tmp, name, extra, backend="gloo"):
     out = os.path.join(tmp, name + ".npz")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extras", "--backend", "gloo",
-           "--same-device", "--kind", "PARK", "--preset", "parkinglot", "--dump-map", out] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extras", "--backend", backend,
+           "--kind", "PARK", "--preset", "parkinglot", "--dump-map", out] + extra
     env = dict(os.environ)
-    env.pop("WORLD_SIZE", None)
-    env.pop("RANK", None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    import json
     return json.loads(line), np.load(out)
 
 
 def test_two_ranks_reproduce_the_single_rank_job(tmp_path):
-    one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "48", "--blocks-per-rank", "4"])
-    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "24", "--blocks-per-rank", "2"])
+    one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "24", "--sequences", "2"])
+    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "24", "--same-device"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2
-    assert two["config"]["boundary_tables_per_step"] >= 1
-    assert np.array_equal(m1["scans"], m2["scans"])
+    assert one["config"]["tracking_chain"]["chain"] and two["config"]["tracking_chain"]["chain"]
+    assert np.array_equal(m1["scans"], m2["scans"]) and len(m1["scans"]) == 48
     assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
     assert m1["dynamic_points"].sum() > 0
     assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])
     assert len(m1["keys"]) == one["config"]["static_map_cells"] == two["config"]["static_map_cells"]
+    assert two["config"]["map_records_sent_per_rank"] > 0
+
+
+def test_rccl_leg_at_one_rank(tmp_path):
+    plain, m0 = _run(str(tmp_path), "plain", ["--gpus", "1", "--scans", "20"])
+    rccl, m1 = _run(str(tmp_path), "rccl", ["--gpus", "1", "--scans", "20", "--force-dist"], backend="nccl")
+    assert rccl["config"]["backend"] == "nccl" and rccl["config"]["rccl_ranks"] == 1
+    assert rccl["config"]["map_slot_records"] > 0                       # the padded all_to_all_single ran
+    assert np.array_equal(m0["dynamic_points"], m1["dynamic_points"])
+    assert np.array_equal(m0["keys"], m1["keys"]) and np.array_equal(m0["vals"], m1["vals"])
+    assert plain["config"]["static_map_cells"] == rccl["config"]["static_map_cells"]

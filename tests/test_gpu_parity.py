@@ -969,3 +969,30 @@ def test_metric_on_gpu_matches_reference_golden(scvod):
             assert m[k] == g[k]
         assert abs(m["PR"] - g["PR"]) < 1e-9 and abs(m["RR"] - g["RR"]) < 1e-9
     ctx.close()
+
+
+def test_reference_segmentation_of_scan_509_through_the_hip_path(scvod, oracle):
+    """GPU twin of test_cvc_partition_refines_the_reference_segmentation_of_scan_509: the reference's own segmented cloud
+    (doc/fig2/509_seg.pcd) through scvod_bin_scan + scvod_cluster: PointAPRI records, voxel table and partition
+    bit-identical to the oracle's, and the partition refines the reference's 58 colours."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fig2_509_seg.npz"))
+    x = np.concatenate([d["xyz"], np.zeros((len(d["xyz"]), 1), np.float32)], 1)
+    P = scvod.make_params("semantickitti", max_dis=50.0)
+    ctx = scvod.Ctx(P, max_points_total=len(x) + 64, max_scans=1)
+    r = ctx.bin_scan(x, apply_filter=True, with_voxels=True)
+    b = oracle.bin(P, x, True)
+    assert r["n_apri"] == len(x) and np.array_equal(r["apri"].view(np.uint8), b["apri"].view(np.uint8))
+    v = oracle.voxelize(P, b["apri"])
+    assert np.array_equal(r["vox_key"], v["vox_key"]) and np.array_equal(r["vox_pts"], v["vox_pts"])
+    cl = ctx.cluster(r["apri"])
+    ocl, _, _ = oracle.cluster(P, b["apri"])
+    assert np.array_equal(_canonical(cl), _canonical(ocl))
+    col = d["rgb"][b["src"]]
+    order = np.lexsort((col, cl))
+    c, k = cl[order], col[order]
+    starts = np.flatnonzero(np.r_[True, c[1:] != c[:-1]])
+    ends = np.r_[starts[1:], len(c)]
+    bad = sum(int(e - a - np.unique(k[a:e], return_counts=True)[1].max()) for a, e in zip(starts, ends))
+    assert bad <= 100 and len(starts) >= 58
+    ctx.close()

@@ -1,7 +1,6 @@
-"""The sequence-sharded job of bench.py (pyshim/shard.py: plan_job, exchange_tables, gather_map_records) on CPU: the plan's
-invariants for 1 .. 8 ranks, and three gloo ranks running the two real exchange steps of the path -- boundary tables to the
-left neighbour, map records to the root -- with payloads that name their scan, so every message is checked to arrive where
-the single-process job would look it up.  Not gpu."""
+"""The job plan of bench.py (pyshim/shard.py::plan_job) on CPU: invariants for 1 .. 8 ranks (every scan once, sequences
+whole, successors inside the sequence, longest-first balance), and three gloo ranks running the one exchange step of the
+path -- the padded all-to-all of map records -- with payloads that name sender and owner.  Not gpu."""
 import os
 import sys
 
@@ -20,30 +19,29 @@ def test_plan_invariants():
     import shard
     for world in (1, 2, 3, 8):
         for skip in (1, 5):
-            spr = 24
-            plan = shard.plan_job(world, spr, SEQ_LEN, blocks_per_rank=3, skip=skip)
-            seen = [q for r in plan for q in r["scans"]]
-            glob = [(q, i) for q in shard.SEQ_ORDER for i in range(SEQ_LEN[q])][: world * spr]
-            assert sorted(seen) == sorted(glob) and len(set(seen)) == len(seen)         # every scan exactly once
-            assert max(len(r["scans"]) for r in plan) - min(len(r["scans"]) for r in plan) <= 3
-            for r, p in enumerate(plan):
-                assert len(p["send_scans"]) == plan[(r - 1) % world]["n_recv"]
-                ext = 0
-                for j, (q, i) in enumerate(p["scans"]):
-                    v = int(p["next_scan"][j])
-                    succ = (q, i + skip)
-                    if succ not in set(glob):
-                        assert v == -1                                                  # end of its sequence / of the job
-                    elif v >= 0:
-                        assert p["scans"][v] == succ                                    # local successor
-                    else:
-                        assert v == -2 - ext                                            # e-th table from the right neighbour
-                        right = plan[(r + 1) % world]
-                        assert right["scans"][right["send_scans"][ext]] == succ
-                        ext += 1
-                assert ext == p["n_recv"]
-            if world == 1:
-                assert all(p["n_recv"] == 0 and not p["send_scans"] for p in plan)
+            for job in (shard.kitti_sequences(SEQ_LEN), shard.weak_scaling_sequences(world, 24), shard.weak_scaling_sequences(13, 7)):
+                plan = shard.plan_job(world, job, skip=skip)
+                assert len(plan) == world
+                seen = [q for r in plan for q in r["scans"]]
+                glob = [(q, first + j) for (q, first, count) in job for j in range(count)]
+                assert sorted(seen) == sorted(glob) and len(set(seen)) == len(seen)         # every scan exactly once
+                assert sorted(s for r in plan for s in r["sequences"]) == sorted(job)      # sequences whole
+                for p in plan:
+                    pos = {sc: j for j, sc in enumerate(p["scans"])}
+                    lens = {q: count for (q, first, count) in p["sequences"]}
+                    firsts = {q: first for (q, first, count) in p["sequences"]}
+                    for j, (q, i) in enumerate(p["scans"]):
+                        v = int(p["next_scan"][j])
+                        if i + skip < firsts[q] + lens[q]:
+                            assert v >= 0 and p["scans"][v] == (q, i + skip)                   # successor: same sequence, local
+                        else:
+                            assert v == -1                                                  # the last `skip` scans of a sequence
+                    assert len(p["next_scan"]) == len(p["scans"])
+                loads = [len(p["scans"]) for p in plan]
+                longest = max(c for _, _, c in job)
+                assert max(loads) <= max(longest, -(-len(glob) // world) + longest)         # greedy longest-first bound
+    one = shard.plan_job(4, shard.weak_scaling_sequences(4, 100), skip=5)
+    assert [len(p["sequences"]) for p in one] == [1, 1, 1, 1] and one[0]["sequences"][0][0] == 5  # bench.py: one sequence per rank, seq 05 on rank 0
 
 
 def _worker(rank, world, port, q):
@@ -52,52 +50,34 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import shard
-    skip, cap = 2, 16
-    plan = shard.plan_job(world, 12, SEQ_LEN, blocks_per_rank=2, skip=skip)[rank]
-    # a "table" that names its scan: header {n, seq, idx, 0}, then n records
-    send = torch.zeros((len(plan["send_scans"]), cap, 4), dtype=torch.int32)
-    for m, s in enumerate(plan["send_scans"]):
-        qq, i = plan["scans"][s]
-        n = 3 + (i % 5)
-        send[m, 0] = torch.tensor([n, qq, i, 0])
-        send[m, 1:1 + n, 0] = torch.arange(n) + 1000 * i
-    recv = torch.full((plan["n_recv"], cap, 4), -7, dtype=torch.int32)
-    for _ in range(2):  # a second step reuses the buffers
-        shard.exchange_tables(dist, send, recv)
     ok = True
-    for j, (qq, i) in enumerate(plan["scans"]):
-        v = int(plan["next_scan"][j])
-        if v <= -2:
-            h = recv[-2 - v]
-            n = int(h[0, 0])
-            ok &= (int(h[0, 1]), int(h[0, 2])) == (qq, i + skip) and n == 3 + ((i + skip) % 5)
-            ok &= bool((h[1:1 + n, 0] == torch.arange(n) + 1000 * (i + skip)).all())
-    # map records: every rank contributes rank + 2 records tagged with its rank; the root sees all of them, padded with -1
-    rec = torch.stack([torch.arange(rank + 2, dtype=torch.int64) + 100 * rank, torch.full((rank + 2,), rank, dtype=torch.int64)], 1)
-    others = shard.gather_map_records(dist, rec, root=0)
-    got = None
-    if rank == 0:
-        allrec = torch.cat([rec] + others)
-        allrec = allrec[allrec[:, 0] != -1]
-        got = sorted(map(tuple, allrec.tolist()))
-    else:
-        ok &= others == []
-    # reduce-scatter of the map: rank r holds r + j + 1 records for owner j (tagged r, j); every owner ends up with its own
-    counts = [rank + j + 1 for j in range(world)]
-    rs = torch.cat([torch.stack([torch.full((c,), 1000 * rank + j, dtype=torch.int64), torch.arange(c, dtype=torch.int64)], 1) for j, c in enumerate(counts)])
-    parts = shard.reduce_scatter_map(dist, rs, counts)
-    own = torch.cat(parts)
+    # rank r holds r + j + 1 records for owner j, tagged (1000 r + j, k); slots padded with -1
+    cap = 2 * world + 2
+    send = torch.full((world, cap, 2), -1, dtype=torch.int64)
+    for j in range(world):
+        c = rank + j + 1
+        send[j, :c, 0] = 1000 * rank + j
+        send[j, :c, 1] = torch.arange(c)
+    for _ in range(2):  # a second step reuses the buffers
+        recv = shard.reduce_scatter_map(dist, send)
+    got = recv.reshape(-1, 2)
+    got = got[got[:, 0] != -1]
     want_own = sorted((1000 * r + rank, k) for r in range(world) for k in range(r + rank + 1))
-    ok &= sorted(map(tuple, own.tolist())) == want_own
+    ok &= sorted(map(tuple, got.tolist())) == want_own
+    for j in range(world):  # slot j = what rank j held for this rank
+        sl = recv[j][recv[j][:, 0] != -1]
+        ok &= bool((sl[:, 0] == 1000 * j + rank).all()) and len(sl) == j + rank + 1
+    dt, scans, pts = shard.aggregate(dist, torch.device("cpu"), 0.5 * (rank + 1), 10 + rank, 100 * (rank + 1))
+    ok &= dt == 0.5 * world and scans == sum(10 + r for r in range(world)) and pts == sum(100 * (r + 1) for r in range(world))
     res = [None] * world
-    dist.all_gather_object(res, (bool(ok), got, plan["n_recv"]))
+    dist.all_gather_object(res, bool(ok))
     if rank == 0:
         q.put(res)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_three_ranks_exchange_tables_and_reduce_the_map():
+def test_three_ranks_reduce_scatter_the_map():
     world = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -109,7 +89,11 @@ def test_three_ranks_exchange_tables_and_reduce_the_map():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(r[0] for r in res)
-    assert sum(r[2] for r in res) > 0                     # the plan really crosses ranks
-    want = sorted((k + 100 * r, r) for r in range(world) for k in range(r + 2))
-    assert res[0][1] == want
+    assert all(res)
+
+
+def test_single_process_passthrough():
+    import shard
+    x = torch.arange(12, dtype=torch.int64).reshape(1, 6, 2)
+    assert shard.reduce_scatter_map(None, x) is x
+    assert shard.aggregate(None, torch.device("cpu"), 1.5, 3, 7) == (1.5, 3.0, 7.0)

@@ -102,3 +102,49 @@ def test_fig2_through_the_hip_path(scvod, oracle):
         assert np.array_equal(r["planes"][f][live].view(np.uint32), o["planes"][f][live].view(np.uint32))
     assert float((r["cls"][:ng] == 0).mean()) >= 0.95
     ctx.close()
+
+
+# ---- beyond Patchwork: binning + voxelisation + curved-voxel clustering against the reference's own segmentation ----
+SEG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fig2_509_seg.npz")
+
+
+def _seg_cloud():
+    d = np.load(SEG)
+    xyz, rgb = d["xyz"], d["rgb"]
+    return np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], 1), rgb
+
+
+def _refinement(cl, col):
+    """points that do not carry the majority colour of their cluster, clusters, colours"""
+    order = np.lexsort((col, cl))
+    c, k = cl[order], col[order]
+    bad = 0
+    for a, b in zip(np.flatnonzero(np.r_[True, c[1:] != c[:-1]]), np.r_[np.flatnonzero(c[1:] != c[:-1]) + 1, len(c)]):
+        _, cnt = np.unique(k[a:b], return_counts=True)
+        bad += int(b - a - cnt.max())
+    return bad, len(np.unique(cl)), len(np.unique(col))
+
+
+def test_cvc_partition_refines_the_reference_segmentation_of_scan_509(oracle, scvod):
+    """doc/fig2/509_seg.pcd is cloud_use of scan 509 coloured per cluster by the reference's binary (SSC::saveSegCloud,
+    ssc.cpp:468-548; 58 colours = clusters after clusterAndCreateFrame + the intensity merge ssc.cpp:571-635 + the box
+    refine).  The oracle's makeApriVec -> makeHashCloud -> clusterAndCreateFrame on the same points (max_dis_ 50, the value
+    that run used) must (a) keep every point -- they all passed the reference's range / FOV filter -- and (b) REFINE the
+    colour partition: the reference only merges CVC clusters afterwards and points it erased can only split ours further,
+    so an oracle cluster that spans two colours would be a binning / neighbourhood error.  Measured: 65 of 29 940 points
+    (0.22 %) sit in a cluster whose majority has another colour; the bar is the verdict's 95 %."""
+    x, rgb = _seg_cloud()
+    assert len(x) == 29940 and len(np.unique(rgb)) == 58
+    P = scvod.make_params("semantickitti", max_dis=50.0)
+    b = oracle.bin(P, x, True)
+    assert len(b["apri"]) == len(x) and len(b["rejected"]) == 0
+    R, S, A, _ = oracle.grid_dims(P)
+    a = b["apri"]
+    assert a["range_idx"].min() >= 0 and a["range_idx"].max() < R and a["azimuth_idx"].min() >= 0 and a["azimuth_idx"].max() < A
+    cl, nc, _ = oracle.cluster(P, a)
+    bad, n_cl, n_col = _refinement(cl, rgb[b["src"]])
+    assert n_cl >= n_col == 58
+    assert bad <= 0.05 * len(x), (bad, n_cl)
+    assert bad <= 100, bad  # (what this oracle measures today: 65; a regression in binning or the neighbourhood shows here first)
+    # the semantickitti.yaml window (max_dis_ 30) is a different run: the same cloud loses its far points there
+    assert len(oracle.bin(scvod.make_params("semantickitti"), x, True)["apri"]) < len(x)
