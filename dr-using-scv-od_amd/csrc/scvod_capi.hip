@@ -81,6 +81,7 @@ struct scvod_ctx {
     size_t chain_ws_bytes = 0;
     ChainWs chain_geom;
     int chain_geom_pts = -1;                 // max_scan_pts the geometry was laid out for
+    int64_t chain_pool_points = 0, chain_geom_pool = -1;  // appended-cloud capacity of a walker (0: 8 x the largest scan)
     bool chain_ran = false;                  // the last scvod_batch_track ran the chain (stats are meaningful)
     bool chain_ws_clean = false;
     int chain_ws_layout_pts = -1;
@@ -627,9 +628,12 @@ int upload_if_changed(scvod_ctx* c, std::vector<T>& held, const T* src, size_t n
 }
 
 // ---- sequential tracking chain: plan (chains of the successor table cut into segments) and workspace ----
-size_t chain_layout(ChainWs& g, int max_scan_pts) {
+size_t chain_layout(ChainWs& g, int max_scan_pts, int64_t pool_points) {
     const size_t nv = (size_t)(max_scan_pts > 0 ? max_scan_pts : 1);
-    const size_t cap_pool = nv * 2 > 65536 ? nv * 2 : 65536;
+    // appended clouds a state can hold: given, or 8 scans' worth (tracking CONSECUTIVE scans of a 10 Hz sequence keeps an object
+    // in range for tens of frames and its cloud grows with every one of them -- the reference's own quadratic behaviour)
+    size_t cap_pool = pool_points > 0 ? (size_t)pool_points : nv * 8;
+    if (cap_pool < 65536) cap_pool = 65536;
     const size_t cap_ent = nv / 4 + 1024;
     g.cap_pool = (int32_t)cap_pool;
     g.cap_ent = (int32_t)cap_ent;
@@ -1148,9 +1152,11 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
         const int nw = plan_chains(c, next, scans, fw, walkers);
         if (nw < 0) return nw;
         if (nw > 0) {
-            if (c->chain_geom_pts != c->A.max_scan_pts) {
-                chain_layout(c->chain_geom, c->A.max_scan_pts);
+            if (c->chain_geom_pts != c->A.max_scan_pts || c->chain_geom_pool != c->chain_pool_points) {
+                chain_layout(c->chain_geom, c->A.max_scan_pts, c->chain_pool_points);
                 c->chain_geom_pts = c->A.max_scan_pts;
+                c->chain_geom_pool = c->chain_pool_points;
+                c->chain_ws_clean = false;
             }
             const size_t need = (size_t)nw * c->chain_geom.stride;
             if (need > c->chain_ws_bytes) {  // first call / larger job: the only allocation, outside any steady-state step
@@ -1197,6 +1203,12 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     return SCVOD_OK;
 }
 
+int scvod_set_chain_capacity(scvod_ctx* c, int64_t pool_points) {
+    if (!c || pool_points < 0 || pool_points > (1ll << 30)) return fail(c, SCVOD_ERR_INVALID, "bad chain capacity");
+    c->chain_pool_points = pool_points;
+    return SCVOD_OK;
+}
+
 int scvod_set_track_mode(scvod_ctx* c, int32_t mode, int32_t segment_steps, int32_t warmup_steps) {
     if (!c || (mode != SCVOD_TRACK_CHAIN && mode != SCVOD_TRACK_FIRST_ORDER && mode != SCVOD_TRACK_CHAIN_GENERIC))
         return fail(c, SCVOD_ERR_INVALID, "unknown tracking mode");
@@ -1217,7 +1229,7 @@ static int chain_status(scvod_ctx* c, int32_t out[8]) {
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy(out, c->d_chain_stats, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out[0])
-        return fail(c, SCVOD_ERR_CAPACITY, "tracking chain overflow (bits %d: 1 appended clouds > %d points, 2 more than %d clusters, 4 created labels, 8 table > bitset)",
+        return fail(c, SCVOD_ERR_CAPACITY, "tracking chain overflow (bits %d: 1 appended clouds > %d points (scvod_set_chain_capacity), 2 more than %d clusters, 4 created labels, 8 table > bitset)",
                     out[0], c->chain_geom.cap_pool, c->chain_geom.cap_ent);
     return SCVOD_OK;
 }

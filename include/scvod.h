@@ -291,6 +291,11 @@ int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_sc
 #define SCVOD_TRACK_FIRST_ORDER 0
 #define SCVOD_TRACK_CHAIN_GENERIC 3 /* testing: the chain with every step through the kernel's generic (HBM-resident) step */
 int scvod_set_track_mode(scvod_ctx* ctx, int32_t mode, int32_t segment_steps, int32_t warmup_steps);
+/* Points of appended clouds one segment's state can hold (0 = default: 8 x the largest scan of the batch).  The reference
+ * appends a static car cluster's whole cloud to its successor at every step (ssc.cpp:1381), so a cloud grows for as long
+ * as the object is tracked; a state that outgrows the capacity is reported (SCVOD_ERR_CAPACITY) by scvod_batch_fetch_track /
+ * scvod_batch_track_stats, never truncated silently.  Workspace = segments x ~70 bytes x this number. */
+int scvod_set_chain_capacity(scvod_ctx* ctx, int64_t pool_points);
 /* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
  * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.
  * Returns SCVOD_ERR_CAPACITY when a chain state did not fit the walkers' workspace (the result is then invalid). */

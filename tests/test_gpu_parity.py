@@ -541,6 +541,28 @@ def test_tracking_chain_of_interleaved_subsequences(scvod, oracle):
     ctx.close()
 
 
+def test_tracking_chain_reports_a_state_that_outgrows_its_capacity(scvod, oracle):
+    """Tracking CONSECUTIVE scans (1 m apart) keeps a parked object in range for tens of frames and the reference appends
+    its whole cloud to the successor at every step (ssc.cpp:1381): the appended clouds outgrow a small capacity.  That is
+    reported (SCVOD_ERR_CAPACITY), never truncated; with room the result is the oracle's chain."""
+    P = _params(scvod, "semantickitti")
+    count = 40
+    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, "K64", 5, 900, count)
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.set_chain_capacity(1)  # (clamped to the minimum, 65 536 points)
+    ctx.set_track_mode(chain=True, segment_steps=64)
+    ctx.batch_track(T)
+    with pytest.raises(scvod.ScvodError, match="chain overflow"):
+        ctx.batch_fetch_track(0)
+    ctx.set_chain_capacity(0)  # default: 8 x the largest scan
+    ctx.batch_track(T)
+    assert ctx.batch_track_stats()["error_bits"] == 0
+    _assert_chain_equal(ctx, oracle, P, res, names, types, poses)
+    ctx.close()
+
+
 def _post_field(shift, moved, seed=11):
     """flat ground + ~2700 thin posts (12 points each, a `car` by the box rules) on a polar lattice whose neighbours are two
     range bins / three sectors apart; `shift` = sensor displacement along x, `moved` = posts displaced by 1 m in y"""

@@ -12,7 +12,7 @@ nxt=np.array([s+skip if s+skip<n else -1 for s in range(n)],np.int32)
 T=np.zeros((n,12),np.float32)
 for s in range(n-skip): T[s]=ctx.pose_delta(poses[s],poses[s+skip])
 ctx.batch_process(pts,offs); ctx.batch_cluster(); ctx.batch_cluster_types()
-for seg,warm in ((24,16),(11,12)):
+for seg,warm in ((11,12),(0,12)):
     ctx.set_track_mode(True,seg,warm)
     ctx.batch_track(T,next_scan=nxt)
     ctx.set_timing(True)
