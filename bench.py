@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--track-mode", default="chain", choices=["chain", "first-order"], help="chain: the reference's sequential tracking chain (default); first-order: every pair independent")
     ap.add_argument("--chain-seg", type=int, default=0, help="steps per chain segment (0: library default)")
     ap.add_argument("--chain-warm", type=int, default=-1, help="warm-up steps in front of a segment (-1: library default)")
+    ap.add_argument("--cluster-exact", action="store_true", help="visiting-order model for components of any size in scans beyond the LDS clustering variant (OS128 class)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (use --backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--dump-map", default="", help="rank 0 writes the merged static map (records sorted by cell key) and the per-scan dynamic counts to this .npz")
@@ -154,6 +155,8 @@ def main():
     ctx = scvod_py.Ctx(P, max_points_total=total_pts + 1024, max_scans=n_sc, device=local)
     if args.track_mode != "chain" or args.chain_seg > 0 or args.chain_warm >= 0:
         ctx.set_track_mode(chain=args.track_mode == "chain", segment_steps=max(args.chain_seg, 0), warmup_steps=max(args.chain_warm, -1))
+    if args.cluster_exact:
+        ctx.set_cluster_exact(True)
     stream = torch.cuda.current_stream().cuda_stream  # torch.distributed orders its work against this stream
     nxt = plan["next_scan"]
     T = np.zeros((n_sc, 12), np.float32)
@@ -247,6 +250,7 @@ def main():
     ctx.set_timing(False)
 
     chain_stats = ctx.batch_track_stats()  # (raises if a chain state overflowed its workspace)
+    cluster_stats = ctx.batch_cluster_stats()  # scans whose clustering kept "everything found is joined" around an out-of-grid triple
     cnt = ctx.batch_counts()
     tot_vox = int(cnt[:, 6].sum())
     tot_apri = int(cnt[:, 4].sum())
@@ -314,10 +318,13 @@ def main():
         tot_ms = sum(v[0] for v in kt.values()) or 1.0
         kernels = {}
         traffic = {}
-        try:  # per-kernel HBM bytes per scan from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/)
-            pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
-            if pm:
+        traffic_src = None
+        try:  # per-kernel HBM bytes per scan from the PMC passes OF THIS WORKLOAD (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/);
+            # no pass for the workload -> traffic is null, never another workload's bytes
+            pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"pmc_traffic_{args.kind.lower()}.json"))
+            if pm and args.preset == {"K64": "semantickitti", "PARK": "parkinglot", "OS128": "os128_fine"}.get(args.kind):
                 traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1]))).get("by_bench_label", {})
+                traffic_src = pm[-1]
         except Exception:
             traffic = {}
         for name, (ms, c) in sorted(kt.items(), key=lambda kv: -kv[1][0]):
@@ -333,6 +340,7 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         pmc_total = sum(v for k, v in traffic.items() if k in kt) if traffic else None
         roof["traffic"] = pmc_total * n_sc if pmc_total else None
+        roof["traffic_source"] = traffic_src
         if dom:
             name, (ms, c) = dom
             roof["dominant_kernel"] = {"name": name, "avg_ms_per_launch": ms / c, "share_of_step": ms / tot_ms,
@@ -390,7 +398,7 @@ def main():
                                        f"{len(job)} sequences of {args.scans} {args.kind} scans (seeded like seq 05, 00, 02, 08, ...), {int(all_scans)} scans in total, whole sequences per rank, {args.preset}.yaml grid"),
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
-                          "static_map_cells": map_cells, "tracking": args.track_mode, "tracking_chain": chain_stats,
+                          "static_map_cells": map_cells, "tracking": args.track_mode, "tracking_chain": chain_stats, "clustering": cluster_stats,
                           "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                           "tracking_stride": args.skip, "sharding": "whole sequences per rank (longest first to the least loaded rank)"},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,

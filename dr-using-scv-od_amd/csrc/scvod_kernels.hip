@@ -2678,7 +2678,9 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             sampled += __syncthreads_count(j < nn && aff[cc_find(parent, j)] != 0);
         }
         int na = 0;
-        if (sampled * 8 <= 2 * kCcExactMaxNodes) {
+        const int exact_max = A.cc_exact_max;
+        const bool listed = (long long)sampled * 8 <= 2ll * exact_max;
+        if (listed) {
             for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
                 const int j = j0 + tid;
                 const bool a = j < nn && aff[cc_find(parent, j)] != 0;
@@ -2692,7 +2694,12 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         // (components of tens of thousands of nodes -- an irregular return on a facade of a 128-beam scan -- are left as they
         // are: the rounds would cost milliseconds in HBM, and around such a point every voxel has finders with three or
         // more points, whose third visit joins all they list)
-        if (na > 0 && na <= kCcExactMaxNodes) {
+        if (tid == 0 && ((!listed && sampled > 0) || na > exact_max || (na > 0 && n_extra + na > n))) {
+            // this scan keeps "everything found is joined" for its affected components (reported: scvod_batch_cluster_stats)
+            atomicAdd(&A.cc_stats[0], 1);
+            atomicAdd(&A.cc_stats[1], listed ? na : sampled * 8);
+        }
+        if (na > 0 && na <= exact_max) {
             struct Run {
                 int o, v, len;
                 int32_t t;
@@ -3667,6 +3674,7 @@ void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream
 }
 
 void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu) {
+    hipMemsetAsync(A.cc_stats, 0, 4 * sizeof(int32_t), st);
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     hipFuncSetAttribute((const void*)k_cc_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcLdsBytes);

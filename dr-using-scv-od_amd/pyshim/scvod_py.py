@@ -125,6 +125,8 @@ def load_lib():
         "scvod_batch_fetch_track": (C.c_int, [vp, i32, C.POINTER(TrackResult)]),
         "scvod_batch_export_table": (C.c_int, [vp, i32, vp, i64, vp]),
         "scvod_set_track_mode": (C.c_int, [vp, i32, i32, i32]),
+        "scvod_set_cluster_exact": (C.c_int, [vp, i32]),
+        "scvod_batch_cluster_stats": (C.c_int, [vp, vp]),
         "scvod_set_chain_capacity": (C.c_int, [vp, i64]),
         "scvod_batch_track_stats": (C.c_int, [vp, vp]),
         "scvod_batch_track_tables": (C.c_int, [vp, vp]),
@@ -161,7 +163,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_chain_capacity", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_chain_capacity", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
@@ -389,6 +391,14 @@ class Ctx:
         """chain=True: the reference's sequential tracking chain (default); False: first-order decisions.
         segment_steps 0: chosen per job; warmup_steps -1: keep the current value."""
         self._chk(self.lib.scvod_set_track_mode(self.h, (3 if generic_step else 1) if chain else 0, int(segment_steps), int(warmup_steps)))
+
+    def set_cluster_exact(self, on=True):
+        self._chk(self.lib.scvod_set_cluster_exact(self.h, int(bool(on))))
+
+    def batch_cluster_stats(self):
+        out = np.zeros(4, np.int32)
+        self._chk(self.lib.scvod_batch_cluster_stats(self.h, out.ctypes.data_as(C.c_void_p)))
+        return dict(scans_approximated=int(out[0]), nodes_concerned=int(out[1]), exact=bool(out[2]))
 
     def set_chain_capacity(self, pool_points):
         self._chk(self.lib.scvod_set_chain_capacity(self.h, int(pool_points)))

@@ -340,6 +340,15 @@ int scvod_batch_export_table(scvod_ctx* ctx, int32_t s, void* d_out, int64_t cap
  * reference's; cluster NAMES are canonical (smallest apri index of the cluster) instead of the
  * order-dependent 5, 6, 7... of the reference.  Results stay on the device until fetched. */
 int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
+/* The visiting order of clusterAndCreateFrame (ssc.cpp:322-340) only matters around index triples OUTSIDE the grid (a
+ * return at polar angle exactly 0 has sector index -1, ...).  Scans whose tables fit the LDS (every 64-beam scan) are
+ * clustered with the exact visiting-order model always.  Larger scans (128 beams on a fine grid) model it exactly for the
+ * components that hold such a triple as long as these have <= 4096 nodes together and otherwise keep "everything found is
+ * joined" (the reference's partition then refines the device's).  on != 0 lifts the bound: exact for every scan, at
+ * milliseconds per affected scan.  scvod_batch_cluster_stats: h_out4 = {scans of the last clustering that kept the
+ * approximation, nodes of the components concerned (upper bound), exact flag, 0}.  Synchronises. */
+int scvod_set_cluster_exact(scvod_ctx* ctx, int32_t on);
+int scvod_batch_cluster_stats(scvod_ctx* ctx, int32_t* h_out4);
 /* copies the cluster name of every apri point of scan s into h_pt_cluster[cap]; returns the count (>= 0)
  * or a negative status */
 int scvod_batch_fetch_clusters(scvod_ctx* ctx, int32_t s, int32_t* h_pt_cluster, int32_t cap);

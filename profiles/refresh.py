@@ -65,26 +65,34 @@ def label(k):
     return k
 
 
-scans = 512
-F, W = load(os.path.join(src, "FETCH_SIZE_counter_collection.csv")), load(os.path.join(src, "WRITE_SIZE_counter_collection.csv"))
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --scans 512 --steps 1 --warmup 0 --no-cpu --no-extras; raw values are "
-               "KB per dispatch, bytes = KB * 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read; uncalibrated for "
-               "gathers, so read-side numbers of gather-heavy kernels are upper bounds); a kernel launched several times per step (k_tk_init) is summed",
-       "scans_per_launch": scans, "kernels": {}}
-by, total = collections.defaultdict(float), 0.0
-# the profiled command runs its step twice (the timed region and the hipEvent attribution pass): per-step = sum / passes
-passes = max(1, len(F.get("k_pw_classify", {}).get("FETCH_SIZE", [0.0])))
-out["passes_in_the_profiled_run"] = passes
-for k in F:
-    f = sum(F[k]["FETCH_SIZE"]) / passes
-    w = sum(W.get(k, {}).get("WRITE_SIZE", [0.0])) / passes
-    b = (2 * f + w) * 1024
-    out["kernels"][k] = {"launches_per_step": len(F[k]["FETCH_SIZE"]) / passes, "fetch_KB_raw_per_step": f, "write_KB_raw_per_step": w, "hbm_bytes_per_step_corrected": b,
-                         "hbm_bytes_per_scan": b / scans}
-    by[label(k)] += b / scans
-    total += b / scans
-out["by_bench_label"], out["total_hbm_bytes_per_scan"] = dict(by), total
-json.dump(out, open(os.path.join(here, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+LABELS.update({"k_tk_chain": "tk_chain", "k_tk_chain_cmp": "tk_chain_fix", "k_tk_chain_fix": "tk_chain_fix"})
+total_by = {}
+for name in ("k64", "park", "os128"):
+    fp, wp = os.path.join(src, f"FETCH_SIZE_counter_collection_{name}.csv"), os.path.join(src, f"WRITE_SIZE_counter_collection_{name}.csv")
+    if not (os.path.exists(fp) and os.path.exists(wp)):
+        continue
+    scans = int(open(os.path.join(src, f"pmc_scans_{name}.txt")).read().split()[0])
+    F, W = load(fp), load(wp)
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py [workload] --steps 1 --warmup 0 --no-cpu --no-extras; raw values are "
+                   "KB per dispatch, bytes = KB * 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read; uncalibrated for "
+                   "gathers, so read-side numbers of gather-heavy kernels are upper bounds); a kernel launched several times per step is summed",
+           "workload": name, "scans_per_launch": scans, "kernels": {}}
+    by, total = collections.defaultdict(float), 0.0
+    # the profiled command runs its step twice (the timed region and the hipEvent attribution pass): per-step = sum / passes
+    passes = max(1, len(F.get("k_pw_classify", {}).get("FETCH_SIZE", [0.0])))
+    out["passes_in_the_profiled_run"] = passes
+    for k in F:
+        f = sum(F[k]["FETCH_SIZE"]) / passes
+        w = sum(W.get(k, {}).get("WRITE_SIZE", [0.0])) / passes
+        b = (2 * f + w) * 1024
+        out["kernels"][k] = {"launches_per_step": len(F[k]["FETCH_SIZE"]) / passes, "fetch_KB_raw_per_step": f, "write_KB_raw_per_step": w, "hbm_bytes_per_step_corrected": b,
+                             "hbm_bytes_per_scan": b / scans}
+        by[label(k)] += b / scans
+        total += b / scans
+    out["by_bench_label"], out["total_hbm_bytes_per_scan"] = dict(by), total
+    json.dump(out, open(os.path.join(here, f"{tag}_pmc_traffic_{name}.json"), "w"), indent=1)
+    total_by[name] = (total, dict(by))
+total, by = total_by.get("k64", (0.0, {}))
 
 # SQ counters: share of the wave cycles that issued an instruction / a VALU / an LDS instruction, that waited, bank conflicts
 p = os.path.join(src, "SQ_counter_collection.csv")

@@ -284,16 +284,21 @@ def _in_grid(oracle, P, apri):
             (apri["azimuth_idx"] >= 0) & (apri["azimuth_idx"] < Az))
 
 
-def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle):
+@pytest.mark.parametrize("exact_flag", [False, True])
+def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle, exact_flag):
     """sixty seeded random clouds on random grids, from a handful of voxels to more than the all-in-LDS variant holds (both
     variants of the clustering kernel).  (a) Their in-grid points alone: the device partition IS the reference's.  (b) With
     the index triples outside the grid (-1 bins of the filtered binning; anything at all when binned without the filter):
     the reference's result depends on the ORDER in which clusterAndCreateFrame visits the points -- a point that finds an
     unlabelled neighbour before a labelled one leaves the first alone (ssc.cpp:322-340), which a later visit repairs only
-    where the two find each other; an aliased voxel is found by points it does not find.  The device joins everything that
-    is found: the reference's partition must refine it, and the points that differ stay below 1 %."""
+    where the two find each other; an aliased voxel is found by points it does not find.  The kernel models that visiting
+    order: exactly for every cloud whose tables fit the LDS, and in the generic (HBM) variant exactly
+    for the components that hold such a triple while they have <= 4096 nodes together.  Beyond that bound it keeps
+    "everything found is joined" -- the reference's partition must then refine the device's, the points that differ stay
+    below 1 %, and scvod_batch_cluster_stats counts the scan -- unless scvod_set_cluster_exact lifted the bound
+    (exact_flag): then every cloud must come out identical and no scan is counted."""
     rng = np.random.default_rng(77)
-    generic = differ = total = exact = 0
+    generic = differ = total = exact = counted = 0
     for case in range(60):
         kw, x = _random_cloud(rng)
         P = scvod.make_params("semantickitti", **kw)
@@ -301,6 +306,8 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle):
         if len(apri) == 0:
             continue
         ctx = scvod.Ctx(P, max_points_total=len(apri) + 64, max_scans=1)
+        if exact_flag:
+            ctx.set_cluster_exact(True)
         reg = apri[_in_grid(oracle, P, apri)].copy()
         generic += len(np.unique(reg["voxel_idx"])) > 14336
         got = ctx.cluster(reg)
@@ -309,10 +316,13 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle):
         assert len(np.unique(got)) == n_ref
         got = ctx.cluster(apri)
         can = _canonical(oracle.cluster(P, apri)[0])
-        if len(np.unique(apri["voxel_idx"])) <= 14336 and len(apri) <= 65535:
-            # all tables in LDS: the visiting order is modelled exactly for the whole scan
+        st = ctx.batch_cluster_stats()
+        counted += st["scans_approximated"]
+        if exact_flag or (len(np.unique(apri["voxel_idx"])) <= 14336 and len(apri) <= 65535):
+            # all tables in LDS (or the bound lifted): the visiting order is modelled exactly for the whole scan
             exact += 1
             assert np.array_equal(got, can), f"case {case} (with its irregular points): {kw}"
+            assert st["scans_approximated"] == 0 and st["exact"] == exact_flag
         else:
             # tables in HBM: exact when the components that hold an irregular run are small (<= 4096 nodes together),
             # "everything found is joined" otherwise -- then the reference's partition refines the device's
@@ -323,6 +333,8 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle):
         ctx.close()
     assert generic >= 5 and exact >= 20
     assert differ < 0.01 * total, (differ, total)
+    if not exact_flag and differ > 0:
+        assert counted > 0  # a cloud that differs was reported as approximated
 
 
 def test_bin_scan_unfiltered_and_filtered(scvod, oracle):
