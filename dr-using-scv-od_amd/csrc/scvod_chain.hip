@@ -1231,15 +1231,34 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
     __shared__ Shared sh;
     extern __shared__ uint32_t ch_bits[];
     const int w0 = C.chain_first_walker[blockIdx.x], w1 = C.chain_first_walker[blockIdx.x + 1];
+    // the verdicts of k_tk_chain_cmp, fetched by all threads at once: next_bad[i] = first walker >= w0 + 1 + i whose check failed
+    constexpr int kFixLds = 1024;
+    __shared__ int32_t next_bad[kFixLds + 1];
+    const int nchk = min(w1 - w0 - 1, kFixLds);
     int all_ok = 1;
-    for (int w = w0 + 1 + (int)threadIdx.x; w < w1; w += kChThreads) all_ok &= wk_of(C.ws, w).hdr[H_SNAP_OK];
+    for (int i = threadIdx.x; i < w1 - w0 - 1; i += kChThreads) {
+        const int ok = wk_of(C.ws, w0 + 1 + i).hdr[H_SNAP_OK];
+        all_ok &= ok;
+        if (i < nchk) next_bad[i] = ok ? 0x7fffffff : w0 + 1 + i;
+    }
     all_ok = __syncthreads_and(all_ok);
     if (threadIdx.x == 0) atomicAdd(&C.stats[2], w1 - w0 - 1);
     if (all_ok) return;
+    if (threadIdx.x == 0) {  // suffix minimum (a chain has a few hundred segments)
+        next_bad[nchk] = (w0 + 1 + nchk < w1) ? w0 + 1 + nchk : 0x7fffffff;  // (beyond the table: taken one by one)
+        for (int i = nchk - 1; i >= 0; --i) next_bad[i] = min(next_bad[i], next_bad[i + 1]);
+    }
     for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
     __syncthreads();
+    int w = w0 + 1;
     bool prev_rewalked = false;
-    for (int w = w0 + 1; w < w1; ++w) {
+    while (w < w1) {
+        if (!prev_rewalked) {  // jump to the next segment whose check failed
+            const int i = w - (w0 + 1);
+            const int nb = i <= nchk ? next_bad[i] : w;
+            if (nb >= w1) break;
+            w = nb;
+        }
         const ChainWalker W = C.walkers[w];
         const Wk K = wk_of(C.ws, w), Kp = wk_of(C.ws, w - 1);
         const int pend = Kp.hdr[H_END_SLOT];
@@ -1249,12 +1268,16 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
         else
             ok = K.hdr[H_SNAP_OK] != 0;
         prev_rewalked = !ok;
-        if (ok) continue;
+        if (ok) {
+            ++w;
+            continue;
+        }
         if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
         copy_state(Kp, pend, K, 0);
         const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.a, W.b, W.a, -1, from_apri);
         if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
         __syncthreads();
+        ++w;
     }
 }
 
