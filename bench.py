@@ -304,7 +304,7 @@ def main():
             extras["voxelgrid_error"] = str(e)[:200]
         try:  # PCIe-inclusive ingest: chunked H2D from pinned host memory on a copy stream, overlapped with the path
             import ingest
-            extras["ingest"] = ingest.measure(scvod_py, P, pts, offs, poses, local)
+            extras["ingest"] = ingest.measure(scvod_py, P, pts, offs, poses, local, skip=args.skip)
         except Exception as e:
             extras["ingest_error"] = str(e)[:200]
 

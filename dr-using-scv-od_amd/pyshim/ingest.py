@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 
-def measure(scvod_py, P, d_pts, offs, poses, device, scans=2048, chunk=512):
+def measure(scvod_py, P, d_pts, offs, poses, device, scans=2048, chunk=512, skip=5):
     import torch
     n_sc = min(int(scans), len(offs) - 1)
     o = np.ascontiguousarray(offs[: n_sc + 1], np.int32)
@@ -22,18 +22,21 @@ def measure(scvod_py, P, d_pts, offs, poses, device, scans=2048, chunk=512):
     max_chunk = max(int(o[min(k + chunk, n_sc)] - o[k]) for k in range(0, n_sc, chunk))
     ctx = scvod_py.Ctx(P, max_points_total=max_chunk + 1024, max_scans=chunk, device=device)
     T = np.zeros((chunk, 12), np.float32)
+    nxt = np.zeros(chunk, np.int32)
     Tall = np.zeros((n_sc, 12), np.float32)
-    for s in range(n_sc - 1):
-        Tall[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    for s in range(n_sc - skip):
+        Tall[s] = ctx.pose_delta(poses[s], poses[s + skip])
 
     def consumers(user, h, first, n, stream):
-        # clustering -> box rules -> differencing inside the chunk (a chunk's last scan has its successor in the next chunk:
-        # a resident job hands that table over, see bench.py; here it is left undecided)
+        # clustering -> box rules -> differencing inside the chunk: scan i against scan i + skip_ like the resident job (the
+        # chains restart at every chunk: the last `skip` scans of a chunk have their successors in the next one and stay undecided)
         if lib.scvod_batch_cluster(h, stream, 0) or lib.scvod_batch_cluster_types(h, stream, 0):
             return -3
         T[:n] = Tall[first:first + n]
-        T[n - 1] = 0
-        return lib.scvod_batch_track(h, T.ctypes.data_as(C.c_void_p), None, None, 0, stream, 0)
+        nxt[:n] = np.arange(n) + skip
+        nxt[max(n - skip, 0):n] = -1
+        nxt[n:] = -1
+        return lib.scvod_batch_track(h, T.ctypes.data_as(C.c_void_p), nxt.ctypes.data_as(C.c_void_p), None, 0, stream, 0)
 
     out = {}
     for name, cb in (("process_only", CB(lambda *a: 0)), ("full_chain", CB(consumers))):
