@@ -278,6 +278,7 @@ void build_dev_params(scvod_ctx* c) {
     b.azimuth_res = p.azimuth_res;
     scvod_grid_dims(&p, &b.range_num, &b.sector_num, &b.azimuth_num, &b.bin_num);
     D.keep = keep_fast_of(b);
+    D.binfast = bin_fast_of(b);
     CzmParams& z = D.czm;
     z.min_range = w.min_range;
     z.max_range = w.max_range;

@@ -284,9 +284,13 @@ __device__ __forceinline__ void carried_probe(const DevParams& P, const Wk& K, f
             const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
             const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
             q[u] = make_float4(x, y, z, q[u].w);
-            Apri a;
-            apri_of_point(P.bin, x, y, z, q[u].w, a);
-            key[u] = a.voxel_idx;
+            int32_t vi;
+            if (!voxel_idx_fast(P.bin, P.binfast, x, y, z, &vi)) {  // (a few points per thousand: next to a bin edge)
+                Apri a;
+                apri_of_point(P.bin, x, y, z, q[u].w, a);
+                vi = a.voxel_idx;
+            }
+            key[u] = vi;
             lo[u] = 0;  // first sample > key
             hi[u] = ns;
         }
@@ -378,15 +382,8 @@ __device__ __forceinline__ int2 eval_entry(const Arena& A, const Wk& K, const St
     wlo = wmin_i(wlo);
     whi = wmax_i(whi);
     wave_sync();
-    // sorted unique slots over the words touched (cleared on the way); the labels are grouped in the same pass: lane t holds
-    // the t-th distinct label id met so far and its count (a cluster hits a handful of labels; more than 64 fall back below)
+    // sorted unique slots over the words touched (cleared on the way)
     int U = 0;
-    int tid_ = -1, tcnt = 0, ntab = 0;
-#ifdef CH_NO_TABLE
-    bool table_ok = false;
-#else
-    bool table_ok = true;
-#endif
     for (int w0 = wlo; w0 <= whi; w0 += 64) {
         const int w = w0 + lane;
         uint32_t word = 0u;
@@ -397,42 +394,42 @@ __device__ __forceinline__ int2 eval_entry(const Arena& A, const Wk& K, const St
         const int c = __popc(word);
         const int inc = wave_incl_scan(c);
         int o = U + inc - c;
-        // labels of this lane's slots (one word: neighbouring voxels, mostly one label)
-        uint32_t rest = word;
-        while (__any(rest != 0u)) {
-            int id = -1;
-            int slot = -1;
-            if (rest) {
-                const int b = __ffs(rest) - 1;
-                rest &= rest - 1;
-                slot = (w << 5) + b;
-                uq[o++] = slot;
-                id = E.rep[slot];
-            }
-            bool todo = id >= 0;
-            while (__any(todo)) {
-                const int firstl = __ffsll((long long)__ballot(todo)) - 1;
-                const int k0 = __shfl(id, firstl);
-                const bool mine = todo && id == k0;
-                const int cntk = __popcll(__ballot(mine));
-                if (mine) todo = false;
-                const unsigned long long hit = __ballot(tid_ == k0);
-                if (hit) {
-                    if (tid_ == k0) tcnt += cntk;
-                } else if (ntab < 64) {
-                    if (lane == ntab) {
-                        tid_ = k0;
-                        tcnt = cntk;
-                    }
-                    ++ntab;
-                } else {
-                    table_ok = false;
-                }
-            }
+        while (word) {
+            const int b = __ffs(word) - 1;
+            word &= word - 1;
+            uq[o++] = (w << 5) + b;
         }
         U += __shfl(inc, 63);
     }
     wave_sync();
+    // remap_name: the labels of the list, 64 slots at a time; lane t holds the t-th distinct label id met so far and its count (a
+    // cluster hits a handful of labels; more than 64 fall back to the min-iteration below)
+    int tid_ = -1, tcnt = 0, ntab = 0;
+    bool table_ok = true;
+    for (int j0 = 0; j0 < U; j0 += 64) {
+        const int j = j0 + lane;
+        const int id = (j < U) ? E.rep[uq[j]] : -1;
+        bool todo = id >= 0;
+        while (__any(todo)) {
+            const int firstl = __ffsll((long long)__ballot(todo)) - 1;
+            const int k0 = __shfl(id, firstl);
+            const bool mine = todo && id == k0;
+            const int cntk = __popcll(__ballot(mine));
+            if (mine) todo = false;
+            const unsigned long long hit = __ballot(tid_ == k0);
+            if (hit) {
+                if (tid_ == k0) tcnt += cntk;
+            } else if (ntab < 64) {
+                if (lane == ntab) {
+                    tid_ = k0;
+                    tcnt = cntk;
+                }
+                ++ntab;
+            } else {
+                table_ok = false;
+            }
+        }
+    }
     int npairs = 0;
     if (table_ok) {  // remap_name in ascending label id
         int rank = 0;

@@ -28,6 +28,7 @@ struct DevParams {
     BinParams bin;
     CzmParams czm;
     KeepFast keep;       // shortcut of the range / FOV verdict (scvod_math.h::keep_of_point)
+    BinFast binfast;     // guarded estimate of a transformed point's voxel index (scvod_math.h::voxel_idx_fast)
     int64_t key_off;     // added to voxel_idx before bucketing (R*S + S + 1)
     int32_t vb_shift;    // bucket = clamp((voxel_idx + key_off) >> vb_shift, 0, n_buckets-1)
     int32_t n_buckets;

@@ -377,6 +377,78 @@ SCVOD_HD int apri_of_point(const BinParams& g, float x, float y, float z, float 
     return keep;
 }
 
+// ---- voxel index of a point WITHOUT the reference's arithmetic where that provably cannot matter (SSC::tracking re-bins
+// every transformed point, ssc.cpp:1280-1286; only the index is used).  The two angles are estimated with a polynomial
+// arctangent (Abramowitz & Stegun 4.4.49, |error| <= 2e-8 rad) in fp32: the estimate and the reference's
+// float(double(atan2f(..)) * 180 / pi) both lie within 2.5e-4 degrees of each other (measured over 10^9 points,
+// tests/test_math_spec.py: < 6e-5), so when the estimate is farther than 1.5e-3 degrees (plus the rounding of the scaled
+// value) from every bin edge the index is the reference's; otherwise -- a few points per thousand -- the caller evaluates
+// apri_of_point.  y == +-0 (angle exactly 0 / 180 / -180: sector -1 and the signed-zero cases of atan2f) and the origin
+// always take the reference arithmetic.  The range index is the reference's own computation (one sqrt, one division).
+struct BinFast {
+    float inv_sector_res, inv_azimuth_res;
+    float m_sector, m_azimuth;  // distance to a bin edge, in bins, below which the estimate decides nothing
+};
+inline BinFast bin_fast_of(const BinParams& g) {
+    BinFast f;
+    f.inv_sector_res = 1.0f / g.sector_res;
+    f.inv_azimuth_res = 1.0f / g.azimuth_res;
+    f.m_sector = 1.5e-3f * f.inv_sector_res + 2.0e-4f;
+    f.m_azimuth = 1.5e-3f * f.inv_azimuth_res + 2.0e-4f;
+    return f;
+}
+SCVOD_HD float atan01_poly(float t) {  // t in [0, 1]
+    const float s = t * t;
+    float q = 0.0028662257f;
+    q = q * s + -0.0161657367f;
+    q = q * s + 0.0429096138f;
+    q = q * s + -0.0752896400f;
+    q = q * s + 0.1065626393f;
+    q = q * s + -0.1420889944f;
+    q = q * s + 0.1999355085f;
+    q = q * s + -0.3333314528f;
+    q = q * s + 1.0f;
+    return t * q;
+}
+SCVOD_HD float rcp_fast(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// degrees in [0, 180] of atan2(|y|, x) for |y| > 0
+SCVOD_HD float atan2_abs_deg_fast(float ay, float x) {
+    const float ax = fabs_f(x);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float a = atan01_poly(mn * rcp_fast(mx));
+    if (ay > ax) a = 1.57079632679f - a;
+    if (x < 0.0f) a = 3.14159265359f - a;
+    return a * 57.2957795131f;
+}
+// true: *voxel_idx is SSC::tracking's index of the point; false: undecided (use apri_of_point)
+SCVOD_HD bool voxel_idx_fast(const BinParams& g, const BinFast& f, float x, float y, float z, int32_t* voxel_idx) {
+    const float ay = fabs_f(y);
+    if (!(ay > 0.0f)) return false;  // y == +-0 (and NaN)
+    const float dis = point_distance2d(x, y);
+    float ang = atan2_abs_deg_fast(ay, x);
+    if (y < 0.0f) ang = 360.0f - ang;
+    const float us = (ang - g.min_angle) * f.inv_sector_res;
+    const float fs = floor_f(us);
+    const float ds = us - fs;
+    if (!(ds > f.m_sector && ds < 1.0f - f.m_sector)) return false;
+    const float az = (z == 0.0f) ? 0.0f : atan2_abs_deg_fast(fabs_f(z), dis);
+    const float azs = z < 0.0f ? -az : az;
+    const float ua = (azs - g.min_azimuth) * f.inv_azimuth_res;
+    const float fa = floor_f(ua);
+    const float da = ua - fa;
+    if (!(da > f.m_azimuth && da < 1.0f - f.m_azimuth)) return false;
+    if (!(fabs_f(us) < 1.0e6f && fabs_f(ua) < 1.0e6f)) return false;
+    const int32_t ri = (int32_t)(ceil_f((dis - g.min_dis) / g.range_res) - 1.0f);
+    *voxel_idx = (int32_t)fa * g.range_num * g.sector_num + ri * g.sector_num + (int32_t)fs;
+    return true;
+}
+
 // ---- range / FOV verdict of makeApriVec WITHOUT the two atan2f of apri_of_point, for callers that only need the
 // verdict (k_pw_arrange).  Same result by construction:
 //   * range: the same fp32 sqrt and comparisons.

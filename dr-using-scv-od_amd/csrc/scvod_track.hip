@@ -125,9 +125,13 @@ __global__ __launch_bounds__(256) void k_tk_probe(DevParams P, Arena A, TrackBat
             const float x = T[0] * q[u].x + T[1] * q[u].y + T[2] * q[u].z + T[3];
             const float y = T[4] * q[u].x + T[5] * q[u].y + T[6] * q[u].z + T[7];
             const float z = T[8] * q[u].x + T[9] * q[u].y + T[10] * q[u].z + T[11];
-            Apri a;
-            apri_of_point(P.bin, x, y, z, q[u].w, a);  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286)
-            key[u] = a.voxel_idx;
+            int32_t vi;  // no range/FOV rejection, no clamping (ssc.cpp:1280-1286); the reference arithmetic next to a bin edge only
+            if (!voxel_idx_fast(P.bin, P.binfast, x, y, z, &vi)) {
+                Apri a;
+                apri_of_point(P.bin, x, y, z, q[u].w, a);
+                vi = a.voxel_idx;
+            }
+            key[u] = vi;
             lo[u] = 0;  // first sample > key
             hi[u] = ns;
         }

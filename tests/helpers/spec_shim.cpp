@@ -87,4 +87,40 @@ int spec_apri(const float g[9], const int dims[4], const float p[4], float out_f
     out_i[0] = a.range_idx; out_i[1] = a.sector_idx; out_i[2] = a.azimuth_idx; out_i[3] = a.voxel_idx;
     return keep;
 }
+// voxel_idx_fast against apri_of_point on n points: returns the number of DECIDED points whose index differs (must be 0);
+// *n_fast = points the estimate decided; *worst_deg = largest |estimate - reference| of the two angles seen (degrees)
+long spec_voxel_fast_compare(const float g[9], const int dims[3], const float* xyz, long n, long* n_fast, double* worst_deg) {
+    scvod::BinParams b;
+    b.min_dis = g[0]; b.max_dis = g[1]; b.min_angle = g[2]; b.max_angle = g[3]; b.min_azimuth = g[4];
+    b.max_azimuth = g[5]; b.range_res = g[6]; b.sector_res = g[7]; b.azimuth_res = g[8];
+    b.range_num = dims[0]; b.sector_num = dims[1]; b.azimuth_num = dims[2]; b.bin_num = dims[0] * dims[1] * dims[2];
+    const scvod::BinFast f = scvod::bin_fast_of(b);
+    long bad = 0, fast = 0;
+    double worst = 0;
+    for (long i = 0; i < n; ++i) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        scvod::Apri a;
+        scvod::apri_of_point(b, x, y, z, 0.f, a);
+        int32_t v = 0;
+        if (scvod::voxel_idx_fast(b, f, x, y, z, &v)) {
+            ++fast;
+            if (v != a.voxel_idx) ++bad;
+        }
+        if (scvod::fabs_f(y) > 0.0f) {
+            float ang = scvod::atan2_abs_deg_fast(scvod::fabs_f(y), x);
+            if (y < 0.0f) ang = 360.0f - ang;
+            double d = std::fabs((double)ang - (double)a.angle);
+            if (d > worst) worst = d;
+            if (z != 0.0f) {
+                float az = scvod::atan2_abs_deg_fast(scvod::fabs_f(z), a.range);
+                if (z < 0.0f) az = -az;
+                d = std::fabs((double)az - (double)a.azimuth);
+                if (d > worst) worst = d;
+            }
+        }
+    }
+    if (n_fast) *n_fast = fast;
+    if (worst_deg) *worst_deg = worst;
+    return bad;
+}
 }

@@ -163,3 +163,41 @@ def test_fast_keep_verdict_equals_reference_arithmetic(spec, scvod):
             assert n_fast.value == 0                                  # shortcut disabled: max_angle < 360
         else:
             assert n_fast.value > 0.6 * n                             # and it really decides most points
+
+
+def test_voxel_index_estimate_never_disagrees_with_the_reference_arithmetic(spec):
+    """scvod_math.h::voxel_idx_fast (polynomial arctangent + distance to the bin edges; used where SSC::tracking re-bins
+    transformed points, ssc.cpp:1280-1286) against apri_of_point: every point it DECIDES carries the reference's voxel
+    index -- uniform points, points scattered 2e-3 degrees around sector / azimuth bin edges, both reference grids and a
+    fine one -- and its angle estimates stay within 2.5e-4 degrees of the reference's (the guard is 1.5e-3)."""
+    import ctypes as C
+    spec.spec_voxel_fast_compare.restype = C.c_long
+    rng = np.random.default_rng(5)
+
+    def run(g, dims, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        nf, w = C.c_long(), C.c_double()
+        gg, dd = np.asarray(g, np.float32), np.asarray(dims, np.int32)
+        bad = spec.spec_voxel_fast_compare(gg.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p), xyz.ctypes.data_as(C.c_void_p),
+                                           C.c_long(len(xyz)), C.byref(nf), C.byref(w))
+        return bad, nf.value / len(xyz), w.value
+    n = 3_000_000
+    grids = [([1.5, 30, 0, 360, -40, 80, 0.4, 1.2, 2.0], [72, 300, 60]), ([0.8, 40, 0, 360, -30, 60, 0.4, 1.2, 2.0], [98, 300, 45]),
+             ([1.5, 30, 0, 360, -40, 80, 0.2, 0.6, 1.0], [143, 600, 120])]
+    for g, dims in grids:
+        xyz = np.stack([rng.uniform(-60, 60, n), rng.uniform(-60, 60, n), rng.uniform(-6, 12, n)], 1)
+        bad, frac, worst = run(g, dims, xyz)
+        assert bad == 0 and frac > 0.98 and worst < 2.5e-4, (bad, frac, worst)
+        r = rng.uniform(1, 60, n)
+        th = np.deg2rad(rng.integers(0, int(360 / g[7]), n) * g[7] + rng.normal(0, 2e-3, n))
+        bad, frac, worst = run(g, dims, np.stack([r * np.cos(th), r * np.sin(th), rng.uniform(-6, 12, n)], 1))
+        assert bad == 0 and worst < 2.5e-4, (bad, worst)
+        az = np.deg2rad(rng.integers(-20, 40, n) * g[8] + rng.normal(0, 2e-3, n))
+        th = rng.uniform(0, 2 * np.pi, n)
+        bad, frac, worst = run(g, dims, np.stack([r * np.cos(th), r * np.sin(th), r * np.tan(az)], 1))
+        assert bad == 0 and worst < 2.5e-4, (bad, worst)
+    # the corner cases that must never be decided by the estimate: y == +-0, the origin, non-finite input
+    edge = np.array([[3.0, 0.0, 0.5], [-3.0, 0.0, 0.5], [3.0, -0.0, 0.5], [-3.0, -0.0, 0.5], [0.0, 0.0, 1.0], [np.nan, 1.0, 1.0],
+                     [1.0, np.inf, 1.0], [1e30, 1e30, 1.0]], np.float32)
+    bad, frac, _ = run(grids[0][0], grids[0][1], edge)
+    assert bad == 0
