@@ -74,8 +74,10 @@ __global__ __launch_bounds__(256) void k_tk_init(Arena A, int phase) {
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
     if (blockIdx.x == 0 && threadIdx.x < 2) A.tk_scan[s * 4 + 2 + threadIdx.x] = 0;  // ([0], [1]: the car lists, written by k_cc_scan)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (A.pt_cluster[(size_t)base + i] != i) continue;
+    // only the car clusters are walked, decided and read back (k_tk_decide, k_tk_dyn, scvod_batch_fetch_track): their roots
+    const int ncar = A.tk_scan[s * 4 + 0];
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < ncar; o += gridDim.x * 256) {
+        const int i = A.tk_clusters[(size_t)base + o];
         A.cl_state[(size_t)base + i] = -1;
         A.tk_npairs[(size_t)base + i] = 0;
         A.tk_nuniq[(size_t)base + i] = 0;
@@ -355,7 +357,7 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
     if (!(phases & 2)) return;  // (phase 1, the successor tables, is written by k_cc_scan with the clustering itself)
     TH_BEGIN("tk_init");  // (the member lists of the car clusters are written by k_cc_scan with the clustering itself)
-    hipLaunchKernelGGL(k_tk_init, g, dim3(256), 0, st, A, 2);
+    hipLaunchKernelGGL(k_tk_init, dim3(1, B), dim3(256), 0, st, A, 2);
     TH_END("tk_init");
     TH_BEGIN("tk_probe");
     hipLaunchKernelGGL(k_tk_probe, dim3(8, B), dim3(256), 0, st, P, A, J, from_apri);  // (a block stages up to 32 KB of keys: few, long-lived blocks)
