@@ -228,3 +228,48 @@ def test_map_in_two_parts_equals_the_map_in_one(scvod):
     for m in (one, two, raw, bad):
         m.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("kind,preset,skip", [("K64", "semantickitti", 5), ("PARK", "parkinglot", 1)])
+def test_map_cells_equal_the_cells_of_the_reference_accumulation(scvod, oracle, kind, preset, skip):
+    """The reference's map is `*instance_map += *rgb_ptr` over the clusters that are not dynamic (SSC::saveSegCloud mode 3,
+    ssc.cpp:477-554) plus the ground clouds and the range / FOV rejects of the evaluation block (ssc.cpp:1460-1480), every scan
+    moved to the world by its pose: a CONCATENATION of clouds.  The device keeps one representative per occupied 0.2 m cell (its
+    own design, checked above against its definition); what must agree with the reference's semantics is WHICH cells are
+    occupied.  Here the clouds come from the ORACLE alone (oracle_time_sequence: Patchwork, binning, clustering, box rules,
+    the sequential tracking chain -> per input point static / dynamic / dropped), not from anything the device computed."""
+    import synth
+    import torch
+    P = scvod.make_params(preset)
+    count = 12
+    scans = [synth.make_scan(5, 200 + k * skip, kind) for k in range(count)]
+    x = np.concatenate([sc[0].numpy() for sc in scans])
+    offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int32)
+    poses = np.asarray([sc[2] for sc in scans], np.float32)
+    _, lab, _ = oracle.time_sequence(P, x, offs, poses)   # 0 static, 1 dynamic, 2 in no cluster (kept), 3 dropped by Patchwork
+    keep = (lab != 1) & (lab != 3)
+    cells = []
+    inv = np.float32(1.0) / np.float32(0.2)
+    for s in range(count):
+        p = x[offs[s]:offs[s + 1]][keep[offs[s]:offs[s + 1]]]
+        T = scvod.pose_matrix(poses[s])
+        w = [((T[4 * i] * p[:, 0] + T[4 * i + 1] * p[:, 1]) + T[4 * i + 2] * p[:, 2]) + T[4 * i + 3] for i in range(3)]
+        u = [(np.floor(c * inv).astype(np.int64) + (1 << 20)).astype(np.uint64) for c in w]
+        cells.append((u[0] << np.uint64(42)) | (u[1] << np.uint64(21)) | u[2])
+    want = np.unique(np.concatenate(cells))
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    d = torch.from_numpy(x).cuda()
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    m = scvod.StaticMap(1 << 21, leaf=0.2)
+    m.accumulate(ctx, poses)
+    k, _ = _sorted_records(m)
+    assert int((lab == 1).sum()) > 0
+    assert np.array_equal(k, want)
+    m.close()
+    ctx.close()
