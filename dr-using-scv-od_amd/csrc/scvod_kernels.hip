@@ -1363,16 +1363,22 @@ __global__ __launch_bounds__(kEmitThreads) void k_emit(DevParams P, Arena A) {
                 const int spos = e - e0;  // position in the non-ground stream of this patch
                 A.nonground_idx[(size_t)base + xng + spos] = (int32_t)id;
                 if (keep) {
-                    Apri a;
-                    apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
-                    // apri_vec is kept in its compact form (source index, voxel key, intensity); the 44-byte
-                    // PointAPRI records are expanded from it on request (k_apri_expand)
+                    // apri_vec is kept in its compact form (source index, voxel key, intensity, index triple); the 44-byte
+                    // PointAPRI records are expanded from it on request (k_apri_expand).  Only the indices are needed here: the
+                    // guarded estimate decides them away from the bin edges, the reference arithmetic next to one
+                    int32_t ri, si, ai;
+                    if (!idx3_fast(P.bin, P.binfast, q.x, q.y, q.z, &ri, &si, &ai)) {
+                        Apri a;
+                        apri_of_point(P.bin, q.x, q.y, q.z, q.w, a);
+                        ri = a.range_idx;
+                        si = a.sector_idx;
+                        ai = a.azimuth_idx;
+                    }
                     A.apri_src[dst0 + ek] = (int32_t)id;
-                    A.apri_key[dst0 + ek] = a.voxel_idx;
-                    A.apri_int[dst0 + ek] = a.intensity;
-                    A.apri_idx3[dst0 + ek] = pack_idx3(a.range_idx, a.sector_idx, a.azimuth_idx);
-                    if ((unsigned)a.range_idx >= (unsigned)P.bin.range_num || (unsigned)a.sector_idx >= (unsigned)P.bin.sector_num ||
-                        (unsigned)a.azimuth_idx >= (unsigned)P.bin.azimuth_num)
+                    A.apri_key[dst0 + ek] = ai * P.bin.range_num * P.bin.sector_num + ri * P.bin.sector_num + si;
+                    A.apri_int[dst0 + ek] = q.w;
+                    A.apri_idx3[dst0 + ek] = pack_idx3(ri, si, ai);
+                    if ((unsigned)ri >= (unsigned)P.bin.range_num || (unsigned)si >= (unsigned)P.bin.sector_num || (unsigned)ai >= (unsigned)P.bin.azimuth_num)
                         A.scan_irr[s] = 1;  // (rare: a -1 bin; every writer stores the same value)
                 } else {
                     A.rejected_src[(size_t)base + xr + (spos - (run_keep + ek))] = (int32_t)id;

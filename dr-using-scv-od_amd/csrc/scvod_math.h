@@ -426,8 +426,8 @@ SCVOD_HD float atan2_abs_deg_fast(float ay, float x) {
     if (x < 0.0f) a = 3.14159265359f - a;
     return a * 57.2957795131f;
 }
-// true: *voxel_idx is SSC::tracking's index of the point; false: undecided (use apri_of_point)
-SCVOD_HD bool voxel_idx_fast(const BinParams& g, const BinFast& f, float x, float y, float z, int32_t* voxel_idx) {
+// true: (*ri, *si, *ai) are the reference's range / sector / azimuth indices of the point; false: undecided (use apri_of_point)
+SCVOD_HD bool idx3_fast(const BinParams& g, const BinFast& f, float x, float y, float z, int32_t* ri_out, int32_t* si_out, int32_t* ai_out) {
     const float ay = fabs_f(y);
     if (!(ay > 0.0f)) return false;  // y == +-0 (and NaN)
     const float dis = point_distance2d(x, y);
@@ -444,8 +444,16 @@ SCVOD_HD bool voxel_idx_fast(const BinParams& g, const BinFast& f, float x, floa
     const float da = ua - fa;
     if (!(da > f.m_azimuth && da < 1.0f - f.m_azimuth)) return false;
     if (!(fabs_f(us) < 1.0e6f && fabs_f(ua) < 1.0e6f)) return false;
-    const int32_t ri = (int32_t)(ceil_f((dis - g.min_dis) / g.range_res) - 1.0f);
-    *voxel_idx = (int32_t)fa * g.range_num * g.sector_num + ri * g.sector_num + (int32_t)fs;
+    *ri_out = (int32_t)(ceil_f((dis - g.min_dis) / g.range_res) - 1.0f);
+    *si_out = (int32_t)fs;
+    *ai_out = (int32_t)fa;
+    return true;
+}
+// true: *voxel_idx is SSC::tracking's index of the point; false: undecided (use apri_of_point)
+SCVOD_HD bool voxel_idx_fast(const BinParams& g, const BinFast& f, float x, float y, float z, int32_t* voxel_idx) {
+    int32_t ri, si, ai;
+    if (!idx3_fast(g, f, x, y, z, &ri, &si, &ai)) return false;
+    *voxel_idx = ai * g.range_num * g.sector_num + ri * g.sector_num + si;
     return true;
 }
 

@@ -104,7 +104,9 @@ long spec_voxel_fast_compare(const float g[9], const int dims[3], const float* x
         int32_t v = 0;
         if (scvod::voxel_idx_fast(b, f, x, y, z, &v)) {
             ++fast;
-            if (v != a.voxel_idx) ++bad;
+            int32_t ri, si, ai;
+            scvod::idx3_fast(b, f, x, y, z, &ri, &si, &ai);
+            if (v != a.voxel_idx || ri != a.range_idx || si != a.sector_idx || ai != a.azimuth_idx) ++bad;
         }
         if (scvod::fabs_f(y) > 0.0f) {
             float ang = scvod::atan2_abs_deg_fast(scvod::fabs_f(y), x);
