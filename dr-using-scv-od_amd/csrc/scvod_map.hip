@@ -47,6 +47,10 @@ namespace {
 constexpr unsigned long long kEmpty = ~0ull;
 constexpr int kMapMaxProbes = 512;  // linear probing: longer runs only appear beyond ~95 % load
 constexpr int kCellBits = 21, kCellBias = 1 << 20;
+// k_map_accumulate: points per thread and round / points per workgroup.  Measured on the 2761-scan K64 job (round 3): one point per
+// thread beats two / four / eight in flight (4.82 / 4.96 / 5.43 / 6.19 ms at 2048 points per workgroup: the extra registers cost
+// occupancy and the later atomics act on staler peeks), and 8192 points per workgroup beat 512 .. 32768 (5.03 .. 4.45 .. 4.58 ms)
+constexpr int kMapU = 1, kMapPts = 8192;
 
 int mfail(scvod_map* m, int code, const char* fmt, ...) {
     if (m) {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = pose[12 * s + i];
     int dropped = 0;
-    constexpr int U = 4;  // four points per thread and step: their loads, then their first probes, are in flight together
+    constexpr int U = kMapU;  // points per thread and round (see kMapU)
     for (int i0 = blockIdx.x * (256 * U); i0 < n; i0 += gridDim.x * (256 * U)) {
         int pid[U], pcnt[U];
         uint8_t cls[U];
@@ -464,7 +468,7 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
         if (need_lists) {  // rare: a map without the ground / without the range-FOV rejects needs those two lists marked
             hipLaunchKernelGGL(k_map_mark_lists, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A);
         }
-        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + kMapPts - 1) / kMapPts, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
                            (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, mode == 1 ? 1 : 0, min_pts, (use_dyn || need_lists || part) ? 1 : 0, part, m->counters);
         MHIP(m, hipGetLastError());
