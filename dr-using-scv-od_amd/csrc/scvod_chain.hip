@@ -270,9 +270,9 @@ __device__ __forceinline__ void fresh_state(const Arena& A, const Wk& K, int slo
 __device__ __forceinline__ void carried_probe(const DevParams& P, const Wk& K, float4* pool, int ncarried, const float* T, const int4* tab, int nv,
                                               const int32_t* skeys, int ns, int shift) {
 #ifndef CH_U
-#define CH_U 4
+#define CH_U 1
 #endif
-    constexpr int U = CH_U;  // four points per thread and round: their loads, searches and table reads overlap
+    constexpr int U = CH_U;  // points per thread and round (measured: 1 beats 2 and 4 -- the phase is ALU-bound, more in flight only costs registers)
     for (int c0 = threadIdx.x; c0 < ncarried; c0 += kChThreads * U) {
         float4 q[U];
         int key[U], lo[U], hi[U];
