@@ -160,9 +160,9 @@ def test_dynamic_removal_quality_matches_the_reference_chain(scvod, oracle, kind
     import synth
     P = scvod.make_params(preset)
     idx = [k * skip for k in range(count)]
-    scans = [synth.make_scan(5, 300 + i, kind) for i in idx]
-    x = np.concatenate([s[0].numpy() for s in scans])
-    gt = np.concatenate([s[1].numpy() for s in scans])
+    scans = [synth.make_scan(5, 300 + i, kind, device="cuda") for i in idx]  # (ray casting on the GPU)
+    x = np.concatenate([s[0].cpu().numpy() for s in scans])
+    gt = np.concatenate([s[1].cpu().numpy() for s in scans])
     offs = np.concatenate([[0], np.cumsum([len(s[0]) for s in scans])]).astype(np.int32)
     poses = np.asarray([s[2] for s in scans], np.float32)
     import torch

@@ -9,10 +9,10 @@ pytestmark = pytest.mark.gpu
 
 def _tracked_batch(scvod, P, kind, seq, first, count, chain=True):
     import synth
-    pts, offs, poses, _ = synth.make_batch(seq, first, count, kind)
+    pts, offs, poses, _ = synth.make_batch(seq, first, count, kind, device="cuda")  # (ray casting on the GPU)
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
     ctx.set_track_mode(chain=chain)
-    d = pts.cuda()
+    d = pts
     ctx.batch_process(d, offs)
     ctx.batch_cluster()
     ctx.batch_cluster_types()
@@ -20,7 +20,7 @@ def _tracked_batch(scvod, P, kind, seq, first, count, chain=True):
     for s in range(count - 1):
         T[s] = ctx.pose_delta(poses[s], poses[s + 1])
     ctx.batch_track(T)
-    return ctx, d, pts.numpy(), offs, poses
+    return ctx, d, pts.cpu().numpy(), offs, poses
 
 
 def _numpy_map(scvod, ctx, x, offs, poses, leaf, use_dyn=True, ground=True, rejected=True):
@@ -242,8 +242,8 @@ def test_map_cells_equal_the_cells_of_the_reference_accumulation(scvod, oracle, 
     import torch
     P = scvod.make_params(preset)
     count = 12
-    scans = [synth.make_scan(5, 200 + k * skip, kind) for k in range(count)]
-    x = np.concatenate([sc[0].numpy() for sc in scans])
+    scans = [synth.make_scan(5, 200 + k * skip, kind, device="cuda") for k in range(count)]
+    x = np.concatenate([sc[0].cpu().numpy() for sc in scans])
     offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int32)
     poses = np.asarray([sc[2] for sc in scans], np.float32)
     _, lab, _ = oracle.time_sequence(P, x, offs, poses)   # 0 static, 1 dynamic, 2 in no cluster (kept), 3 dropped by Patchwork

@@ -392,10 +392,10 @@ def test_track_probe_parity(scvod, oracle):
     ctx.close()
 
 
-def _segmented_batch(scvod, P, kind, seq, first, count):
+def _segmented_batch(scvod, P, kind, seq, first, count, gen="cuda"):
     """count consecutive scans through process -> cluster -> cluster types on the device; returns ctx + per-scan host copies"""
     import synth
-    pts, offs, poses, _ = synth.make_batch(seq, first, count, kind)
+    pts, offs, poses, _ = synth.make_batch(seq, first, count, kind, device=gen)  # (ray casting on the GPU by default: seconds instead of minutes)
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
     d = pts.cuda()
     ctx.batch_process(d, offs)
@@ -429,7 +429,7 @@ def test_batch_track_decision_parity(scvod, oracle, kind, preset, seq, first):
     else:
         P = _params(scvod, preset)
     count = 9 if kind != "OS128" else 5
-    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, kind, seq, first, count)
+    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, kind, seq, first, count, gen="cpu")  # (the samples were chosen on the CPU generator's draws)
     if preset == "fine":
         assert min(r["n_voxels"] for r in res) > 8192
     T = np.zeros((count, 12), np.float32)
@@ -486,12 +486,12 @@ def test_tracking_chain_equals_the_reference_chain(scvod, oracle, kind, preset, 
     import synth
     import torch
     P = _params(scvod, preset)
-    scans = [synth.make_scan(5, first + k * skip, kind) for k in range(count)]
-    x = np.concatenate([sc[0].numpy() for sc in scans])
+    scans = [synth.make_scan(5, first + k * skip, kind, device="cuda") for k in range(count)]  # (ray casting on the GPU: seconds instead of minutes)
+    d = torch.cat([sc[0] for sc in scans]).contiguous()
+    x = d.cpu().numpy()
     offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int32)
     poses = np.asarray([sc[2] for sc in scans], np.float32)
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
-    d = torch.from_numpy(x).cuda()
     ctx.batch_process(d, offs)
     ctx.batch_cluster()
     ctx.batch_cluster_types()
