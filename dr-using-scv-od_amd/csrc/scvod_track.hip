@@ -11,8 +11,10 @@
 //   one non-car label at or above the ratio leaves the state untouched (-1).
 // The labels / cluster sizes / types of the successor are those of its fresh segmentation (clusterAndCreateFrame +
 // refineClusterByBoundingBox + the box rules of recognize), i.e. the state SSC::tracking finds before an earlier pair has
-// re-labelled anything: the FIRST-ORDER decision.  The re-labelling chain of ssc.cpp:1354-1372 / 1399-1419 (a pair mutates
-// the successor's cluster_set before the next pair reads it) is sequential host bookkeeping and lives in host/ssc.cpp.
+// re-labelled anything: the FIRST-ORDER decision, all pairs in parallel.  The sequential chain of SSC::segDF (ssc.cpp:1449-1451:
+// a pair appends clouds to / splits / fuses the successor's clusters before the next pair walks them, ssc.cpp:1351-1419) is
+// replayed on top of these results by scvod_chain.hip (launch_track_chain below, between the decision and the per-point bytes);
+// what this file leaves for it per car cluster: the sorted unique hit list, remap_name with the label ids, the state.
 //
 // Everything stays in HBM: cluster names and types come from scvod_batch_cluster / scvod_batch_cluster_types, the member
 // lists of the car clusters are built here (counting sort by cluster root), no host round trip inside a call.

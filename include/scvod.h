@@ -41,8 +41,8 @@ extern "C" {
 /* One scan holds at most 2^19 points (a 128-beam x 2048-column sweep is 262144): sort keys carry the point index in
  * 19 bits.  Larger scans are refused with SCVOD_ERR_CAPACITY. */
 #define SCVOD_MAX_SCAN_POINTS 524288
-/* A ctx holds at most 2^31 - 65 points in total (int32 scan offsets); in practice the ≈ 210 B/point arena of a 288 GB
- * device ends near 1.3 G points. */
+/* A ctx holds at most 2^31 - 65 points in total (int32 scan offsets); in practice the ≈ 310 B/point arena of a 288 GB
+ * device ends near 0.85 G points (scvod_arena_bytes). */
 
 #define SCVOD_NUM_ZONES 4
 #define SCVOD_MAX_PATCHES 1024 /* reference model has 504 (patchwork.h:48-49) */
