@@ -553,6 +553,44 @@ def test_tracking_chain_of_interleaved_subsequences(scvod, oracle):
     ctx.close()
 
 
+def test_tracking_chain_ends_at_an_external_table(scvod, oracle):
+    """A scan tracked against an EXTERNAL table (the first scan of a block that lives on another shard) ends its chain: the
+    scans before it carry the sequential chain's result -- identical to the unsplit run, the chain only looks forward --
+    and the boundary scan itself the per-pair decision against that table."""
+    import torch
+    P = _params(scvod, "semantickitti")
+    count, cut = 12, 8
+    ctx, d, offs, poses, res, names, types = _segmented_batch(scvod, P, "K64", 5, 1400, count)
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    whole = [ctx.batch_fetch_track(s) for s in range(count)]
+    ctx.set_track_mode(chain=False)
+    ctx.batch_track(T)
+    first_order = [ctx.batch_fetch_track(s) for s in range(count)]
+    msg = torch.zeros((res[cut]["n_voxels"] + 1, 4), dtype=torch.int32, device="cuda")
+    ctx.batch_export_table(cut, msg)
+    torch.cuda.synchronize()
+    ctx.close()
+    oa = np.asarray(offs[:cut + 1], np.int32)
+    ca = scvod.Ctx(P, max_points_total=int(oa[-1]) + 64, max_scans=cut)
+    ca.batch_process(d[:offs[cut]].contiguous(), oa)
+    ca.batch_cluster()
+    ca.batch_cluster_types()
+    nxt = np.array(list(range(1, cut)) + [-2], np.int32)
+    ca.batch_track(T[:cut], next_scan=nxt, ext_tables=[msg])
+    st = ca.batch_track_stats()
+    assert st["chain"] and st["error_bits"] == 0
+    ta = [ca.batch_fetch_track(s) for s in range(cut)]
+    for s in range(cut - 1):
+        for k in ("cluster_root", "cluster_state", "pt_dyn"):
+            assert np.array_equal(ta[s][k], whole[s][k]), (s, k)
+    for k in ("cluster_root", "cluster_state", "pt_dyn", "n_unique", "pair_label", "pair_count"):
+        assert np.array_equal(ta[cut - 1][k], first_order[cut - 1][k]), k
+    ca.close()
+
+
 def test_tracking_chain_reports_a_state_that_outgrows_its_capacity(scvod, oracle):
     """Tracking CONSECUTIVE scans (1 m apart) keeps a parked object in range for tens of frames and the reference appends
     its whole cloud to the successor at every step (ssc.cpp:1381): the appended clouds outgrow a small capacity.  That is
