@@ -53,6 +53,7 @@ __device__ unsigned long long g_prof[8][16];
 #define PROF_MARK(k, i)
 #endif
 #define CC_MARK(i) PROF_MARK(0, i)
+#define CCW_MARK(i) PROF_MARK(4, i)  // the windowed search of the generic k_cc_scan variant
 
 // Normalised bitonic network (every comparator puts the minimum at the lower index), valid for any n:
 // indices >= n act as +inf (all-ones key) and are never read or written.  Works on LDS or global (flat)
@@ -2041,6 +2042,7 @@ struct CcKeys {
     int nv;
     const TabT* tab;
     int bshift;
+    int first = 0;  // searches start at this node or later (a window of the node list: cc_search_windows)
 };
 template <typename TabT>
 __device__ __forceinline__ int cc_lower_bound2(const CcKeys<TabT>& K, int key) {  // key >= 0
@@ -2122,7 +2124,9 @@ __device__ __forceinline__ void cc_search_canon(const CcKeys<TabT>& K, int* pare
 // where the node or the candidate is the HEAD of its run always exists (the head of the run that starts later touches the
 // other run): a node in the middle of a run skips the candidates in the middle of theirs -- the unions left are one or two per
 // run, every find is a step or two.  Irregular voxels do not search like this: they are runs of their own (always heads).
-template <typename TabT>
+//   RUNS (parents in LDS, runs linked up front): a candidate that continues the run of the candidate before it is in that one's
+// component already and is skipped, as is the predecessor of a node inside a run -- four or five unions instead of thirteen.
+template <bool RUNS = false, typename TabT>
 __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* parent, const int* heads, int me, int ri, int si, int ai, int R,
                                                int S, int Az) {
     const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
@@ -2138,12 +2142,12 @@ __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* paren
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int b = max(k0[q], 0) >> K.bshift;
-        lo[q] = (int)K.tab[b];
-        hi[q] = (int)K.tab[b + 1];
+        lo[q] = max((int)K.tab[b], K.first);
+        hi[q] = max((int)K.tab[b + 1], K.first);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (k0[q] < 0) lo[q] = hi[q] = 0;
+        if (k0[q] < 0) lo[q] = hi[q] = K.first;
     bool more = true;
     while (more) {
         more = false;
@@ -2162,7 +2166,7 @@ __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* paren
             }
         }
     }
-    int cand[12], hw[12];  // a range holds at most three keys (sectors y-1 .. y+1), distinct and ascending
+    int cand[12], hw[12], pu[12];  // a range holds at most three keys (sectors y-1 .. y+1), distinct and ascending
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -2170,6 +2174,7 @@ __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* paren
             const int u = min(lo[q] + e, K.nv - 1);
             cand[q * 3 + e] = K.k[u];
             hw[q * 3 + e] = heads ? heads[u >> 5] : -1;
+            pu[q * 3 + e] = cc_ld(&parent[u]);  // read together: a candidate that hangs under my root already costs nothing more
         }
     const int prev = K.k[max(me - 1, 0)];
     // heads == nullptr (parents in LDS, where a union is cheap): every node is treated as a head -- all pairs are joined
@@ -2183,8 +2188,17 @@ __device__ __forceinline__ void cc_search_half(const CcKeys<TabT>& K, int* paren
         for (int e = 0; e < 3; ++e) {
             const int u = lo[q] + e;
             if (!(k0[q] >= 0 && u < K.nv && cand[q * 3 + e] <= k1[q])) continue;
-            if (me_head || ((hw[q * 3 + e] >> (u & 31)) & 1)) ra = cc_union_r(parent, ra, u);
+            if (pu[q * 3 + e] == ra) continue;  // (a parent link is for good: u is in ra's component)
+            const bool u_head = (hw[q * 3 + e] >> (u & 31)) & 1;
+            if (RUNS) {
+                if (e == 0 || u_head) ra = cc_union_r(parent, ra, u);
+                continue;
+            }
+            if (me_head || u_head) ra = cc_union_r(parent, ra, u);
         }
+    // I am a candidate of the nodes of the next row and plane: hanging straight under the root I ended at keeps their finds at a
+    // step and lets most of their candidates pass the test above
+    if (ra < me) atomicMin(&parent[me], ra);
 }
 
 // The occupied voxels around triple t in the order findVoxelNeighbors lists them (ssc.cpp:395-411: range outermost, azimuth
@@ -2206,7 +2220,8 @@ __device__ __forceinline__ void cc_for_each_listed(const CcKeys<TabT>& K, int32_
 // predecessor's inside the row, or one of the two is irregular); parent[v] = the head of v's run (the latest head at or
 // before v: ballots inside a wave, one LDS word per wave across the workgroup, a carry across the 1024-node chunks).
 // `regular` = nullptr: every voxel is regular.  Extra-run nodes (>= nv) are their own parents.
-__device__ __forceinline__ void cc_link_runs(const int* keys, int nv, int nn, int S, const int* regular, int* heads, int* parent, int* wlast) {
+__device__ __forceinline__ void cc_link_runs(const int* keys, int nv, int nn, int S, const int* regular, int* heads, int* parent, int* wlast,
+                                             int off = 0) {  // off: the node number of entry 0 (a window of the node list)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int carry = 0;  // latest head before this chunk
     for (int j0 = 0; j0 < nv; j0 += kCcThreads) {
@@ -2226,13 +2241,128 @@ __device__ __forceinline__ void cc_link_runs(const int* keys, int nv, int nn, in
         for (int w = 0; w < wave; ++w) before = max(before, wlast[w]);
         const unsigned long long upto = b & ((2ull << lane) - 1ull);
         const int mine = upto ? j0 + (wave << 6) + 63 - __clzll((long long)upto) : before;
-        if (j < nv) parent[j] = mine;
+        if (j < nv) parent[j] = mine + off;
         int last = carry;
         for (int w = 0; w < kCcThreads / 64; ++w) last = max(last, wlast[w]);
         carry = last;
         __syncthreads();
     }
     for (int j = nv + tid; j < nn; j += kCcThreads) parent[j] = j;
+}
+
+// Generic variant (nodes in HBM): the backward search of the regular nodes, one WINDOW of whole z-planes at a time with the
+// window's keys and parents in LDS.  A regular node only joins nodes of its own plane and of the plane before it, so a window
+// holds the plane before its first one as well; a window's forest is flattened into the scan's parent array when it is done
+// (parents are global node numbers throughout: the LDS arrays are addressed through pointers shifted by the window's start),
+// and what the window joined among the nodes of that earlier plane -- which belong to the window before -- is joined in HBM,
+// a few unions per window.  Returns false, with nothing changed, when two consecutive planes do not fit `cap` nodes.
+//   regular == nullptr: every node is regular.  Nodes outside the grid's key range (negative keys, extra runs) are left as
+// their own parents for the caller's pass over the irregular nodes.
+// the same for a window of the node list held in LDS: the head bits first, then every node looks its head up in the words at
+// and before its own (no barrier per chunk; entry 0 is a head); parents are node numbers, entry i is node off + i
+__device__ __forceinline__ void cc_link_runs_lds(const int* keys, int count, int S, const int* regular, int* heads, int* parent, int off) {
+    const int tid = threadIdx.x;
+    for (int j0 = 0; j0 < count; j0 += kCcThreads) {
+        const int j = j0 + tid;
+        bool head = false;
+        if (j < count) {
+            const int key = keys[j], pk = keys[max(j - 1, 0)];
+            head = j == 0 || pk != key - 1 || key < 0 || (key % S) == 0;
+            if (regular && !head) head = !cc_bit(regular, j) || !cc_bit(regular, j - 1);
+        }
+        const unsigned long long b = __ballot(head);
+        if ((tid & 31) == 0 && j0 + (tid & ~31) < count) heads[j >> 5] = (int)(unsigned)((tid & 32) ? (b >> 32) : b);
+    }
+    __syncthreads();
+    for (int j = tid; j < count; j += kCcThreads) {
+        int w = j >> 5;
+        unsigned m = (unsigned)heads[w] & (0xffffffffu >> (31 - (j & 31)));
+        while (!m) m = (unsigned)heads[--w];
+        parent[j] = off + (w << 5) + 31 - __clz(m);
+    }
+}
+
+#ifdef SCVOD_PROFILE
+#define CCW_PROF_PARAM , unsigned long long& t_prev
+#define CCW_PROF_ARG , t_prev
+#else
+#define CCW_PROF_PARAM
+#define CCW_PROF_ARG
+#endif
+template <typename TabT>
+__device__ __forceinline__ bool cc_search_windows(const CcKeys<TabT>& K, int* parent_g, const int* regular, int nn, int R, int S, int Az, int* lds,
+                                                  int lds_words, int* wlast CCW_PROF_PARAM) {
+    const int tid = threadIdx.x, RS = R * S;
+    // LDS: [plane starts Az + 1][regular bits of the window][keys cap + 1][parents cap + 1]
+    if (Az + 1 + 64 > lds_words / 4) return false;
+    int* pstart = lds;
+    const int cap = ((lds_words - (Az + 1)) * 32 / 66) - 40;  // 2 words + 2 bits per node
+    int* reg_l = pstart + Az + 1;                              // [cap / 32 + 2]
+    int* heads_l = reg_l + (cap >> 5) + 2;                     // [cap / 32 + 2]
+    int* keys_l = heads_l + (cap >> 5) + 2;                    // [cap + 1]
+    int* par_l = keys_l + cap + 1;                             // [cap + 1]
+    for (int z = tid; z <= Az; z += kCcThreads) pstart[z] = z >= Az ? K.nv : cc_lower_bound2(K, z * RS);
+    __syncthreads();
+    bool too_big = false;
+    for (int z = tid; z < Az; z += kCcThreads) too_big |= pstart[z + 1] - (max(pstart[max(z - 1, 0)] - 1, 0) & ~31) > cap;
+    if (__syncthreads_or(too_big ? 1 : 0)) return false;
+    for (int j = tid; j < nn; j += kCcThreads) parent_g[j] = j;
+    CCW_MARK(1);
+    int z = 0;
+    while (z < Az) {
+        __syncthreads();
+        if (tid == 0) {
+            const int p0 = pstart[max(z - 1, 0)];
+            const int w0 = max(p0 - 1, 0) & ~31;  // (the predecessor read of the window's first node; whole words of the regular bits)
+            int lo = z + 1, hi = Az;              // the last plane end that still fits
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pstart[mid] - w0 <= cap)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            wlast[0] = w0;
+            wlast[1] = p0;
+            wlast[2] = pstart[z];
+            wlast[3] = pstart[lo];
+            wlast[4] = lo;
+        }
+        __syncthreads();
+        const int w0 = wlast[0], p0 = wlast[1], c0 = wlast[2], c1 = wlast[3], z_end = wlast[4];
+        CCW_MARK(2);
+        for (int i = w0 + tid; i < c1; i += kCcThreads) keys_l[i - w0] = K.k[i];
+        if (regular)
+            for (int w = (w0 >> 5) + tid; w <= ((c1 - 1) >> 5); w += kCcThreads) reg_l[w - (w0 >> 5)] = regular[w];
+        __syncthreads();
+        cc_link_runs_lds(keys_l, c1 - w0, S, regular ? reg_l : (const int*)nullptr, heads_l, par_l, w0);
+        __syncthreads();
+        CCW_MARK(3);
+        CcKeys<TabT> KL = K;
+        KL.k = keys_l - w0;
+        KL.nv = c1;
+        KL.first = w0;
+        int* par = par_l - w0;
+        for (int j = c0 + tid; j < c1; j += kCcThreads) {
+            if (regular && !((reg_l[(j - w0) >> 5] >> (j & 31)) & 1)) continue;
+            const int key = KL.k[j];
+            const int ai = key / RS, rem = key - ai * RS;
+            const int ri = rem / S, si = rem - ri * S;
+            cc_search_half<true>(KL, par, heads_l - (w0 >> 5), j, ri, si, ai, R, S, Az);
+        }
+        __syncthreads();
+        CCW_MARK(4);
+        for (int g = c0 + tid; g < c1; g += kCcThreads) parent_g[g] = cc_find(par, g);
+        for (int g = p0 + tid; g < c0; g += kCcThreads) {
+            const int r = cc_find(par, g);
+            // (the window before left both under its own root when it had them in one component: the usual case)
+            if (r != g && cc_ld(&parent_g[g]) != cc_ld(&parent_g[r])) cc_union(parent_g, g, r);
+        }
+        z = z_end;
+        CCW_MARK(5);
+    }
+    __syncthreads();
+    return true;
 }
 
 __device__ __forceinline__ uint32_t f2ord(float f) { return float_sort_key(f); }
@@ -2398,19 +2528,53 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         for (int j = tid; j < nn; j += kCcThreads) parent[j] = j;
         __syncthreads();
     }
+    // generic variant: the bit arrays of the slots leave the LDS for the search (they are not read by it) and the regular
+    // nodes are joined window by window on LDS copies of their keys and parents (cc_search_windows)
+    constexpr int kWinWords = (int)(kCcLdsBytes / 4) - kCcNodes - 64;
+    int* spill[3] = {A.pt_voxel + base, A.tk_members + base, A.tk_clusters + base};
+    auto windows = [&](const int* regular) -> bool {
+        if (FAST || kspan != (int)span) return false;
+        if (slots_lds) {
+            for (int w = tid; w < nw; w += kCcThreads) {
+                spill[0][w] = vstart[w];
+                spill[1][w] = rstart[w];
+                spill[2][w] = prefix[w];
+            }
+            __syncthreads();
+        }
+        const bool done = cc_search_windows(K, parent, regular, nn, R, S, Az, cc_smem + kCcNodes, kWinWords, wlast CCW_PROF_ARG);
+        if (slots_lds) {
+            __syncthreads();
+            for (int w = tid; w < nw; w += kCcThreads) {
+                vstart[w] = spill[0][w];
+                rstart[w] = spill[1][w];
+                prefix[w] = spill[2][w];
+            }
+            __syncthreads();
+        }
+        return done;
+    };
     if (allreg) {
-        if (!FAST) {
+        const bool windowed = windows(nullptr);
+        if (!FAST && !windowed) {
             cc_link_runs(K.k, nv, nn, S, (const int*)nullptr, heads, parent, wlast);
+            __syncthreads();
+        }
+        if (FAST) {  // runs linked in LDS, their head bits in the (unused: every voxel is touched) touched words
+            cc_link_runs_lds(lkeys, nv, S, (const int*)nullptr, touched, parent, 0);
             __syncthreads();
         }
         const int RS = R * S;
         int k_next = K.k[min(tid, nv - 1)];
-        for (int j = tid; j < nv; j += kCcThreads) {
+        for (int j = tid; j < nv && !windowed; j += kCcThreads) {
             const int key = k_next;
             k_next = K.k[min(j + kCcThreads, nv - 1)];
             const int ai = key / RS, rem = key - ai * RS;  // the triple IS the key's decomposition
             const int ri = rem / S, si = rem - ri * S;
-            cc_search_half(K, parent, heads, j, ri, si, ai, R, S, Az);
+            if (FAST)
+                cc_search_half<true>(K, parent, touched, j, ri, si, ai, R, S, Az);
+            else
+                cc_search_half(K, parent, heads, j, ri, si, ai, R, S, Az);
         }
     } else if (FAST && n <= 65535) {
         // ---- a scan with index triples outside the grid, all tables in LDS: the visiting order of clusterAndCreateFrame
@@ -2604,19 +2768,20 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         int* regular = FAST ? cc_smem + 2 * kCcNodes + 3 * (kCcSlots / 32) + 2 * (kCcNodes / 32) + kCcBuckets / 2 : A.pt_cluster + base;
         int* triple = (int*)(A.tk_pairs + base);  // [nn] opener triples (arena scratch, free until the naming pass)
         const int nwords = (nn + 31) >> 5;
-        for (int j0 = 0; j0 < nn; j0 += kCcThreads * 4) {  // the three dependent gathers of four nodes per thread in flight together
-            int tc[4];
+        constexpr int kG = FAST ? 4 : 8;
+        for (int j0 = 0; j0 < nn; j0 += kCcThreads * kG) {  // the three dependent gathers of kG nodes per thread in flight together
+            int tc[kG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kG; ++u) {
                 const int j = j0 + u * kCcThreads + tid;
                 tc[u] = (j < nn) ? ((j < nv) ? vbeg[j] : extras[j - nv]) : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tc[u] = vpts[tc[u]];
+            for (int u = 0; u < kG; ++u) tc[u] = vpts[tc[u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tc[u] = idx3[tc[u]];
+            for (int u = 0; u < kG; ++u) tc[u] = idx3[tc[u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kG; ++u) {
                 const int j = j0 + u * kCcThreads + tid;
                 const int t = tc[u];
                 const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
@@ -2632,16 +2797,72 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             }
         }
         __syncthreads();
-        if (!FAST) {
+        CCW_MARK(0);
+        const bool windowed = windows(regular);
+        if (!FAST && !windowed) {
             cc_link_runs(K.k, nv, nn, S, regular, heads, parent, wlast);
             __syncthreads();
         }
+        if (windowed) {
+            // the regular nodes are done: only the irregular ones (a handful per scan) search, straight from the bit words
+            // listed, then one WAVE per node: the nine (azimuth, range) rows around its triple on lanes 0-8 (cc_search), the nine
+            // around its key's own triple on lanes 16-24 (cc_search_canon) -- a thread alone walks 18 searches in HBM one
+            // after the other
+            int* irr = heads;  // [nn] (the run heads are not used by the windowed search)
+            if (tid == 0) wlast[8] = 0;
+            __syncthreads();
+            for (int w = tid; w < nwords; w += kCcThreads) {
+                unsigned m = ~(unsigned)regular[w];
+                if (w == nwords - 1 && (nn & 31)) m &= (1u << (nn & 31)) - 1u;
+                while (m) {
+                    irr[atomicAdd(&wlast[8], 1)] = (w << 5) + __ffs((int)m) - 1;
+                    m &= m - 1;
+                }
+            }
+            __syncthreads();
+            const int n_irr = wlast[8], lane = tid & 63, RS = R * S;
+            for (int x = tid >> 6; x < n_irr; x += kCcThreads / 64) {
+                const int j = cc_ld(&irr[x]);
+                const int q = lane & 15, canon = lane >> 4;  // canon: 0 = around the triple, 1 = around the key's triple
+                int ri, si, ai;
+                bool on = q < 9 && canon < 2;
+                if (canon == 0) {
+                    const int t = triple[j];
+                    ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+                } else {
+                    const int key = (j < nv) ? K.k[j] : -1;
+                    on = on && key >= 0 && key < kspan;
+                    ai = key / RS;
+                    const int rem = key - ai * RS;
+                    ri = rem / S, si = rem - ri * S;
+                }
+                const int z = ai - 1 + q / 3, xx = ri - 1 + q % 3;
+                const int ylo = max(si - 1, 0), yhi = min(si + 1, S - 1);
+                on = on && ylo <= yhi && z >= 0 && z <= Az - 1 && xx >= 0 && xx <= R - 1;
+                bool hit = false;
+                if (on) {
+                    const int k0 = xx * S + ylo + z * RS, k1 = k0 + (yhi - ylo);
+                    for (int u = cc_lower_bound2(K, k0); u < K.nv && K.k[u] <= k1; ++u) {
+                        if (canon == 0) {
+                            cc_set(touched, u);  // every point of u joins (ssc.cpp:316)
+                            if (u != j) cc_union(parent, j, u);
+                            hit = true;
+                        } else if (u != j && cc_bit(regular, u)) {
+                            cc_set(touched, j);  // the regular voxel u finds me here (ssc.cpp:316)
+                            cc_union(parent, j, u);
+                        }
+                    }
+                }
+                if (__any(hit) && lane == 0) cc_set(found, j);
+            }
+        }
         int t_next = triple[min(tid, nn - 1)];
-        for (int j = tid; j < nn; j += kCcThreads) {
+        for (int j = tid; j < nn && !windowed; j += kCcThreads) {
             const int t = t_next;
             t_next = triple[min(j + kCcThreads, nn - 1)];
             if (cc_bit(regular, j)) {
-                cc_search_half(K, parent, heads, j, (t & 2047) - 2, ((t >> 11) & 2047) - 2, ((t >> 22) & 1023) - 2, R, S, Az);
+                if (!windowed)
+                    cc_search_half(K, parent, heads, j, (t & 2047) - 2, ((t >> 11) & 2047) - 2, ((t >> 22) & 1023) - 2, R, S, Az);
             } else {
                 if (cc_search(K, parent, touched, j, t, R, S, Az)) cc_set(found, j);
                 if (j < nv) {
@@ -2674,8 +2895,15 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         int* Tng = A.tk_cursor + base;                        // [nv] next round's times, then [na] q per listed node
         for (int j = tid; j < nn; j += kCcThreads) aff[j] = 0;
         __syncthreads();
-        for (int j = tid; j < nn; j += kCcThreads)
-            if (j >= nv || !cc_bit(regular, j)) aff[cc_find(parent, j)] = 1;
+        for (int w = tid; w < ((nn + 31) >> 5); w += kCcThreads) {  // the irregular nodes, straight from the bit words (extra runs have no bit set)
+            unsigned m = ~(unsigned)regular[w];
+            if (w == ((nn + 31) >> 5) - 1 && (nn & 31)) m &= (1u << (nn & 31)) - 1u;
+            while (m) {
+                const int j = (w << 5) + __ffs((int)m) - 1;
+                m &= m - 1;
+                aff[cc_find(parent, j)] = 1;
+            }
+        }
         __syncthreads();
         // (a sample of every eighth node first: components far beyond the bound are not even listed)
         int sampled = 0;
@@ -2875,6 +3103,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     // canonical name of a component: the smallest apri index among the openers of its nodes (every other member of a
     // node sits behind its opener in an ascending point list)
     int* minpt = FAST ? lkeys : A.cl_count + base;  // the key table is not needed any more
+    int* flat_g = A.tk_cursor + base;               // [nn] generic variant: root of every node
     for (int j = tid; j < nn; j += kCcThreads) minpt[j] = 0x7fffffff;
     __syncthreads();
     if (FAST) {
@@ -2884,25 +3113,48 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             atomicMin(&minpt[r], vpts[k]);
         }
     } else {
-        // minima in HBM: neighbours in the node list mostly share their root -- one atomic per distinct root of a wave
-        for (int j0 = 0; j0 < nn; j0 += kCcThreads) {
-            const int j = j0 + tid;
-            int r = -1, name = 0x7fffffff;
-            if (j < nn) {
-                const int k = (j < nv) ? vbeg[j] : extras[j - nv];
-                r = cc_find(parent, j);
-                name = vpts[k];
-            }
-            bool todo = r >= 0;
-            while (__any(todo)) {
-                const int first = __ffsll((long long)__ballot(todo)) - 1;
-                const int r0 = __shfl(r, first);
-                const bool mine = todo && r == r0;
-                int m = mine ? name : 0x7fffffff;
+        // minima in HBM: neighbours in the node list mostly share their root -- one atomic per distinct root of a wave.  Four nodes
+        // per thread and step, their gathers and the hops to their roots in flight together; the roots are final here and are
+        // kept (flat_g) for the numbering below
+        for (int j0 = 0; j0 < nn; j0 += kCcThreads * 4) {
+            int kk[4], rr[4], nm[4];
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) m = min(m, __shfl_xor(m, d));
-                if ((tid & 63) == first) atomicMin(&minpt[r0], m);
-                if (mine) todo = false;
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCcThreads + tid;
+                kk[u] = (j < nn) ? ((j < nv) ? vbeg[j] : extras[j - nv]) : 0;
+                rr[u] = (j < nn) ? cc_ld(&parent[j]) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nm[u] = vpts[kk[u]];
+            bool more = true;
+            while (more) {
+                more = false;
+                int pp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pp[u] = cc_ld(&parent[rr[u]]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (pp[u] != rr[u]) {
+                        rr[u] = pp[u];
+                        more = true;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCcThreads + tid;
+                const int r = (j < nn) ? rr[u] : -1;
+                if (j < nn) flat_g[j] = r;
+                bool todo = r >= 0;
+                while (__any(todo)) {
+                    const int first = __ffsll((long long)__ballot(todo)) - 1;
+                    const int r0 = __shfl(r, first);
+                    const bool mine = todo && r == r0;
+                    int m = mine ? nm[u] : 0x7fffffff;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) m = min(m, __shfl_xor(m, d));
+                    if ((tid & 63) == first) atomicMin(&minpt[r0], m);
+                    if (mine) todo = false;
+                }
             }
         }
     }
@@ -2910,12 +3162,14 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     CC_MARK(4);
     // flatten, then number the components 0 .. ncl-1 in node order: parent[j] becomes the compact id of j's component
     int* flat = A.tk_cursor + base;                 // [nn] root of every node (arena scratch, nn <= n)
-    for (int j = tid; j < nn; j += kCcThreads) {
-        int r = j;
-        for (int q = parent[r]; q != r; q = parent[r]) r = q;  // read-only walk: the roots are final
-        flat[j] = r;
-    }
-    __syncthreads();
+    if (FAST) {
+        for (int j = tid; j < nn; j += kCcThreads) {
+            int r = j;
+            for (int q = parent[r]; q != r; q = parent[r]) r = q;  // read-only walk: the roots are final
+            flat[j] = r;
+        }
+        __syncthreads();
+    }  // (generic variant: written with the names above)
     int* slot_cid = (int*)(A.tk_pairs + base);      // [n] compact id of every apri point's component, -1 = a cluster of its own
     int* rootcid = slot_cid + n;                    // [nn]
     int* names = A.tk_nuniq + base;                 // [ncl] canonical name per compact id
@@ -2987,7 +3241,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     }
     __syncthreads();
     {
-        constexpr int U = 4;  // four points per thread and step: their index and point loads are in flight together
+        constexpr int U = 4;  // four points per thread and step: their index and point loads are in flight together (eight: slower)
         for (int i0 = 0; i0 < n; i0 += kCcThreads * U) {
             int cidv[U], srcv[U];
             float4 qv[U];

@@ -19,6 +19,8 @@ KERNELS = [
     ("k_pw_sort<4096> (per scan)", ["load keys", "bitonic sort", "gather + write sorted points"]),
     ("k_pw_sort<8192> (per scan)", ["load keys", "bitonic sort", "gather + write sorted points"]),
     ("k_vx_bucket<4096> (per scan)", ["load keys", "bitonic sort", "heads + voxel starts", "stage intensities", "per-voxel sums", "final writes"]),
+    ("k_cc_scan generic variant, inside 'neighbour search + unions' (per scan)",
+     ["opener triples + regular bits", "spill, plane starts, init", "windows: plan", "windows: load", "windows: search in LDS", "windows: write-out"]),
 ]
 
 
