@@ -2880,6 +2880,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         if (cc_bit(touched, v)) cc_union(parent, nv + e, v);
     }
     __syncthreads();
+    if (!FAST) CCW_MARK(6);
     if (!FAST && !allreg && slots_lds && kspan == (int)span) {
         // ---- generic variant, scan with irregular triples: what stands now is "everything found is joined".  The visiting
         // order (the model of the all-in-LDS variant above) can only SPLIT components that hold an
@@ -3100,6 +3101,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             }
         }
     }
+    if (!FAST) CCW_MARK(7);
     // canonical name of a component: the smallest apri index among the openers of its nodes (every other member of a
     // node sits behind its opener in an ascending point list)
     int* minpt = FAST ? lkeys : A.cl_count + base;  // the key table is not needed any more

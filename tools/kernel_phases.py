@@ -20,7 +20,8 @@ KERNELS = [
     ("k_pw_sort<8192> (per scan)", ["load keys", "bitonic sort", "gather + write sorted points"]),
     ("k_vx_bucket<4096> (per scan)", ["load keys", "bitonic sort", "heads + voxel starts", "stage intensities", "per-voxel sums", "final writes"]),
     ("k_cc_scan generic variant, inside 'neighbour search + unions' (per scan)",
-     ["opener triples + regular bits", "spill, plane starts, init", "windows: plan", "windows: load", "windows: search in LDS", "windows: write-out"]),
+     ["opener triples + regular bits", "spill, plane starts, init", "windows: plan", "windows: load", "windows: search in LDS", "windows: write-out",
+      "(from 'extra runs, canonical names') extra runs", "(from 'extra runs, canonical names') affected components: marks, sample, list"]),
 ]
 
 
