@@ -12,7 +12,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
 for f in os.listdir(here):
-    if f.startswith(tag + "_"):
+    if f.startswith(tag + "_") and not f.endswith(".md"):  # (hand-written notes of the round stay)
         os.remove(os.path.join(here, f))
 
 
