@@ -113,7 +113,8 @@ struct Arena {
     int32_t cc_exact_max;     // generic clustering variant: nodes of components with irregular runs that are re-clustered exactly
                               //   (default 4096; scvod_set_cluster_exact lifts it to "any")
     int32_t* cc_stats;        // [4] per clustering call: scans that kept "everything found is joined" for a component, nodes of
-                              //   those components (an upper bound from a sample when they are not even listed), 0, 0
+                              //   those components (an upper bound from a sample when they are not even listed), 0, scans of the generic variant
+                              //   whose z-planes are too large for the windowed search (forest in HBM)
     int32_t* cc_parent;       // [N] union-find forest over apri indices (scan-local)
     uint8_t* cc_touched;      // [N] per voxel slot: appeared in a neighbourhood
     int32_t* pt_voxel;        // [N] voxel slot of every apri point

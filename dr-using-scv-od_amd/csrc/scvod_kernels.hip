@@ -2556,6 +2556,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     };
     if (allreg) {
         const bool windowed = windows(nullptr);
+        if (!FAST && !windowed && tid == 0) atomicAdd(&A.cc_stats[3], 1);  // planes too large for a window: forest in HBM
         if (!FAST && !windowed) {
             cc_link_runs(K.k, nv, nn, S, (const int*)nullptr, heads, parent, wlast);
             __syncthreads();
@@ -2799,6 +2800,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         __syncthreads();
         CCW_MARK(0);
         const bool windowed = windows(regular);
+        if (!FAST && !windowed && tid == 0) atomicAdd(&A.cc_stats[3], 1);
         if (!FAST && !windowed) {
             cc_link_runs(K.k, nv, nn, S, regular, heads, parent, wlast);
             __syncthreads();

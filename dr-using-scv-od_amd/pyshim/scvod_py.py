@@ -398,7 +398,7 @@ class Ctx:
     def batch_cluster_stats(self):
         out = np.zeros(4, np.int32)
         self._chk(self.lib.scvod_batch_cluster_stats(self.h, out.ctypes.data_as(C.c_void_p)))
-        return dict(scans_approximated=int(out[0]), nodes_concerned=int(out[1]), exact=bool(out[2]))
+        return dict(scans_approximated=int(out[0]), nodes_concerned=int(out[1]), exact=bool(out[2]), scans_on_hbm_forest=int(out[3]))
 
     def set_chain_capacity(self, pool_points):
         self._chk(self.lib.scvod_set_chain_capacity(self.h, int(pool_points)))

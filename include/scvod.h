@@ -346,7 +346,8 @@ int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
  * components that hold such a triple as long as these have <= 4096 nodes together and otherwise keep "everything found is
  * joined" (the reference's partition then refines the device's).  on != 0 lifts the bound: exact for every scan, at
  * milliseconds per affected scan.  scvod_batch_cluster_stats: h_out4 = {scans of the last clustering that kept the
- * approximation, nodes of the components concerned (upper bound), exact flag, 0}.  Synchronises. */
+ * approximation, nodes of the components concerned (upper bound), exact flag, scans beyond the LDS whose z-planes were
+ * too large for the windowed search and were joined on a forest in HBM instead (slower, same result)}.  Synchronises. */
 int scvod_set_cluster_exact(scvod_ctx* ctx, int32_t on);
 int scvod_batch_cluster_stats(scvod_ctx* ctx, int32_t* h_out4);
 /* copies the cluster name of every apri point of scan s into h_pt_cluster[cap]; returns the count (>= 0)

@@ -879,6 +879,26 @@ def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("irregular", [0, 60])
+def test_cluster_partition_on_a_grid_of_two_large_planes(scvod, oracle, irregular):
+    """the generic variant joins its regular nodes window by window in LDS, a window being whole z-planes; a grid whose planes
+    hold more nodes than a window (two azimuth bins, fine in range and sector) is joined on the forest in HBM instead: same
+    partition, and the scan is counted"""
+    import synth
+    P = scvod.make_params("semantickitti", range_res=0.04, sector_res=0.18, azimuth_res=25.0)
+    x = synth.make_scan(5, 41, "K64")[0].numpy()
+    if irregular:
+        x = _with_irregular_returns(x, irregular, 9)
+    ctx = scvod.Ctx(P, max_points_total=x.shape[0] + 64, max_scans=1)
+    r = ctx.process_scan(x)
+    assert r["n_voxels"] > 14336  # the generic variant
+    got = ctx.cluster(r["apri"])
+    assert ctx.batch_cluster_stats()["scans_on_hbm_forest"] == 1
+    ref, _, _ = oracle.cluster(P, r["apri"])
+    assert np.array_equal(got, _canonical(ref))
+    ctx.close()
+
+
 def test_cluster_partition_on_a_fine_grid(scvod, oracle):
     """more voxels than the clustering kernel's LDS key table holds: neighbourhood searches in global memory"""
     import synth
@@ -889,6 +909,7 @@ def test_cluster_partition_on_a_fine_grid(scvod, oracle):
     assert r["n_voxels"] > 14336               # the generic variant: keys and parents in HBM
     assert (r["apri"]["sector_idx"] < 0).any()  # ... with a few irregular nodes among the regular ones
     got = ctx.cluster(r["apri"])
+    assert ctx.batch_cluster_stats()["scans_on_hbm_forest"] == 0  # (joined window by window in LDS)
     ref, _, _ = oracle.cluster(P, r["apri"])
     assert np.array_equal(got, _canonical(ref))
     ctx.close()
