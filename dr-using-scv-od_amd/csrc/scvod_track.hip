@@ -372,7 +372,16 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     const size_t per_wave = (size_t)words * 4;
     TH_BEGIN("tk_decide");
     hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * small_words * 4, st, A, J, small_words, -1);
+    // (a 128-beam scan on a fine grid: 70 k voxels in a batch sized for 260 k points) tables of up to 131 072 voxels: 16 KB per wave
+    const int mid_words = 4096;
+    int done_words = small_words;
+    if (words > mid_words) {
+        hipFuncSetAttribute((const void*)k_tk_decide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * mid_words * 4);
+        hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * mid_words * 4, st, A, J, mid_words, small_words);
+        done_words = mid_words;
+    }
     if (words > small_words) {
+        const int small_words = done_words;  // (the launches below take the tables beyond what is done)
         if (4 * per_wave <= 64 * 1024) {  // two workgroups per CU
             hipFuncSetAttribute((const void*)k_tk_decide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * per_wave));
             hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * per_wave, st, A, J, words, small_words);
