@@ -205,9 +205,24 @@ def main():
                 a[0] += e0.elapsed_time(e1)
                 a[1] += 1
             if multi:  # reduce-scatter of the map: equal padded slots, one all-to-all, no size on the host
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+                if timed:
+                    ev[0].record()
                 smap.export_parts_padded(world, part_send, stream=stream)
                 pmap.clear(stream=stream)
-                pmap.merge(shard.reduce_scatter_map(dist, part_send, part_recv), stream=stream)
+                if timed:
+                    ev[1].record()
+                got = shard.reduce_scatter_map(dist, part_send, part_recv)
+                if timed:
+                    ev[2].record()
+                pmap.merge(got, stream=stream)
+                if timed:
+                    ev[3].record()
+                    ev[3].synchronize()
+                    for name, i in (("map_export_parts", 0), ("map_all_to_all", 1), ("map_merge", 2)):
+                        a = kt.setdefault(name, [0.0, 0])
+                        a[0] += ev[i].elapsed_time(ev[i + 1])
+                        a[1] += 1
 
     def barrier():
         torch.cuda.synchronize()

@@ -249,31 +249,54 @@ __global__ __launch_bounds__(256) void k_map_merge(const MapRec* __restrict__ re
 // occupied records -> dense list (order = whatever the atomics give: consumers that need a canonical order sort by key)
 __global__ __launch_bounds__(256) void k_map_export(const MapRec* __restrict__ table, long long capacity, MapRec* out, long long cap_out,
                                                     float4* out_xyzi, float leaf, unsigned long long* counters) {
+    __shared__ unsigned int cnt;
+    __shared__ unsigned long long gstart;
+    constexpr int IT = 8;  // slots per thread and round: one reservation on the shared counter per 2048 slots, not per wave
     const int lane = threadIdx.x & 63;
-    for (long long t0 = blockIdx.x * 256ll; t0 < capacity; t0 += (long long)gridDim.x * 256) {
-        const long long t = t0 + threadIdx.x;
-        MapRec r;
-        r.key = kEmpty;
-        if (t < capacity) r = table[t];
-        const bool occ = r.key != kEmpty;
-        const unsigned long long bal = __ballot(occ);
-        if (!bal) continue;
-        unsigned long long start = 0;
-        if (lane == 0) start = atomicAdd(&counters[0], (unsigned long long)__popcll(bal));
-        start = __shfl(start, 0);
-        if (occ) {
-            const long long o = (long long)start + __popcll(bal & ((1ull << lane) - 1ull));
-            if (o < cap_out) {
-                if (out) out[o] = r;
-                if (out_xyzi) {
-                    const int cx = (int)(r.key >> (2 * kCellBits)) - kCellBias, cy = (int)((r.key >> kCellBits) & ((1u << kCellBits) - 1u)) - kCellBias,
-                              cz = (int)(r.key & ((1u << kCellBits) - 1u)) - kCellBias;
-                    const float qx = (float)((r.val >> 48) & 0xffffu), qy = (float)((r.val >> 32) & 0xffffu), qz = (float)((r.val >> 16) & 0xffffu);
-                    out_xyzi[o] = make_float4(((float)cx + (qx + 0.5f) / 65536.0f) * leaf, ((float)cy + (qy + 0.5f) / 65536.0f) * leaf,
-                                              ((float)cz + (qz + 0.5f) / 65536.0f) * leaf, (float)(r.val & 0xffffu) / 256.0f);
-                }
+    for (long long t0 = blockIdx.x * (256ll * IT); t0 < capacity; t0 += (long long)gridDim.x * (256 * IT)) {
+        if (threadIdx.x == 0) cnt = 0;
+        __syncthreads();
+        MapRec r[IT];
+        int loc[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const long long t = t0 + it * 256 + threadIdx.x;
+            r[it].key = kEmpty;
+            r[it].val = kEmpty;
+            if (t < capacity) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&table[t]);
+                r[it].key = v.x;
+                r[it].val = v.y;
             }
         }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const bool occ = r[it].key != kEmpty;
+            const unsigned long long bal = __ballot(occ);
+            unsigned int wbase = 0;
+            if (lane == 0 && bal) wbase = atomicAdd(&cnt, (unsigned int)__popcll(bal));
+            wbase = __shfl(wbase, 0);
+            loc[it] = occ ? (int)(wbase + __popcll(bal & ((1ull << lane) - 1ull))) : -1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && cnt) gstart = atomicAdd(&counters[0], (unsigned long long)cnt);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (loc[it] < 0) continue;
+            const long long o = (long long)gstart + loc[it];
+            if (o >= cap_out) continue;
+            const MapRec& q = r[it];
+            if (out) *reinterpret_cast<ulonglong2*>(&out[o]) = make_ulonglong2(q.key, q.val);
+            if (out_xyzi) {
+                const int cx = (int)(q.key >> (2 * kCellBits)) - kCellBias, cy = (int)((q.key >> kCellBits) & ((1u << kCellBits) - 1u)) - kCellBias,
+                          cz = (int)(q.key & ((1u << kCellBits) - 1u)) - kCellBias;
+                const float qx = (float)((q.val >> 48) & 0xffffu), qy = (float)((q.val >> 32) & 0xffffu), qz = (float)((q.val >> 16) & 0xffffu);
+                out_xyzi[o] = make_float4(((float)cx + (qx + 0.5f) / 65536.0f) * leaf, ((float)cy + (qy + 0.5f) / 65536.0f) * leaf,
+                                          ((float)cz + (qz + 0.5f) / 65536.0f) * leaf, (float)(q.val & 0xffffu) / 256.0f);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -300,24 +323,40 @@ __global__ __launch_bounds__(256) void k_map_scatter_parts(const MapRec* __restr
                                                            unsigned long long* part_cursor, MapRec* out, long long cap_out) {
     __shared__ int hist[kMapMaxParts];
     __shared__ unsigned long long start[kMapMaxParts];
-    for (long long t0 = blockIdx.x * 256ll; t0 < capacity; t0 += (long long)gridDim.x * 256) {
+    constexpr int IT = 8;
+    for (long long t0 = blockIdx.x * (256ll * IT); t0 < capacity; t0 += (long long)gridDim.x * (256 * IT)) {
         if (threadIdx.x < kMapMaxParts) hist[threadIdx.x] = 0;
         __syncthreads();
-        const long long t = t0 + threadIdx.x;
-        MapRec r;
-        r.key = kEmpty;
-        if (t < capacity) r = table[t];
-        int part = -1, rank = 0;
-        if (r.key != kEmpty) {
-            part = map_part(r.key, n_parts);
-            rank = atomicAdd(&hist[part], 1);
+        MapRec r[IT];
+        int part[IT], rank[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const long long t = t0 + it * 256 + threadIdx.x;
+            r[it].key = kEmpty;
+            r[it].val = kEmpty;
+            if (t < capacity) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&table[t]);
+                r[it].key = v.x;
+                r[it].val = v.y;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            part[it] = -1;
+            rank[it] = 0;
+            if (r[it].key != kEmpty) {
+                part[it] = map_part(r[it].key, n_parts);
+                rank[it] = atomicAdd(&hist[part[it]], 1);
+            }
         }
         __syncthreads();
         if (threadIdx.x < n_parts && hist[threadIdx.x]) start[threadIdx.x] = atomicAdd(&part_cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
-        if (part >= 0) {
-            const long long o = (long long)start[part] + rank;
-            if (o < cap_out) out[o] = r;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (part[it] < 0) continue;
+            const long long o = (long long)start[part[it]] + rank[it];
+            if (o < cap_out) *reinterpret_cast<ulonglong2*>(&out[o]) = make_ulonglong2(r[it].key, r[it].val);
         }
         __syncthreads();
     }
@@ -331,26 +370,42 @@ __global__ __launch_bounds__(256) void k_map_scatter_parts_padded(const MapRec* 
                                                                   unsigned long long* counters) {
     __shared__ int hist[kMapMaxParts];
     __shared__ unsigned long long start[kMapMaxParts];
+    constexpr int IT = 8;  // slots per thread and round: eight 16-byte loads in flight, one reservation per part and 2048 slots
     int dropped = 0;
-    for (long long t0 = blockIdx.x * 256ll; t0 < capacity; t0 += (long long)gridDim.x * 256) {
+    for (long long t0 = blockIdx.x * (256ll * IT); t0 < capacity; t0 += (long long)gridDim.x * (256 * IT)) {
         if (threadIdx.x < kMapMaxParts) hist[threadIdx.x] = 0;
         __syncthreads();
-        const long long t = t0 + threadIdx.x;
-        MapRec r;
-        r.key = kEmpty;
-        if (t < capacity) r = table[t];
-        int part = -1, rank = 0;
-        if (r.key != kEmpty) {
-            part = map_part(r.key, n_parts);
-            rank = atomicAdd(&hist[part], 1);
+        MapRec r[IT];
+        int part[IT], rank[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const long long t = t0 + it * 256 + threadIdx.x;
+            r[it].key = kEmpty;
+            r[it].val = kEmpty;
+            if (t < capacity) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&table[t]);
+                r[it].key = v.x;
+                r[it].val = v.y;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            part[it] = -1;
+            rank[it] = 0;
+            if (r[it].key != kEmpty) {
+                part[it] = map_part(r[it].key, n_parts);
+                rank[it] = atomicAdd(&hist[part[it]], 1);
+            }
         }
         __syncthreads();
         if (threadIdx.x < n_parts && hist[threadIdx.x]) start[threadIdx.x] = atomicAdd(&part_cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
-        if (part >= 0) {
-            const long long o = (long long)start[part] + rank;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (part[it] < 0) continue;
+            const long long o = (long long)start[part[it]] + rank[it];
             if (o < cap_part)
-                out[(long long)part * cap_part + o] = r;
+                *reinterpret_cast<ulonglong2*>(&out[(long long)part[it] * cap_part + o]) = make_ulonglong2(r[it].key, r[it].val);
             else
                 ++dropped;
         }
