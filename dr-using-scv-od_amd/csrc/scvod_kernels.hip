@@ -1987,6 +1987,8 @@ constexpr int kCcThreads = 1024;
 constexpr int kCcBoxes = 2048;   // bounding boxes per scan held in LDS (7 words each, in the key table once the search is over)
 constexpr int kCcBuckets = 8192; // entries of the key-bucket index (uint16 node numbers; the generic variant: kCcNodes 32-bit entries)
 constexpr int kCcExactMaxNodes = 4096;  // generic variant: nodes in components with irregular runs that are re-clustered exactly
+constexpr int kCcBad = 256;          // generic variant: apri points outside the grid that are listed (more: every slot / node is looked at)
+constexpr int kCcBadVoxel = 4096;    // ... and the largest voxel whose slots one thread walks for them
 constexpr int kCcSlotsBig = 262144;  // generic variant: the nodes live in HBM, which leaves LDS for the bit arrays of this many points
 
 static_assert(7 * kCcBoxes <= kCcNodes, "box records must fit the released key table");
@@ -2383,10 +2385,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // variant picks LDS or arena scratch per table at run time.
 extern __shared__ int cc_smem[];
 template <bool FAST>
-__device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A, int from_apri, int* wsum, int* wlast, int& n_extra_s, int s, int base,
-                                             int n, int nv) {
+__device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A, int from_apri, int* wsum, int* wlast, int& n_extra_s, int* bad_s, int s,
+                                             int base, int n, int nv) {
     PROF_BEGIN();
     const int tid = threadIdx.x;
+    if (!FAST) {  // bad_s: [kCcBad] listed points (then their voxels), [kCcBad] = how many there are
+        if (tid == 0) bad_s[kCcBad] = 0;
+        __syncthreads();
+    }
     const int32_t* vbeg = A.vox_pt_begin + base + s;
     const int32_t* vpts = A.vox_pts + base;
     const int32_t* idx3 = A.apri_idx3 + base;
@@ -2408,11 +2414,21 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         for (int u = 0; u < 4; ++u) {
             const int t = tv[u];
             const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
-            bad |= ri < 0 || ri >= R || si < 0 || si >= S || ai < 0 || ai >= Az;
-            if (from_apri) bad |= kv[u] != ri * S + si + ai * R * S;
+            bool b = ri < 0 || ri >= R || si < 0 || si >= S || ai < 0 || ai >= Az;
+            if (from_apri) b |= kv[u] != ri * S + si + ai * R * S;
+            bad |= b;
+            // the generic variant lists the offenders (a handful of returns at polar angle exactly 0 per 128-beam scan): only
+            // their voxels can hold a second run or be irregular, so two passes over every slot / node shrink to these voxels
+            const int i = i0 + u * kCcThreads + tid;
+            if (!FAST && b && i < n) {
+                const int x = atomicAdd(&bad_s[kCcBad], 1);
+                if (x < kCcBad) bad_s[x] = i;
+            }
         }
     }
     const bool allreg = !__syncthreads_or(bad ? 1 : 0);
+    const int n_bad = FAST ? 0 : bad_s[kCcBad];
+    bool sparse = !FAST && !allreg && span > 0 && span < 0x7fffffffLL && n_bad <= kCcBad;
     const int nw = (n + 31) >> 5;             // words of the per-slot bit arrays
     // storage.  FAST: everything in LDS -- [keys N][parents N][vstart][rstart][prefix][touched][found][bucket index][regular].
     // Generic: nodes (keys, parents, touched / found) in HBM, LDS = [bucket index, 32-bit][vstart][rstart][prefix] for up to
@@ -2439,7 +2455,32 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
     CC_MARK(0);
     // runs inside a voxel: a slot whose triple differs from the previous slot's opens one (ssc.cpp:306-330 walks the
     // voxel's points with their own triples; equal triples have equal neighbourhoods)
-    if (!allreg) {
+    if (sparse) {
+        const int* vkey = A.vox_key + base;
+        bool fail = false;
+        for (int x = tid; x < n_bad; x += kCcThreads) {
+            const int i = bad_s[x];
+            const int key = A.apri_key[(size_t)base + i];
+            const int v = cc_lower_bound(vkey, nv, key);
+            if (v >= nv || vkey[v] != key || vbeg[v + 1] - vbeg[v] > kCcBadVoxel) {
+                fail = true;
+                continue;
+            }
+            bad_s[x] = v;  // (from here on: the voxel)
+            int t_prev = idx3[vpts[vbeg[v]]];
+            for (int k = vbeg[v] + 1; k < vbeg[v + 1]; ++k) {
+                const int t = idx3[vpts[k]];
+                if (t != t_prev && !((atomicOr(&rstart[k >> 5], 1 << (k & 31)) >> (k & 31)) & 1)) {  // (two listed points of one voxel)
+                    const int e = atomicAdd(&n_extra_s, 1);
+                    extras[e] = k;
+                    extra_of_slot[k] = e;
+                }
+                t_prev = t;
+            }
+        }
+        if (__syncthreads_or(fail ? 1 : 0)) sparse = false;  // (what was found stays: the pass below skips the slots that are marked)
+    }
+    if (!allreg && !sparse) {
         for (int k0 = 0; k0 < n; k0 += kCcThreads * 4) {
             int pa[4], pb[4], ta[4], tb[4];
 #pragma unroll
@@ -2457,11 +2498,10 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + u * kCcThreads + tid;
                 if (k >= n || cc_bit(vstart, k)) continue;
-                if (ta[u] != tb[u]) {
+                if (ta[u] != tb[u] && !((atomicOr(&rstart[k >> 5], 1 << (k & 31)) >> (k & 31)) & 1)) {
                     const int e = atomicAdd(&n_extra_s, 1);
                     extras[e] = k;
                     extra_of_slot[k] = e;
-                    cc_set(rstart, k);
                 }
             }
         }
@@ -2770,7 +2810,33 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         int* triple = (int*)(A.tk_pairs + base);  // [nn] opener triples (arena scratch, free until the naming pass)
         const int nwords = (nn + 31) >> 5;
         constexpr int kG = FAST ? 4 : 8;
-        for (int j0 = 0; j0 < nn; j0 += kCcThreads * kG) {  // the three dependent gathers of kG nodes per thread in flight together
+        if (sparse) {
+            // every voxel is regular except the listed ones whose OPENER is outside the grid (or does not encode to the key);
+            // only irregular nodes need their triple (a regular one's is its key's decomposition: triple_of)
+            for (int w = tid; w < nwords; w += kCcThreads) {
+                const int c = min(max(nv - (w << 5), 0), 32);
+                const int word = c >= 32 ? -1 : (int)((1u << c) - 1u);
+                regular[w] = word;
+                touched[w] = word;  // a regular voxel finds itself
+                found[w] = word;
+            }
+            __syncthreads();
+            for (int x = tid; x < n_bad; x += kCcThreads) {
+                const int v = bad_s[x];
+                const int t = idx3[vpts[vbeg[v]]];
+                const int ri = (t & 2047) - 2, si = ((t >> 11) & 2047) - 2, ai = ((t >> 22) & 1023) - 2;
+                const bool reg = ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == K.k[v]);
+                if (!reg) {
+                    const int m = ~(1 << (v & 31));
+                    atomicAnd(&regular[v >> 5], m);
+                    atomicAnd(&touched[v >> 5], m);
+                    atomicAnd(&found[v >> 5], m);
+                    triple[v] = t;
+                }
+            }
+            for (int e = tid; e < n_extra; e += kCcThreads) triple[nv + e] = idx3[vpts[extras[e]]];
+        }
+        for (int j0 = 0; j0 < nn && !sparse; j0 += kCcThreads * kG) {  // the three dependent gathers of kG nodes per thread in flight together
             int tc[kG];
 #pragma unroll
             for (int u = 0; u < kG; ++u) {
@@ -2858,14 +2924,13 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
                 if (__any(hit) && lane == 0) cc_set(found, j);
             }
         }
-        int t_next = triple[min(tid, nn - 1)];
         for (int j = tid; j < nn && !windowed; j += kCcThreads) {
-            const int t = t_next;
-            t_next = triple[min(j + kCcThreads, nn - 1)];
             if (cc_bit(regular, j)) {
-                if (!windowed)
-                    cc_search_half(K, parent, heads, j, (t & 2047) - 2, ((t >> 11) & 2047) - 2, ((t >> 22) & 1023) - 2, R, S, Az);
+                const int RS = R * S, key = K.k[j];  // (a regular node's triple is its key's decomposition)
+                const int ai = key / RS, rem = key - ai * RS;
+                cc_search_half(K, parent, heads, j, rem / S, rem % S, ai, R, S, Az);
             } else {
+                const int t = triple[j];
                 if (cc_search(K, parent, touched, j, t, R, S, Az)) cc_set(found, j);
                 if (j < nv) {
                     const int key = K.k[j];
@@ -2890,7 +2955,13 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         // component; a voxel's labelling time depends on its finders only): those components are clustered again, exactly,
         // with the times / first points / next times of their voxels in arena scratch.
         int* regular = A.pt_cluster + base;
-        const int* triple = (const int*)(A.tk_pairs + base);  // [nn] opener triples (written by the search above)
+        const int* triple = (const int*)(A.tk_pairs + base);  // [nn] opener triples (written by the search above: the irregular nodes' at least)
+        auto triple_of = [&](int j) -> int32_t {
+            if (j >= nv || !cc_bit(regular, j)) return triple[j];
+            const int RS = R * S, key = K.k[j];
+            const int ai = key / RS, rem = key - ai * RS;
+            return (int32_t)((rem / S + 2) | ((rem % S + 2) << 11) | ((ai + 2) << 22));
+        };
         int* aff = A.tk_members + base;                       // [nn] root flag: the component holds an irregular run
         int* La = A.tk_clusters + base;                       // [na] the nodes of those components
         int* Tg = A.cl_count + base;                          // [nv] labelling times (run heads are used up)
@@ -2950,7 +3021,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
                 unsigned m = (w < nw) ? ((unsigned)rstart[w] & ~((1u << ((r.o + 1) & 31)) - 1u)) : 0u;
                 while (!m && ++w < nw) m = (unsigned)rstart[w];
                 r.len = (m ? min((w << 5) + __ffs((int)m) - 1, n) : n) - r.o;
-                r.t = triple[j];
+                r.t = triple_of(j);
                 const int ri = (r.t & 2047) - 2, si = ((r.t >> 11) & 2047) - 2, ai = ((r.t >> 22) & 1023) - 2;
                 r.regular = ri >= 0 && ri < R && si >= 0 && si < S && ai >= 0 && ai < Az && (ri * S + si + ai * R * S == K.k[r.v]);
                 return r;
@@ -3082,7 +3153,7 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
                     const int j = La[x];
                     const int q = qnode[x];
                     int jj = 0;
-                    walk(x, triple[j], [&](int u) -> bool {
+                    walk(x, triple_of(j), [&](int u) -> bool {
                         if (jj >= q) {
                             cc_set(touched, u);
                             if (u != j) cc_union(parent, j, u);
@@ -3463,6 +3534,7 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
     __shared__ int wsum[17];
     __shared__ int wlast[kCcThreads / 64];
     __shared__ int n_extra_s;
+    __shared__ int bad_s[kCcBad + 1];
     const int s = A.cc_perm[blockIdx.x];
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
@@ -3472,10 +3544,10 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         return;
     }
     if (n <= kCcSlots && nv <= kCcNodes && (long long)P.bin.range_num * P.bin.sector_num * P.bin.azimuth_num < 0x7fffffffLL) {
-        if (cc_scan_impl<true>(P, A, from_apri, wsum, wlast, n_extra_s, s, base, n, nv)) return;
+        if (cc_scan_impl<true>(P, A, from_apri, wsum, wlast, n_extra_s, bad_s, s, base, n, nv)) return;
         __syncthreads();
     }
-    cc_scan_impl<false>(P, A, from_apri, wsum, wlast, n_extra_s, s, base, n, nv);
+    cc_scan_impl<false>(P, A, from_apri, wsum, wlast, n_extra_s, bad_s, s, base, n, nv);
 }
 
 // ------------------------------------------------------------------------------------------
