@@ -879,6 +879,31 @@ def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
     ctx.close()
 
 
+def test_cluster_partition_with_a_listed_point_in_a_crowded_voxel(scvod, oracle):
+    """the generic variant lists the few out-of-grid points of a scan and walks only THEIR voxels for second runs; a listed point
+    that aliases into a voxel of more than 4096 points (a return at polar angle 0 next to a dense blob in the last sector of the
+    range bin before it) makes the kernel give that short cut up half way and look at every slot / node instead: same partition"""
+    import synth
+    P = _params(scvod, "os128_fine")
+    x = synth.make_scan(5, 3, "OS128")[0].numpy()
+    rng = np.random.default_rng(5)
+    k, m = 40, 6000
+    r_blob, r_bad = P.min_dis + (k - 0.5) * P.range_res, P.min_dis + (k + 0.5) * P.range_res
+    rb, tb = r_blob + rng.uniform(-0.03, 0.03, m), np.deg2rad(359.8) + rng.uniform(-0.001, 0.001, m)
+    blob = np.stack([rb * np.cos(tb), rb * np.sin(tb), 0.3 + rng.uniform(-0.01, 0.01, m), np.full(m, 0.5)], 1)
+    bad = np.array([[r_bad, 0.0, 0.3 * r_bad / r_blob, 0.5]])
+    apri = oracle.bin(P, np.concatenate([x, blob, bad]).astype(np.float32), True)["apri"]
+    listed = apri["sector_idx"] < 0
+    assert 0 < listed.sum() <= 256
+    assert max((apri["voxel_idx"] == v).sum() for v in np.unique(apri["voxel_idx"][listed])) > 4096
+    ctx = scvod.Ctx(P, max_points_total=len(apri) + 64, max_scans=1)
+    got = ctx.cluster(apri)
+    ref, n_ref, _ = oracle.cluster(P, apri)
+    assert np.array_equal(got, _canonical(ref))
+    assert len(np.unique(got)) == n_ref
+    ctx.close()
+
+
 @pytest.mark.parametrize("irregular", [0, 60])
 def test_cluster_partition_on_a_grid_of_two_large_planes(scvod, oracle, irregular):
     """the generic variant joins its regular nodes window by window in LDS, a window being whole z-planes; a grid whose planes
