@@ -3812,6 +3812,7 @@ constexpr int kLGEv = 3, kTSv = 2;             // voxel-bucket sorts measured fa
 constexpr int kPersistCUs = 256;  // MI355X: 256 CUs; list-driven kernels launch a few workgroups per CU
 constexpr int kSortCapS = 1024, kSortThreadsS = 64;
 constexpr int kSortCapL = 8192, kSortThreadsL = 512;
+constexpr int kSortCapXL = 16384, kClassXL = 52;  // n >= 8192 (pw_size_class)
 constexpr size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8; }
 constexpr int kVoxCapS = 1024, kVoxThreadsS = 64;
 constexpr int kVoxCapL = 8192, kVoxThreadsL = 512;
@@ -3842,11 +3843,17 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_order_offsets, dim3(1), dim3(64), 0, st, A);
         hipLaunchKernelGGL(k_pw_order_scatter, dim3((n_all + 255) / 256), dim3(256), 0, st, P, A);
         TH_END("pw_order");
-        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, 63, kLGE>,
+        // patches of more than 8192 points (the rings next to a 128-beam sensor: up to 11 k points, a few per scan) have their own
+        // tier -- 16 384 keys in 144 KB of LDS, one workgroup per CU -- instead of the in-place sort in global memory that
+        // remains for anything larger still
+        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapXL, 1024, kClassXL, 63, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sort_lds_bytes(kSortCapXL));
+        hipFuncSetAttribute((const void*)k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, kClassXL - 1, kLGE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes(kSortCapL));
         TH_BEGIN("pw_sort_8192");  // one timing label per kernel; largest first: their tail overlaps the smaller tiers' launches
-        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, 63, kLGE>), dim3(kPersistCUs * 2), dim3(kSortThreadsL * kTS),
-                           sort_lds_bytes(kSortCapL), st, P, A);
+        hipLaunchKernelGGL((k_pw_sort<kSortCapXL, 1024, kClassXL, 63, 4>), dim3(kPersistCUs), dim3(1024), sort_lds_bytes(kSortCapXL), st, P, A);
+        hipLaunchKernelGGL((k_pw_sort<kSortCapL, kSortThreadsL * kTS, kClassL, kClassXL - 1, kLGE>), dim3(kPersistCUs * 2),
+                           dim3(kSortThreadsL * kTS), sort_lds_bytes(kSortCapL), st, P, A);
         TH_END("pw_sort_8192");
         TH_BEGIN("pw_sort_4096");
         hipLaunchKernelGGL((k_pw_sort<4096, 256 * kTS, kClassM2, kClassL - 1, kLGE>), dim3(kPersistCUs * 4), dim3(256 * kTS),

@@ -146,14 +146,14 @@ def test_edge_cases(scvod, oracle):
 
 def test_patch_sizes_at_every_tier_boundary(scvod, oracle):
     """one patch of exactly n points for every n next to a size-class boundary of the sort tiers (64 / 256 / 1024 / 2048 /
-    4096 / 8192), of the two plane-fit kernels (512, and 64 for small batches) and of num_min_pts (10): once as a batch
+    4096 / 8192 / 16 384), of the two plane-fit kernels (512, and 64 for small batches) and of num_min_pts (10): once as a batch
     (sequence configuration, 16 lanes per large patch) and once scan by scan (latency configuration, 64 lanes), with z
     ties and duplicated points"""
     import torch
     rng = np.random.default_rng(21)
     P = _params(scvod, "semantickitti")
     sizes = [9, 10, 11, 12, 63, 64, 65, 127, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096,
-             4097, 8191, 8192, 8193]
+             4097, 8191, 8192, 8193, 11000, 16383, 16384, 16385]  # (above 16 384: the in-place sort in global memory)
     scans = []
     for n in sizes:
         ang = rng.uniform(0.02, 0.37, n)
