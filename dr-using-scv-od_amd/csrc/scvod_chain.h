@@ -35,6 +35,27 @@ struct ChainJob {
     int32_t force_generic;  // testing: every step through the HBM-resident generic path
 };
 
+#ifdef __HIPCC__
+// Successor-table look-up behind the sampled keys (k_tk_probe, the chain's carried points): the slot among the records
+// [a0, a1) whose key is `key` and whose label is set, -1 otherwise (ssc.cpp:1304-1305).  `first` = tab[a0], already loaded.
+// A table sampled every record (a1 = a0 + 1: any 64-beam scan) is decided by `first`; a larger one (2^k records behind a
+// sample: 16 for the 72 k voxels of a 128-beam scan) is bisected -- k dependent reads instead of 2^(k-1) on average.
+__device__ __forceinline__ int tk_find_slot(const int4* __restrict__ tab, int a0, int a1, int4 first, int key) {
+    if (first.x >= key) return (first.x == key && first.y != -1) ? a0 : -1;
+    int l = a0 + 1, h = a1;  // first record behind a0 whose key is >= key
+    while (l < h) {
+        const int mid = (l + h) >> 1;
+        if (tab[mid].x < key)
+            l = mid + 1;
+        else
+            h = mid;
+    }
+    if (l >= a1) return -1;
+    const int4 rec = tab[l];
+    return (rec.x == key && rec.y != -1) ? l : -1;
+}
+#endif
+
 void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st,
                         TimerHook th, void* tu);
 

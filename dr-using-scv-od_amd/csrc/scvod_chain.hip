@@ -321,17 +321,8 @@ __device__ __forceinline__ void carried_probe(const DevParams& P, const Wk& K, f
             if (c >= ncarried) continue;
             int slot = -1;
             if (lo[u] > 0) {
-                int a0 = (lo[u] - 1) << shift;
-                const int a1 = min(a0 + (1 << shift), nv);
-                int4 rec = first[u];
-                for (;;) {
-                    if (rec.x >= key[u]) {
-                        if (rec.x == key[u] && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
-                        break;
-                    }
-                    if (++a0 >= a1) break;
-                    rec = tab[a0];
-                }
+                const int a0 = (lo[u] - 1) << shift;
+                slot = tk_find_slot(tab, a0, min(a0 + (1 << shift), nv), first[u], key[u]);
             }
             pool[c] = q[u];
             K.chit[c] = slot;

@@ -166,17 +166,8 @@ __global__ __launch_bounds__(256) void k_tk_probe(DevParams P, Arena A, TrackBat
             if (k >= n_car) continue;
             int slot = -1;
             if (lo[u] > 0) {
-                int a0 = (lo[u] - 1) << shift;
-                const int a1 = min(a0 + (1 << shift), N.nv);
-                int4 rec = first[u];
-                for (;;) {
-                    if (rec.x >= key[u]) {
-                        if (rec.x == key[u] && rec.y != -1) slot = a0;  // found and labelled (ssc.cpp:1304-1305)
-                        break;
-                    }
-                    if (++a0 >= a1) break;
-                    rec = N.tab[a0];
-                }
+                const int a0 = (lo[u] - 1) << shift;
+                slot = tk_find_slot(N.tab, a0, min(a0 + (1 << shift), N.nv), first[u], key[u]);
             }
             A.tk_hit[(size_t)base + k] = slot;
         }

@@ -1,11 +1,12 @@
 import sys, os
 sys.path.insert(0,'dr-using-scv-od_amd/pyshim')
 import numpy as np, torch, scvod_py, synth
-P=scvod_py.make_params("semantickitti")
+kind=sys.argv[2] if len(sys.argv)>2 else "K64"; preset=sys.argv[3] if len(sys.argv)>3 else "semantickitti"
+P=scvod_py.make_params(preset)
 n=int(sys.argv[1]) if len(sys.argv)>1 else 600; skip=5
 parts=[];offs=[0];poses=[]
 for i in range(n):
-    p,l,pose=synth.make_scan(5,i,"K64",device="cuda"); parts.append(p); offs.append(offs[-1]+p.shape[0]); poses.append(pose)
+    p,l,pose=synth.make_scan(5,i,kind,device="cuda"); parts.append(p); offs.append(offs[-1]+p.shape[0]); poses.append(pose)
 pts=torch.cat(parts).contiguous(); offs=np.asarray(offs,np.int32)
 ctx=scvod_py.Ctx(P,max_points_total=int(offs[-1])+64,max_scans=n)
 nxt=np.array([s+skip if s+skip<n else -1 for s in range(n)],np.int32)
