@@ -363,12 +363,13 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     const size_t per_wave = (size_t)words * 4;
     TH_BEGIN("tk_decide");
     hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * small_words * 4, st, A, J, small_words, -1);
-    // (a 128-beam scan on a fine grid: 70 k voxels in a batch sized for 260 k points) tables of up to 131 072 voxels: 16 KB per wave
-    const int mid_words = 4096;
+    // (a 128-beam scan on a fine grid: 70 k voxels in a batch sized for 260 k points) tables of up to 81 920 voxels: 10 KB per wave,
+    // four workgroups per CU; up to 131 072 voxels: 16 KB per wave, two workgroups per CU
     int done_words = small_words;
-    if (words > mid_words) {
+    for (const int mid_words : {2560, 4096}) {
+        if (words <= mid_words) break;
         hipFuncSetAttribute((const void*)k_tk_decide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * mid_words * 4);
-        hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * mid_words * 4, st, A, J, mid_words, small_words);
+        hipLaunchKernelGGL(k_tk_decide<4>, dim3(8, B), dim3(256), 4 * mid_words * 4, st, A, J, mid_words, done_words);
         done_words = mid_words;
     }
     if (words > small_words) {
