@@ -1978,8 +1978,10 @@ __global__ __launch_bounds__(256) void k_vx_final(DevParams P, Arena A) {
 // its voxel -- only possible when different triples alias onto one voxel_idx, i.e. next to the -1 bins -- is an extra
 // node.  Per scan: ~10 k voxels x 9 binary searches (the three sector neighbours of one (range, azimuth) pair are
 // adjacent keys) + lock-free unions, all on a 64 KB key table and a 64 KB parent array in LDS; the canonical cluster name
-// is the smallest apri index of the component.  Scans with more than kCcNodes voxels or kCcSlots points run the same
-// code on arena scratch in HBM.
+// is the smallest apri index of the component.  Scans with more than kCcNodes voxels or kCcSlots points (128-beam scans on a
+// fine grid) run the generic variant: nodes (keys, parents, bits) on arena scratch in HBM; its search still runs in LDS, one
+// window of whole z-planes of the node list at a time (cc_search_windows), the few out-of-grid points of such a scan are
+// listed by the regularity pass so that run detection and the regular bits look at their voxels only.
 // ------------------------------------------------------------------------------------------
 constexpr int kCcNodes = 14336;  // voxels + extra run openers per scan held in LDS
 constexpr int kCcSlots = 65536;  // apri points per scan whose run / voxel start bits are held in LDS
