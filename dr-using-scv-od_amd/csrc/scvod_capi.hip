@@ -689,26 +689,37 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
     fw.assign(1, 0);
     walkers.clear();
     std::vector<char> seen(B, 0);
-    // segment length: given, or such that the job has about as many segments as the device has CUs (a walker fills one)
-    int seg = c->chain_seg;
-    if (seg <= 0) {
-        long long steps_total = 0;
-        for (int s = 0; s < B; ++s) steps_total += next[s] >= 0 ? 1 : 0;
-        seg = (int)((steps_total + 249) / 250);
-        if (seg < 4) seg = 4;
-    }
-    c->chain_seg_used = seg;
-    const int warm = c->chain_warm > 0 ? c->chain_warm : 0;
-    int n_chains = 0;
+    // the chains: frames in order
+    std::vector<int> chain_first, chain_len;
     for (int h = 0; h < B; ++h) {
         if (pred[h] != -1 || next[h] < 0) continue;  // not a head, or a head without a successor in the batch
-        const int first = (int)scans.size();
+        chain_first.push_back((int)scans.size());
         int n = 0;
         for (int s = h; s >= 0 && !seen[s]; s = next[s] >= 0 ? next[s] : -1) {
             seen[s] = 1;
             scans.push_back(s);
             ++n;
         }
+        chain_len.push_back(n);
+    }
+    // segment length: given, or the SHORTEST whose segments still fit the device one per CU (a walker fills a CU; every walker
+    // pays the warm-up, so more segments than CUs would run in two rounds) -- 11 steps = 255 walkers for seq 05 with skip_ 5
+    int seg = c->chain_seg;
+    if (seg <= 0) {
+        const int n_cu = 256;  // MI355X
+        int longest = 0;
+        for (int n : chain_len) longest = n - 1 > longest ? n - 1 : longest;
+        for (seg = 4; seg < longest; ++seg) {  // (more chains than CUs: one segment per chain)
+            long long nseg = 0;
+            for (int n : chain_len) nseg += (n - 1 + seg - 1) / seg;
+            if (nseg <= n_cu) break;
+        }
+    }
+    c->chain_seg_used = seg;
+    const int warm = c->chain_warm > 0 ? c->chain_warm : 0;
+    int n_chains = 0;
+    for (size_t ci = 0; ci < chain_len.size(); ++ci) {
+        const int first = chain_first[ci], n = chain_len[ci];
         const int steps = n - 1;
         for (int a = 0; a < steps; a += seg) {
             const int b = a + seg < steps ? a + seg : steps;

@@ -282,7 +282,7 @@ int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_sc
  *                            segments of `segment_steps` steps walked concurrently, each warmed up `warmup_steps` steps
  *                            earlier; a segment whose warm-up did not reproduce the state its predecessor really ended
  *                            in is walked again from that state, so the result never depends on the two lengths
- *                            (segment_steps 0 = chosen per job so that it has about 250 segments, the default;
+ *                            (segment_steps 0 = the shortest segment whose walkers still fit the device one per CU (<= 256), the default;
  *                            warmup_steps -1 = keep, default 12).  A scan tracked against an EXTERNAL table ends its
  *                            chain: across shard boundaries the decision is first-order -- keep a sequence on one shard.
  *   SCVOD_TRACK_FIRST_ORDER  every cluster against its successor's fresh segmentation (all pairs independent).
