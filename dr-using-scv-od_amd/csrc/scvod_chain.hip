@@ -84,7 +84,7 @@ __device__ __forceinline__ Wk wk_of(const ChainWs& S, int w) {
 }
 
 // header words of a walker
-enum { H_EPOCH = 0, H_END_SLOT = 1, H_HAS_SNAP = 2, H_SNAP_OK = 3, H_NENT = 4 /* [3] */, H_NCARRIED = 8 /* [3] */, H_NPARTS = 12 /* [3] */ };
+enum { H_EPOCH = 0, H_END_SLOT = 1, H_HAS_SNAP = 2, H_SNAP_OK = 3, H_NENT = 4 /* [3] */, H_SPEC = 7, H_NCARRIED = 8 /* [3] */, H_NPARTS = 12 /* [3] */ };
 
 __device__ __forceinline__ int wmin_i(int v) {
 #pragma unroll
@@ -1210,7 +1210,33 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_cmp(ChainJob C) {
         const Wk Kp = wk_of(C.ws, w - 1);
         ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, Kp.hdr[H_END_SLOT], K, 2);
     }
-    if (threadIdx.x == 0) K.hdr[H_SNAP_OK] = ok;
+    if (threadIdx.x == 0) {
+        K.hdr[H_SNAP_OK] = ok;
+        K.hdr[H_SPEC] = 0;
+    }
+}
+
+// verification, part 1b: failed segments are usually isolated, and a segment whose PREDECESSOR passed its check can be walked
+// again at once -- all of them concurrently, one workgroup each -- from the state that predecessor ended in: that state is the
+// true one unless a segment further up the chain fails and its new end state cascades down to it, which part 2 notices (it
+// compares again whenever a predecessor's end state changed) and then walks the segment once more.
+__global__ __launch_bounds__(kChThreads) void k_tk_chain_spec(DevParams P, Arena A, TrackBatch J, ChainJob C, int from_apri) {
+    __shared__ Shared sh;
+    extern __shared__ uint32_t ch_bits[];
+    const int w = blockIdx.x;
+    const ChainWalker W = C.walkers[w];
+    if (W.a == 0) return;  // the first segment of a chain
+    const Wk K = wk_of(C.ws, w), Kp = wk_of(C.ws, w - 1);
+    if (K.hdr[H_SNAP_OK] != 0 || Kp.hdr[H_SNAP_OK] == 0) return;  // passed / the predecessor is being walked again itself
+    for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
+    copy_state(Kp, Kp.hdr[H_END_SLOT], K, 0);
+    const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.a, W.b, W.a, -1, from_apri);
+    if (threadIdx.x == 0) {
+        K.hdr[H_END_SLOT] = end;
+        K.hdr[H_SPEC] = 1;
+    }
 }
 
 // verification, part 2: one workgroup per chain; a segment whose warm-up did not reproduce the state its predecessor really
@@ -1250,20 +1276,24 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
         const ChainWalker W = C.walkers[w];
         const Wk K = wk_of(C.ws, w), Kp = wk_of(C.ws, w - 1);
         const int pend = Kp.hdr[H_END_SLOT];
+        const bool pred_changed = prev_rewalked;
         bool ok;
-        if (prev_rewalked)  // the predecessor's end state changed: compare again
+        if (pred_changed)  // the predecessor's end state changed: compare again
             ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, pend, K, 2);
         else
             ok = K.hdr[H_SNAP_OK] != 0;
-        prev_rewalked = !ok;
+        prev_rewalked = !ok;  // (either way this segment's end state is not the one its successor was compared with)
         if (ok) {
             ++w;
             continue;
         }
-        if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
-        copy_state(Kp, pend, K, 0);
-        const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.a, W.b, W.a, -1, from_apri);
-        if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
+        // already walked again by k_tk_chain_spec from the state its predecessor still ends in: that walk stands
+        if (!(K.hdr[H_SPEC] != 0 && !pred_changed)) {
+            if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
+            copy_state(Kp, pend, K, 0);
+            const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.a, W.b, W.a, -1, from_apri);
+            if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
+        }
         __syncthreads();
         ++w;
     }
@@ -1275,11 +1305,13 @@ void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J,
     const size_t dyn = (size_t)C.n_eval_waves * C.words * 4;
     hipFuncSetAttribute((const void*)k_tk_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipFuncSetAttribute((const void*)k_tk_chain_fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipFuncSetAttribute((const void*)k_tk_chain_spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (th) th(tu, "tk_chain", 1);
     hipLaunchKernelGGL(k_tk_chain, dim3(C.n_walkers), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
     if (th) th(tu, "tk_chain", 0);
     if (th) th(tu, "tk_chain_fix", 1);
     hipLaunchKernelGGL(k_tk_chain_cmp, dim3(C.n_walkers), dim3(kChThreads), 0, st, C);
+    hipLaunchKernelGGL(k_tk_chain_spec, dim3(C.n_walkers), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
     hipLaunchKernelGGL(k_tk_chain_fix, dim3(C.n_chains), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
     if (th) th(tu, "tk_chain_fix", 0);
 }
