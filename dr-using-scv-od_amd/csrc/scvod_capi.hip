@@ -72,6 +72,8 @@ struct scvod_ctx {
     int chain_seg = 0, chain_warm = 12;      // steps per segment (0: from the job, ~250 segments), warm-up steps in front of it
     int chain_seg_used = 0;
     bool chain_generic = false;              // testing: every step through the generic (HBM-resident) step function
+    bool max_name_literal = true;            // ssc.cpp:354: a frame's first new cluster re-uses the last running number (scvod_lastname.hip)
+    bool last_name_valid = false;
     int32_t* d_chain_scans = nullptr;        // [cap_scans]
     ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
     int32_t* d_chain_fw = nullptr;           // [cap_scans + 1]
@@ -217,6 +219,9 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cl_bbox = k.take<uint32_t>(7 * N + 64);
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
+    A.cc_last = k.take<int32_t>(B * 4);
+    A.cc_redo = k.take<int32_t>(B + 1);
+    A.ln_stats = k.take<int32_t>(4);
     A.vg_par = k.take<int32_t>(B * 16);
     A.vg_range = k.take<int32_t>(2);  // [0] largest cell-index range of the batch, [1] bin shift of the bucket table
     A.vg_outoff = k.take<int32_t>(B + 1);
@@ -1065,6 +1070,11 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
         return fail(c, SCVOD_ERR_INVALID, "grid of %d x %d x %d bins is finer than the clustering's packed index triples hold (2040 x 2040 x 1016)",
                     c->dev.bin.range_num, c->dev.bin.sector_num, c->dev.bin.azimuth_num);
     launch_cluster(c->dev, c->A, c->batch_mode == 2 ? 1 : 0, st, timer_hook, c);
+    c->last_name_valid = false;
+    if (c->max_name_literal) {
+        launch_lastname(c->dev, c->A, st, timer_hook, c);
+        c->last_name_valid = true;
+    }
     HIPCHK(c, hipGetLastError());
     c->clusters_valid = true;
     c->types_valid = false;  // scvod_batch_cluster_types publishes them
@@ -1206,6 +1216,7 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             CJ.n_eval_waves = ev < 1 ? 1 : (ev > 16 ? 16 : ev);
             if ((size_t)CJ.words * 4 > lds_bits) return fail(c, SCVOD_ERR_CAPACITY, "scan too large for the chain's LDS bitset");
             CJ.force_generic = c->chain_generic ? 1 : 0;
+            CJ.literal_max_name = (c->max_name_literal && c->last_name_valid) ? 1 : 0;
             c->chain_ran = true;
         }
     }
@@ -1231,6 +1242,23 @@ int scvod_batch_cluster_stats(scvod_ctx* c, int32_t* h_out4) {
     HIPCHK(c, hipMemcpy(h_out4, c->A.cc_stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
     h_out4[2] = c->A.cc_exact_max > 4096 ? 1 : 0;
     return SCVOD_OK;
+}
+
+int scvod_set_max_name_literal(scvod_ctx* c, int32_t literal) {
+    if (!c) return SCVOD_ERR_INVALID;
+    c->max_name_literal = literal != 0;
+    c->clusters_valid = c->types_valid = c->tables_valid = c->track_valid = false;  // (the clustering publishes the name)
+    return SCVOD_OK;
+}
+
+int scvod_batch_cluster_last_name(scvod_ctx* c, int32_t* h_out4, int32_t cap_scans, int32_t* h_stats4) {
+    if (!c || !h_out4) return SCVOD_ERR_INVALID;
+    if (!c->clusters_valid || !c->last_name_valid) return fail(c, SCVOD_ERR_STATE, "no clustering with max_name tracking for the last batch");
+    if (cap_scans < c->A.n_scans) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d scans)", cap_scans, c->A.n_scans);
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    HIPCHK(c, hipMemcpy(h_out4, c->A.cc_last, sizeof(int32_t) * 4 * (size_t)c->A.n_scans, hipMemcpyDeviceToHost));
+    if (h_stats4) HIPCHK(c, hipMemcpy(h_stats4, c->A.ln_stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return c->A.n_scans;
 }
 
 int scvod_set_chain_capacity(scvod_ctx* c, int64_t pool_points) {

@@ -33,6 +33,7 @@ struct ChainJob {
     int32_t words;        // bitset words of an evaluating wave
     int32_t n_eval_waves;
     int32_t force_generic;  // testing: every step through the HBM-resident generic path
+    int32_t literal_max_name;  // 1: a frame's first new cluster re-uses Frame::max_name as ssc.cpp:354 stores it (Arena::cc_last)
 };
 
 #ifdef __HIPCC__

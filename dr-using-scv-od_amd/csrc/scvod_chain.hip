@@ -461,7 +461,18 @@ struct EntEval {        // what the walk needs of one cluster: remap_name agains
 };
 struct StepCounters {
     int n_dirty, nl, n_newlab, n_created, n_cparts;
+    int kid;  // label id of the successor's cluster that still carries Frame::max_name (ssc.cpp:354), -1: none, or handed out already
 };
+// `frame_ssc.max_name = cluster_name ++` (ssc.cpp:354) keeps the LAST USED running number K, so the first
+// `cluster_new.name = frame_next_.max_name ++` of a call (ssc.cpp:1357, :1401) is K again.  The label id of the cluster that
+// still carries K in the successor as refineClusterByBoundingBox left it (scvod_lastname.hip found which one it is), -1 when
+// no cluster does: then the number is as good as a fresh one.
+__device__ __forceinline__ int max_name_label(const Arena& A, const ChainJob& C, const StepEnv& E, int sj) {
+    if (!C.literal_max_name) return -1;
+    const int name = A.cc_last[(size_t)sj * 4], u = A.cc_last[(size_t)sj * 4 + 1];
+    if (name < 0 || u < 0 || u >= E.nv) return -1;
+    return E.tab[u].y == name ? E.rep[u] : -1;
+}
 
 // SSC::tracking's decision and re-labelling for ONE walked cluster against the successor as it is now (ssc.cpp:1323-1421);
 // one wave, every lane runs it with the same arguments.  Returns Cluster::state.  links / dsz_now: where an appended
@@ -520,7 +531,18 @@ __device__ __forceinline__ int commit_entry(const StepEnv& E, const TrackBatch& 
             } else {       // ssc.cpp:1351-1372: the hit voxels leave the label for a new cluster of the same type
                 state = 0;
                 const int Y = nv + S.n_newlab;
-                if (S.n_newlab < C.ws.cap_ent) {
+                const int Kd = S.kid;
+                S.kid = -1;
+                if (Kd >= 0) {
+                    // the split-off cluster is called K and K is alive: the hit voxels take K's label (ssc.cpp:1366), the source
+                    // loses them (reduceVec, :1364), `cluster_set.insert` (:1372) is a no-op -- cluster K keeps its own
+                    // occupy_voxels / type and now answers for these voxels too
+                    if (Kd != L)
+                        for (int j = lane; j < v.nu; j += 64)
+                            if (cur_label(E, v.uq[j]) == L) st64(&E.vlab[v.uq[j]], ((u64)E.epoch << 32) | (uint32_t)Kd);
+                    if (lane == 0) st64(&E.lcnt[L], ((u64)E.epoch << 32) | (uint32_t)(nvx - c) | ((uint32_t)typ << 28));
+                    ++S.n_dirty;
+                } else if (S.n_newlab < C.ws.cap_ent) {
                     for (int j = lane; j < v.nu; j += 64)
                         if (cur_label(E, v.uq[j]) == L) st64(&E.vlab[v.uq[j]], ((u64)E.epoch << 32) | (uint32_t)Y);
                     if (lane == 0) {
@@ -554,7 +576,37 @@ __device__ __forceinline__ int commit_entry(const StepEnv& E, const TrackBatch& 
         }
     } else {  // ssc.cpp:1396-1419: the car clusters hit at or above the ratio fuse into one new car cluster
         state = 0;
-        if (S.n_newlab < C.ws.cap_ent && S.n_created < C.ws.cap_ent) {
+        const int Kd = S.kid;
+        S.kid = -1;
+        bool lost = false;
+        if (Kd >= 0) {
+            // the fused cluster is called K.  If K itself is one of the clusters fused, `erase` (ssc.cpp:1411) frees the name
+            // before the insert and nothing differs from a fresh number; otherwise the voxels of the fused clusters take K's
+            // label (:1417), the clusters leave cluster_set (:1411) and the insert (:1419) is a no-op: the fused cluster is
+            // lost, nothing walks its points in the next call
+            bool k_fused = false;
+            for (int p = lane; p < v.np; p += 64) {
+                const int L = v.prid ? v.prid[p] : v.pr[p].x;
+                if (L != Kd) continue;
+                const uint32_t ct = cur_cnttype(E, L);
+                k_fused |= (int)(ct >> 28) == 2 && (float)v.pr[p].y / (float)(int)(ct & 0x0fffffffu) >= J.occupancy;
+            }
+            lost = !__any(k_fused);
+        }
+        if (lost) {
+            bool any = false;
+            for (int p = 0; p < v.np; ++p) {
+                const int L = v.prid ? v.prid[p] : v.pr[p].x;
+                const int c = v.pr[p].y;
+                const uint32_t ct = cur_cnttype(E, L);
+                const int nvx = (int)(ct & 0x0fffffffu), typ = (int)(ct >> 28);
+                if (typ != 2 || !((float)c / (float)nvx >= J.occupancy)) continue;
+                if (lane == 0) st64(&E.lfwd[L], ((u64)E.epoch << 32) | (uint32_t)Kd);
+                any = true;
+            }
+            if (any) ++S.n_dirty;
+            wave_sync();
+        } else if (S.n_newlab < C.ws.cap_ent && S.n_created < C.ws.cap_ent) {
             const int N = nv + S.n_newlab;
             const int q = S.n_created;
             const int cbeg = S.n_cparts;
@@ -609,6 +661,10 @@ __device__ __forceinline__ void chain_step_big(const DevParams& P, const Arena& 
     const int base_i = A.scan_off[si], base_j = A.scan_off[sj];
     const int nv = A.counts[sj * 8 + 6];
     const int ncar_j = min(A.tk_scan[sj * 4 + 0], C.ws.cap_ent);
+    if (write_out) {  // a car cluster the walk does not reach (its frame lost it: commit_entry, Frame::max_name) keeps Cluster::state -1
+        const int ncar_i = A.tk_scan[si * 4 + 0];
+        for (int o = tid; o < ncar_i; o += kChThreads) A.cl_state[(size_t)base_i + A.tk_clusters[(size_t)base_i + o]] = -1;
+    }
     const int4* tab = A.vox_track + base_j;
     const int nent = K.hdr[H_NENT + cur];
     const int ncarried = K.hdr[H_NCARRIED + cur];
@@ -665,7 +721,7 @@ __device__ __forceinline__ void chain_step_big(const DevParams& P, const Arena& 
 
     // ---- phase 3: the clusters in walking order, one wave: decision against the successor AS IT IS NOW, re-labelling ----
     if (wave == 0) {
-        StepCounters S = {0, 0, 0, 0, 0};
+        StepCounters S = {0, 0, 0, 0, 0, max_name_label(A, C, E, sj)};
         int ndc = 0, ndp = 0;
         const int32_t* car_j = A.tk_clusters + base_j;
         for (int k = 0; k < nent; ++k) {
@@ -845,6 +901,10 @@ __device__ __forceinline__ void chain_step_small(const DevParams& P, const Arena
     const int ncar_j = A.tk_scan[sj * 4 + 0];
     const int4* tab = A.vox_track + base_j;
     const int nent = K.hdr[H_NENT + cur];
+    if (write_out) {  // (see chain_step_big)
+        const int ncar_i = A.tk_scan[si * 4 + 0];
+        for (int o = tid; o < ncar_i; o += kChThreads) A.cl_state[(size_t)base_i + A.tk_clusters[(size_t)base_i + o]] = -1;
+    }
     const int ncarried = K.hdr[H_NCARRIED + cur];
     const int4* ent = K.ent[cur];
     const int32_t* parts = K.parts[cur];
@@ -949,7 +1009,7 @@ __device__ __forceinline__ void chain_step_small(const DevParams& P, const Arena
 
     // ---- D: the walk (one wave, LDS) and the successor's next state ----
     if (wave == 0) {
-        StepCounters S = {0, 0, 0, 0, 0};
+        StepCounters S = {0, 0, 0, 0, 0, max_name_label(A, C, E, sj)};
         int ndc = 0, ndp = 0;
         for (int k = 0; k < nent; ++k) {
             const int4 fr = M.fr[k], fx = M.fx[k];

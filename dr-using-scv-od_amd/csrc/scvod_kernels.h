@@ -122,6 +122,11 @@ struct Arena {
     uint32_t* cl_bbox;        // [7N] clustering scratch: bounding-box records of the scans that do not fit the LDS
     int32_t* cl_count;        // [N] per cluster root: number of points
     uint8_t* pt_type;         // [N] per apri point: 0 erased, 1 other, 2 car
+    // the cluster that still carries Frame::max_name as ssc.cpp:354 stores it (scvod_lastname.hip)
+    int32_t* cc_last;         // [B][4] {canonical name or -1, lowest voxel slot whose first point belongs to it or -1,
+                              //         status: 0 exact, 1 a replay did not fit the LDS, 2 too many index triples outside the grid, events replayed}
+    int32_t* cc_redo;         // [B + 1] scans handed to the second pass (larger tables), [B] = how many
+    int32_t* ln_stats;        // [4] per clustering call: scans with status 1, with status 2, 0, 0
     // sequence differencing on the device (scvod_batch_track, scvod_track.hip)
     int4* vox_track;          // [N] per voxel: {key, label = cluster root of its points or -1, |occupy_voxels| of that
                               //     cluster, its type}: the table the probe of the PREVIOUS scan runs against; also the
@@ -202,6 +207,7 @@ void launch_voxelgrid_lut(const Arena& A, hipStream_t st);
 void launch_voxelgrid_gather(const DevParams& P, const Arena& A, const VgJob& J, long long out_capacity, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu);
+void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
 struct ChainJob;

@@ -1,0 +1,1033 @@
+// scvod_lastname.hip -- which cluster of a scan still carries Frame::max_name? (gfx950, wave64)
+//
+// Reference: SSC::clusterAndCreateFrame ends with `frame_ssc.max_name = cluster_name ++;` (/root/reference/src/ssc.cpp:354):
+// max_name is the LAST USED running number K, not the next free one.  SSC::tracking hands it out again
+// (`cluster_new.name = frame_next_.max_name ++`, ssc.cpp:1357 and :1401): the first cluster a call splits off or fuses in
+// frame i + 1 is called K, and when a cluster K is still alive `cluster_set.insert` (ssc.cpp:1372, :1419) is a no-op -- the
+// voxels were already re-labelled K, the new cluster is lost.  The chain (scvod_chain.hip) reproduces that, and for it the
+// device has to know WHICH of its clusters (canonical names = smallest point index) the reference would call K.
+//
+// K is the number the last "opener" of the visiting loop created (ssc.cpp:303-350: a point that carries no label after it
+// looked at its neighbours opens a new cluster), and it survives only if no later mergeClusters(oc, nc) call (ssc.cpp:329,
+// :413-419: the VISITING point's cluster takes the NEIGHBOUR's name) renamed it.  Both depend on the visiting order, so the
+// loop has to be replayed -- but only where it matters:
+//   * the loop never looks across a connected component of "lists" (every listed voxel ends up in the lister's component), so
+//     each component can be replayed on its own, at voxel level: a voxel is unlabelled, labelled through its visited points,
+//     or FULLY labelled; only the first three visits from a voxel change anything (the state machine of
+//     k_cc_scan's exact path), points whose index triple lies outside the grid visit one by one with their own lists;
+//   * the last opener is at least as late as the birth (smallest point) of the latest-born component, L: that component is
+//     replayed (it is small: all of its points come after L), and of all other components only a voxel whose first point
+//     comes after the best opener found so far can still hold a later one.  Such a voxel is no opener when one of the voxels
+//     it lists holds a visited point, or CERTAINLY carries a label by then (a lister's third visit labels its whole list,
+//     the second everything from its own cell on, any visit everything behind a voxel that holds a visited point); the
+//     few candidates no certificate settles get their component replayed;
+//   * a replay lives in LDS (one thread walks the events in order, all threads build its tables); a component with more
+//     nodes than the LDS holds is not replayed: the scan reports "unknown" (counted, scvod_batch_cluster_stats), the chain
+//     then hands out a fresh number as if K had been merged away.
+// Validated against the oracle's literal loop (oracle_cluster_last_name) in tests/test_gpu_lastname.py.
+#include "scvod_dev.h"
+
+namespace scvod {
+
+namespace {
+
+constexpr int kLnThreads = 256;
+constexpr int kLnWaves = kLnThreads / 64;
+constexpr int kLnIrr = 256;       // index triples outside the grid handled per scan (a 128-beam scan holds 36)
+constexpr int kLnPairs = 1024;    // links between clusters that such points create
+constexpr int kLnNames = 512;     // distinct cluster names in those links
+constexpr int kLnSamples = 1024;  // sampled voxel keys (LDS)
+constexpr int kLnMarked = 16;     // components to replay besides the latest-born one
+constexpr int kLnChunk = 512;     // events staged per round
+constexpr int kInf = 0x7fffffff;
+
+enum : uint8_t { F_FULL = 1, F_REGVIS = 2 };
+
+struct Ln {  // per-scan view
+    const int32_t* vkey;
+    const int32_t* vbeg;
+    const int32_t* vpts;
+    const int32_t* ptc;
+    const int32_t* idx3;
+    const int32_t* akey;
+    int n, nv, R, S, Az;
+    long long span;
+    bool irregular;
+    // scratch (arena arrays that are dead between the clustering and the tracking)
+    int32_t* vcl;   // [nv] closure class of the voxel's first point
+    int32_t* loc;   // [nv] voxel -> node of the current replay, -1
+    int32_t* evn;   // [n] event point -> node
+    uint32_t* bits; // [n / 32 + 1] event points
+    int32_t* evl;   // [n] events in time order
+    int32_t* cvl;   // [nv] node -> voxel
+    int32_t* fp;    // [nv] first point of the voxel
+    long long rows_bytes;  // room for the lists
+    int n_raw;      // input points of the scan (size of the per-scan scratch regions)
+    // LDS
+    int32_t* skey;
+    int sshift, ns;
+    int32_t* irr_pt;    // [kLnIrr] sorted by point
+    int32_t* irr_home;  // voxel slot
+    int32_t* irr_cls;   // closure class
+    int32_t* irr_reg0;  // first regular point of the home voxel
+    int n_irr;
+    int32_t* cname;  // class table: sorted names
+    int32_t* crep;
+    int n_names;
+};
+
+__device__ __forceinline__ void decode3(int32_t t, int& r, int& s, int& a) {
+    r = (t & 2047) - 2;
+    s = ((t >> 11) & 2047) - 2;
+    a = ((t >> 22) & 1023) - 2;
+}
+__device__ __forceinline__ bool in_grid(const Ln& L, int r, int s, int a) { return r >= 0 && r < L.R && s >= 0 && s < L.S && a >= 0 && a < L.Az; }
+__device__ __forceinline__ bool regular_point(const Ln& L, int i) {
+    int r, s, a;
+    decode3(L.idx3[i], r, s, a);
+    return in_grid(L, r, s, a) && L.akey[i] == a * L.R * L.S + r * L.S + s;
+}
+// voxel slot of a key, -1 when no voxel carries it
+__device__ __forceinline__ int slot_of_key(const Ln& L, int key) {
+    int lo = 0, hi = L.ns;  // first sample > key
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.skey[mid] <= key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo == 0) return -1;
+    int a = (lo - 1) << L.sshift, b = min(a + (1 << L.sshift), L.nv);
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (L.vkey[mid] < key)
+            a = mid + 1;
+        else
+            b = mid;
+    }
+    return (a < L.nv && L.vkey[a] == key) ? a : -1;
+}
+__device__ __forceinline__ int slot_of_cell(const Ln& L, int r, int s, int a) {
+    if (!in_grid(L, r, s, a)) return -1;
+    return slot_of_key(L, a * L.R * L.S + r * L.S + s);
+}
+__device__ __forceinline__ bool cell_of_voxel(const Ln& L, int v, int& r, int& s, int& a) {
+    const int key = L.vkey[v];
+    if (key < 0 || (long long)key >= L.span) return false;
+    const int RS = L.R * L.S;
+    a = key / RS;
+    const int rem = key - a * RS;
+    r = rem / L.S;
+    s = rem - r * L.S;
+    return true;
+}
+__device__ __forceinline__ bool holds_irregular(const Ln& L, int v) {  // (irr_home is not sorted: a few hundred entries at most)
+    for (int j = 0; j < L.n_irr; ++j)
+        if (L.irr_home[j] == v) return true;
+    return false;
+}
+// e-th REGULAR point of voxel v (e = 0, 1, 2), kInf when it has fewer
+__device__ __forceinline__ int reg_of(const Ln& L, int v, int e) {
+    const int b = L.vbeg[v], c = L.vbeg[v + 1] - b;
+    if (!L.irregular || !holds_irregular(L, v)) return e < c ? L.vpts[b + e] : kInf;
+    int seen = 0;
+    for (int j = 0; j < c; ++j) {
+        const int i = L.vpts[b + j];
+        if (regular_point(L, i) && seen++ == e) return i;
+    }
+    return kInf;
+}
+__device__ __forceinline__ int cls_of(const Ln& L, int name) {
+    int lo = 0, hi = L.n_names;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.cname[mid] < name)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (lo < L.n_names && L.cname[lo] == name) ? L.crep[lo] : name;
+}
+
+template <int CAP>
+struct Rp {  // tables of one class (LDS unless said otherwise)
+    int32_t* T;      // [CAP] voxel node: time of the visit that labelled it FULLY, kInf never
+    int32_t* fa;     // [CAP] voxel node: its first point (of any kind), kInf for the nodes of irregular points
+    int32_t* par;    // [CAP] classes at / after the last opener
+    uint8_t* fl;     // [CAP]
+    int16_t* inext;  // [kLnIrr] next irregular point of the same voxel
+    int16_t* inode;  // [kLnIrr] irr list entry -> node of this class, -1
+    uint8_t* ivis;   // [kLnIrr]
+    int32_t* ev_t;   // [kLnChunk]
+    int32_t* ev_x;   // [kLnChunk]
+    // arena scratch
+    int16_t* rows;   // [nodes][32] listed nodes in findVoxelNeighbors order (ssc.cpp:400-410: range outermost, azimuth innermost), -1 none
+    int32_t* Tn;     // [nodes] next round's times
+    int32_t* ifirst; // [nodes] voxel node -> its first irregular point of this class (index into the scan's irr list), -1
+};
+
+struct RpOut {
+    int last_open;   // time of the class's last opener, -1 none
+    int fin;         // the cluster that point ends in still carries the number it created
+    int canon;       // smallest point of that cluster
+    int slot;        // lowest voxel slot whose first point belongs to it
+    int n_events;    // events walked one by one (after the last opener)
+    int too_big;
+};
+
+template <int CAP>
+__device__ __forceinline__ int rp_find(const Rp<CAP>& T, int x) {
+    while (T.par[x] != x) {
+        const int p = T.par[x];
+        T.par[x] = T.par[p];
+        x = T.par[x];
+    }
+    return x;
+}
+template <int CAP>
+__device__ __forceinline__ int rp_find_ro(const Rp<CAP>& T, int x) {
+    int p;
+    while ((p = __hip_atomic_load(&T.par[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != x) x = p;
+    return x;
+}
+// concurrent union (the partition at the time of the last opener: names do not matter there)
+template <int CAP>
+__device__ __forceinline__ void rp_union(const Rp<CAP>& T, int a, int b) {
+    for (;;) {
+        a = rp_find_ro(T, a);
+        b = rp_find_ro(T, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&T.par[a], a, b) == a) return;
+    }
+}
+// the visiting point (class oc, -1 = no label yet) meets the points of voxel k in index order (ssc.cpp:322-340); kroot: the
+// class that carries the last number handed out, -1 once a mergeClusters call renamed it
+template <int CAP>
+__device__ __forceinline__ void rp_meet(const Ln& L, const Rp<CAP>& T, int& oc, int k, int& kroot) {
+    auto take = [&](int c) {
+        if (oc < 0) {
+            oc = c;
+        } else if (c != oc) {  // mergeClusters(oc, nc), ssc.cpp:329: the VISITOR's cluster takes the neighbour's name
+            if (oc == kroot) kroot = -1;
+            T.par[oc] = c;
+            oc = c;
+        }
+    };
+    if (T.fl[k] & F_FULL) {
+        take(rp_find(T, k));
+        return;
+    }
+    // labelled so far: the visited regular points (one class: the voxel node's) and the visited irregular points, by index
+    int it = L.irregular ? T.ifirst[k] : -1;
+    bool reg_todo = (T.fl[k] & F_REGVIS) != 0;
+    const int r0 = (it >= 0) ? L.irr_reg0[it] : 0;
+    for (;;) {
+        while (it >= 0 && !T.ivis[it]) it = T.inext[it];
+        int node;
+        if (reg_todo && (it < 0 || r0 < L.irr_pt[it])) {
+            node = k;
+            reg_todo = false;
+        } else if (it >= 0) {
+            node = T.inode[it];
+            it = T.inext[it];
+        } else {
+            break;
+        }
+        take(rp_find(T, node));
+    }
+    if (oc < 0) return;  // nothing labelled on either side: left alone (ssc.cpp:332-341, no branch assigns)
+    const int rk = rp_find(T, k);
+    if (rk != oc) T.par[rk] = oc;  // (the voxel's unlabelled rest: a root of its own until now)
+    if (L.irregular)
+        for (int j = T.ifirst[k]; j >= 0; j = T.inext[j]) {
+            const int rj = rp_find(T, T.inode[j]);
+            if (rj != oc) T.par[rj] = oc;
+        }
+    T.fl[k] |= F_FULL;
+}
+
+// what one visit does, given the labelling times: is the visitor labelled when it starts; q = first listed voxel that holds a
+// label (-1 none: the visit opens a cluster when the visitor carries none either).  The listed voxels from q on are joined.
+template <int CAP>
+__device__ __forceinline__ void rp_visit(const Rp<CAP>& T, const int16_t* row16, int home, int t, bool optimistic, bool& cs, int& q, int (&nb)[27]) {
+    const uint4* row = reinterpret_cast<const uint4*>(row16);
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+    const unsigned w[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+    cs = optimistic || (home >= 0 && T.T[home] < t);
+    q = -1;
+#pragma unroll
+    for (int e = 0; e < 27; ++e) {
+        const int u = (int)(int16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        nb[e] = u;
+        if (u >= 0 && q < 0 && (T.T[u] < t || T.fa[u] < t)) q = e;
+    }
+}
+
+// Class `cls`: the time of its last opener; and, when that is later than `t_beat`, whether the cluster this point ends in still
+// carries the number it created.  All threads of the workgroup.
+//   1. labelling times by Jacobi rounds over the class's visits (the fixed point is the sequential loop's: a time depends on
+//      earlier times only), 2. openers = visits that start without a label and find none, 3. the partition right after the
+//      last opener = unions of what every visit up to it joined, 4. the visits after it walked one by one (ssc.cpp:322-350).
+template <int CAP>
+__device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat, int* wsum, int* bc) {
+    const int tid = threadIdx.x;
+    RpOut out = {-1, 0, -1, -1, 0, 0};
+    // ---- nodes: the class's voxels in slot order, then its irregular points ----
+    int m = 0;
+    for (int v0 = 0; v0 < L.nv; v0 += kLnThreads) {
+        const int v = v0 + tid;
+        const int in = (v < L.nv && L.vcl[v] == cls) ? 1 : 0;
+        int total;
+        const int ex = block_excl_scan<kLnThreads>(in, total, wsum);
+        if (in && m + ex < CAP) {
+            L.cvl[m + ex] = v;
+            L.loc[v] = m + ex;
+        }
+        m += total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nn = m;
+        for (int j = 0; j < L.n_irr; ++j) {
+            T.inode[j] = -1;
+            T.inext[j] = -1;
+            T.ivis[j] = 0;
+            if (L.irr_cls[j] == cls) T.inode[j] = (int16_t)min(nn++, CAP - 1);
+        }
+        bc[0] = nn;
+    }
+    __syncthreads();
+    const int nn = bc[0];
+    auto leave = [&]() {
+        for (int l = tid; l < min(m, CAP); l += kLnThreads) L.loc[L.cvl[l]] = -1;
+        __syncthreads();
+    };
+    if (nn > CAP || m > CAP || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || nn > L.n_raw) {  // does not fit
+        leave();
+        out.too_big = 1;
+        return out;
+    }
+    for (int x = tid; x < nn; x += kLnThreads) {
+        T.T[x] = kInf;
+        T.fa[x] = x < m ? L.fp[L.cvl[x]] : kInf;
+        if (L.irregular) T.ifirst[x] = -1;
+    }
+    __syncthreads();
+    if (tid == 0 && L.n_irr > 0) {  // per voxel: its irregular points of this class in index order (irr_pt is sorted)
+        for (int j = L.n_irr - 1; j >= 0; --j) {
+            if (T.inode[j] < 0) continue;
+            const int hv = L.irr_home[j];
+            const int l = hv >= 0 ? L.loc[hv] : -1;
+            if (l >= 0) {
+                T.inext[j] = (int16_t)T.ifirst[l];
+                T.ifirst[l] = j;
+            }
+        }
+    }
+    auto irr_of_node = [&](int x) {
+        int j = 0;
+        while (T.inode[j] != x) ++j;
+        return j;
+    };
+    // ---- lists: 27 cells around a voxel's own cell / around an irregular point's triple ----
+    for (int w = tid; w < nn * 32; w += kLnThreads) {
+        const int x = w >> 5, pos = w & 31;
+        int node = -1;
+        if (pos < 27) {
+            int r, s, a;
+            bool ok;
+            if (x < m) {
+                ok = cell_of_voxel(L, L.cvl[x], r, s, a);
+            } else {
+                decode3(L.idx3[L.irr_pt[irr_of_node(x)]], r, s, a);
+                ok = true;
+            }
+            if (ok) {
+                const int dx = pos / 9 - 1, dy = (pos / 3) % 3 - 1, dz = pos % 3 - 1;
+                const int k = slot_of_cell(L, r + dx, s + dy, a + dz);
+                if (k >= 0) node = L.loc[k];  // (closure: a listed voxel belongs to the lister's class)
+            }
+        }
+        T.rows[w] = (int16_t)node;
+    }
+    __syncthreads();
+    // the visits of node x: a voxel's first three regular points, an irregular point itself; `home` = the voxel whose full
+    // labelling labels the visitor before it starts
+    auto visits_of = [&](int x, int (&ie)[3], int& home) {
+        ie[0] = ie[1] = ie[2] = kInf;
+        if (x < m) {
+            const int v = L.cvl[x];
+            for (int e = 0; e < 3; ++e) {
+                ie[e] = reg_of(L, v, e);
+                if (ie[e] == kInf) break;
+            }
+            home = x;
+        } else {
+            const int j = irr_of_node(x);
+            ie[0] = L.irr_pt[j];
+            const int hv = L.irr_home[j];
+            home = hv >= 0 ? L.loc[hv] : -1;
+        }
+    };
+    // ---- 1. labelling times ----
+    bool converged = false;
+    for (int round = 0; round < 96 && !converged; ++round) {
+        for (int x = tid; x < nn; x += kLnThreads) T.Tn[x] = kInf;
+        __syncthreads();
+        for (int x = tid; x < nn; x += kLnThreads) {
+            int ie[3], home;
+            visits_of(x, ie, home);
+            for (int e = 0; e < 3 && ie[e] != kInf; ++e) {
+                bool cs;
+                int q, nb[27];
+                // round 0 starts from the optimistic end (every visit labels its whole list): any start reaches the same fixed
+                // point, this one in fewer rounds than "nothing is ever labelled"
+                rp_visit(T, T.rows + (size_t)x * 32, home, ie[e], round == 0, cs, q, nb);
+                const int from = (cs || q < 0) ? 0 : q;
+#pragma unroll
+                for (int p = 0; p < 27; ++p)
+                    if (p >= from && nb[p] >= 0 && nb[p] < m) atomicMin(&T.Tn[nb[p]], ie[e]);
+            }
+        }
+        __syncthreads();
+        int changed = 0;
+        for (int x = tid; x < m; x += kLnThreads) {
+            const int tv = __hip_atomic_load(&T.Tn[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            changed |= tv != T.T[x];
+            T.T[x] = tv;
+        }
+        converged = !__syncthreads_or(changed);
+    }
+    if (!converged) {  // (never seen; reported like a class that does not fit)
+        leave();
+        out.too_big = 1;
+        return out;
+    }
+    // ---- 2. the last opener ----
+    if (tid == 0) bc[1] = -1;
+    __syncthreads();
+    for (int x = tid; x < nn; x += kLnThreads) {
+        int ie[3], home;
+        visits_of(x, ie, home);
+        bool cs;
+        int q, nb[27];
+        if (ie[0] != kInf) {  // (only a voxel's first regular point or an irregular point can open a cluster)
+            rp_visit(T, T.rows + (size_t)x * 32, home, ie[0], false, cs, q, nb);
+            if (!cs && q < 0) atomicMax(&bc[1], ie[0]);
+        }
+    }
+    __syncthreads();
+    const int t_open = bc[1];
+    out.last_open = t_open;
+    if (t_open <= t_beat) {
+        leave();
+        return out;
+    }
+    // ---- 3. the partition right after the last opener's visit ----
+    for (int x = tid; x < nn; x += kLnThreads) T.par[x] = x;
+    if (tid == 0) bc[2] = -1;
+    __syncthreads();
+    for (int x = tid; x < nn; x += kLnThreads) {
+        int ie[3], home;
+        visits_of(x, ie, home);
+        for (int e = 0; e < 3 && ie[e] <= t_open; ++e) {
+            bool cs;
+            int q, nb[27];
+            rp_visit(T, T.rows + (size_t)x * 32, home, ie[e], false, cs, q, nb);
+            const int from = (cs || q < 0) ? 0 : q;
+            if (ie[e] == t_open) bc[2] = x;
+            for (int p = from; p < 27; ++p) {
+                const int u = nb[p];
+                if (u < 0) continue;
+                rp_union(T, x, u);
+                if (L.irregular)
+                    for (int j = T.ifirst[u]; j >= 0; j = T.inext[j]) rp_union(T, u, T.inode[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int x = tid; x < nn; x += kLnThreads) {
+        uint8_t f = 0;
+        if (x < m) {
+            if (T.T[x] <= t_open) f |= F_FULL;
+            if (reg_of(L, L.cvl[x], 0) <= t_open) f |= F_REGVIS;
+        } else {
+            T.ivis[irr_of_node(x)] = L.irr_pt[irr_of_node(x)] <= t_open;
+        }
+        T.fl[x] = f;
+    }
+    // ---- 4. the visits after it, in order ----
+    int tmax = -1;
+    for (int x = tid; x < nn; x += kLnThreads) {
+        int ie[3], home;
+        visits_of(x, ie, home);
+        for (int e = 0; e < 3 && ie[e] != kInf; ++e)
+            if (ie[e] > t_open) tmax = max(tmax, ie[e]);
+    }
+    for (int d = 32; d > 0; d >>= 1) tmax = max(tmax, __shfl_xor(tmax, d));
+    __syncthreads();
+    if ((tid & 63) == 0) wsum[tid >> 6] = tmax;
+    __syncthreads();
+    for (int w = 0; w < kLnWaves; ++w) tmax = max(tmax, wsum[w]);
+    __syncthreads();
+    int n_ev = 0;
+    if (tmax > t_open) {
+        const int w_lo = (t_open + 1) >> 5, w_hi = tmax >> 5;
+        for (int w = w_lo + tid; w <= w_hi; w += kLnThreads) L.bits[w] = 0u;
+        __syncthreads();
+        for (int x = tid; x < nn; x += kLnThreads) {
+            int ie[3], home;
+            visits_of(x, ie, home);
+            for (int e = 0; e < 3 && ie[e] != kInf; ++e)
+                if (ie[e] > t_open) {
+                    L.evn[ie[e]] = x;
+                    atomicOr(&L.bits[ie[e] >> 5], 1u << (ie[e] & 31));
+                }
+        }
+        __syncthreads();
+        for (int w0 = w_lo; w0 <= w_hi; w0 += kLnThreads) {
+            const int w = w0 + tid;
+            uint32_t word = (w <= w_hi) ? __hip_atomic_load(&L.bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            int total;
+            int o = n_ev + block_excl_scan<kLnThreads>(__popc(word), total, wsum);
+            while (word) {
+                const int b = __ffs((int)word) - 1;
+                word &= word - 1;
+                L.evl[o++] = (w << 5) + b;
+            }
+            n_ev += total;
+        }
+        __syncthreads();
+    }
+    out.n_events = n_ev;
+    int kroot = -1;
+    if (tid == 0) {
+        kroot = rp_find(T, bc[2]);
+        bc[3] = 0;  // a visit after the "last" opener opened a cluster: the model is broken (never seen; reported as unknown)
+    }
+    for (int e0 = 0; e0 < n_ev; e0 += kLnChunk) {
+        const int ce = min(kLnChunk, n_ev - e0);
+        __syncthreads();
+        for (int e = tid; e < ce; e += kLnThreads) {
+            const int i = __hip_atomic_load(&L.evl[e0 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T.ev_t[e] = i;
+            T.ev_x[e] = __hip_atomic_load(&L.evn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int e = 0; e < ce && kroot >= 0; ++e) {  // (once the number is gone nothing brings it back)
+                const int x = T.ev_x[e];
+                const bool reg = x < m;
+                int lv, jirr = -1;
+                if (reg) {
+                    lv = x;
+                } else {
+                    jirr = irr_of_node(x);
+                    const int hv = L.irr_home[jirr];
+                    lv = hv >= 0 ? L.loc[hv] : -1;
+                }
+                const int16_t* row = T.rows + (size_t)x * 32;
+                int nb[27];
+                for (int pos = 0; pos < 27; ++pos) nb[pos] = row[pos];
+                int oc = (lv >= 0 && (T.fl[lv] & F_FULL)) ? rp_find(T, lv) : -1;  // the visiting point's own label
+                for (int pos = 0; pos < 27; ++pos)
+                    if (nb[pos] >= 0) rp_meet(L, T, oc, nb[pos], kroot);
+                if (oc < 0) {
+                    bc[3] = 1;
+                    break;
+                }
+                if (reg) {
+                    if (!(T.fl[x] & (F_FULL | F_REGVIS))) {  // only the visited point carries the label: the voxel node holds its class
+                        const int r = rp_find(T, x);
+                        if (r != oc) T.par[r] = oc;
+                    }
+                    T.fl[x] |= F_REGVIS;
+                } else {
+                    const int r = rp_find(T, x);
+                    if (r != oc) T.par[r] = oc;
+                    T.ivis[jirr] = 1;
+                }
+            }
+        }
+    }
+    // ---- result ----
+    if (tid == 0) {
+        bc[0] = kroot >= 0 ? rp_find(T, kroot) : -1;
+        bc[4] = kInf;  // canon
+        bc[5] = kInf;  // slot
+    }
+    __syncthreads();
+    if (bc[3]) {
+        leave();
+        out.too_big = 1;
+        return out;
+    }
+    const int root = bc[0];
+    out.fin = root >= 0;
+    if (root >= 0) {
+        int canon = kInf, slot = kInf;
+        for (int x = tid; x < nn; x += kLnThreads) {
+            if (rp_find_ro(T, x) != root) continue;
+            if (x < m) {
+                const int v = L.cvl[x];
+                canon = min(canon, reg_of(L, v, 0));
+                if (!L.irregular || regular_point(L, L.fp[v])) slot = min(slot, v);
+            } else {
+                const int j = irr_of_node(x);
+                canon = min(canon, L.irr_pt[j]);
+                const int hv = L.irr_home[j];
+                if (hv >= 0 && L.fp[hv] == L.irr_pt[j]) slot = min(slot, hv);
+            }
+        }
+        atomicMin(&bc[4], canon);
+        atomicMin(&bc[5], slot);
+        __syncthreads();
+        out.canon = bc[4] == kInf ? -1 : bc[4];
+        out.slot = bc[5] == kInf ? -1 : bc[5];
+    }
+    leave();
+    return out;
+}
+
+template <int CAP>
+constexpr size_t ln_lds_bytes() {
+    return (size_t)CAP * (4 + 4 + 4 + 1) + kLnIrr * (2 + 2 + 1) + kLnChunk * 8  // tables of a class
+           + kLnSamples * 4 + kLnIrr * 4 * 4 + kLnNames * 8 + 512;
+}
+
+// per wave: the 5 x 5 x 5 block of cells around a candidate
+struct Blk {
+    int32_t fa[125];      // first point of the voxel in the cell, kInf: no voxel
+    int32_t reg[125][3];  // its first three regular points
+};
+
+template <int CAP>
+__global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo,
+                                                             int32_t* n_redo) {
+    extern __shared__ __align__(16) unsigned char ln_smem[];
+    __shared__ int wsum[2 * kLnWaves + 2];
+    __shared__ int bc[8];
+    __shared__ int mk_cls[kLnMarked], mk_t[kLnMarked], n_mk, n_pairs_s, n_irr_s, fail_s;
+    __shared__ int red[kLnWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int s = blockIdx.x;
+    if (todo) {
+        if (s >= *n_todo) return;
+        s = todo[s];
+    }
+    Ln L;
+    const int base = A.scan_off[s];
+    L.n = A.counts[s * 8 + 4];
+    L.nv = A.counts[s * 8 + 6];
+    int32_t* outp = A.cc_last + (size_t)s * 4;
+    if (L.n <= 0 || L.nv <= 0) {
+        if (tid == 0) outp[0] = outp[1] = -1, outp[2] = 0, outp[3] = 0;
+        return;
+    }
+    L.vkey = A.vox_key + base;
+    L.vbeg = A.vox_pt_begin + base + s;
+    L.vpts = A.vox_pts + base;
+    L.ptc = A.pt_cluster + base;
+    L.idx3 = A.apri_idx3 + base;
+    L.akey = A.apri_key + base;
+    L.R = P.bin.range_num, L.S = P.bin.sector_num, L.Az = P.bin.azimuth_num;
+    L.span = (long long)L.R * L.S * L.Az;
+    L.irregular = A.scan_irr[s] != 0;
+    L.vcl = A.tmp_vox_key + base;
+    L.loc = A.tmp_vox_begin + base;
+    L.evn = (int32_t*)A.tmp_vox_av + base;
+    L.bits = (uint32_t*)A.tmp_vox_cov + base;
+    L.evl = (int32_t*)(A.vkeys + base);
+    L.cvl = (int32_t*)A.tk_uniq + base;
+    L.fp = (int32_t*)A.sorted_idx + base;
+    L.n_raw = A.scan_off[s + 1] - base;
+    L.rows_bytes = 8ll * L.n_raw;
+    // LDS carve
+    unsigned char* q = ln_smem;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = q;
+        q += (bytes + 15) & ~(size_t)15;
+        return p;
+    };
+    L.skey = (int32_t*)take(kLnSamples * 4);
+    L.irr_pt = (int32_t*)take(kLnIrr * 4);
+    L.irr_home = (int32_t*)take(kLnIrr * 4);
+    L.irr_cls = (int32_t*)take(kLnIrr * 4);
+    L.irr_reg0 = (int32_t*)take(kLnIrr * 4);
+    L.cname = (int32_t*)take(kLnNames * 4);
+    L.crep = (int32_t*)take(kLnNames * 4);
+    unsigned char* ovl = q;  // from here on: the replay tables, overlaid by the link pairs / the candidates' blocks
+    Rp<CAP> T;
+    T.T = (int32_t*)take((size_t)CAP * 4);
+    T.fa = (int32_t*)take((size_t)CAP * 4);
+    T.par = (int32_t*)take((size_t)CAP * 4);
+    T.fl = (uint8_t*)take(CAP);
+    T.inext = (int16_t*)take(kLnIrr * 2);
+    T.inode = (int16_t*)take(kLnIrr * 2);
+    T.ivis = (uint8_t*)take(kLnIrr);
+    T.ev_t = (int32_t*)take(kLnChunk * 4);
+    T.ev_x = (int32_t*)take(kLnChunk * 4);
+    T.rows = (int16_t*)(A.keys + base);
+    T.Tn = (int32_t*)A.tmp_vox_av + base;
+    T.ifirst = A.tk_hit + base;
+    int2* pairs = (int2*)ovl;        // [kLnPairs]
+    Blk* blk = (Blk*)ovl + wave;     // [kLnWaves]
+    static_assert(sizeof(Blk) * kLnWaves <= 2048 * 12 && kLnPairs * 8 <= 2048 * 12, "overlays fit the smallest replay table");
+
+    L.n_irr = 0;
+    L.n_names = 0;
+    // sampled keys
+    L.sshift = 0;
+    while (((L.nv + (1 << L.sshift) - 1) >> L.sshift) > kLnSamples) ++L.sshift;
+    L.ns = (L.nv + (1 << L.sshift) - 1) >> L.sshift;
+    for (int j = tid; j < L.ns; j += kLnThreads) L.skey[j] = L.vkey[(size_t)j << L.sshift];
+    if (tid == 0) n_mk = 0, n_pairs_s = 0, n_irr_s = 0, fail_s = 0;
+    __syncthreads();
+
+    // ---- index triples outside the grid: the points, then which clusters their lists tie into one closure class ----
+    if (L.irregular) {
+        for (int i0 = 0; i0 < L.n; i0 += kLnThreads) {
+            const int i = i0 + tid;
+            if (i < L.n && !regular_point(L, i)) {
+                const int x = atomicAdd(&n_irr_s, 1);
+                if (x < kLnIrr) L.irr_pt[x] = i;
+            }
+        }
+        __syncthreads();
+        if (n_irr_s > kLnIrr) {
+            if (tid == 0) {
+                outp[0] = outp[1] = -1, outp[2] = 2, outp[3] = 0;
+                atomicAdd(&A.ln_stats[1], 1);
+            }
+            return;
+        }
+        L.n_irr = n_irr_s;
+        if (tid == 0) {  // by point index (a handful)
+            for (int a = 1; a < L.n_irr; ++a) {
+                const int v = L.irr_pt[a];
+                int b = a - 1;
+                while (b >= 0 && L.irr_pt[b] > v) {
+                    L.irr_pt[b + 1] = L.irr_pt[b];
+                    --b;
+                }
+                L.irr_pt[b + 1] = v;
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < L.n_irr; j += kLnThreads) {
+            L.irr_home[j] = slot_of_key(L, L.akey[L.irr_pt[j]]);
+            L.irr_cls[j] = L.ptc[L.irr_pt[j]];
+        }
+        __syncthreads();
+        for (int j = tid; j < L.n_irr; j += kLnThreads) L.irr_reg0[j] = L.irr_home[j] >= 0 ? reg_of(L, L.irr_home[j], 0) : kInf;
+        __syncthreads();
+        auto link = [&](int a, int b) {
+            if (a == b) return;
+            const int x = atomicAdd(&n_pairs_s, 1);
+            if (x < kLnPairs) pairs[x] = make_int2(a, b);
+        };
+        // one wave per irregular point: what it lists, and who lists its voxel
+        for (int j = wave; j < L.n_irr; j += kLnWaves) {
+            const int p = L.irr_pt[j], cp = L.ptc[p];
+            int r, s3, a;
+            decode3(L.idx3[p], r, s3, a);
+            if (lane < 27) {
+                const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
+                const int k = slot_of_cell(L, r + dx, s3 + dy, a + dz);
+                if (k >= 0) {
+                    const int r0 = reg_of(L, k, 0);
+                    if (r0 != kInf) link(cp, L.ptc[r0]);
+                    for (int j2 = 0; j2 < L.n_irr; ++j2)
+                        if (L.irr_home[j2] == k) link(cp, L.ptc[L.irr_pt[j2]]);
+                }
+            }
+            const int hv = L.irr_home[j];
+            int hr, hs, ha;
+            if (hv >= 0 && cell_of_voxel(L, hv, hr, hs, ha) && lane < 27) {  // the regular points around the voxel's own cell list it
+                const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
+                const int w = slot_of_cell(L, hr + dx, hs + dy, ha + dz);
+                if (w >= 0) {
+                    const int r0 = reg_of(L, w, 0);
+                    if (r0 != kInf) link(cp, L.ptc[r0]);
+                }
+            }
+        }
+        __syncthreads();
+        if (n_pairs_s > kLnPairs) {
+            if (tid == 0) {
+                outp[0] = outp[1] = -1, outp[2] = 2, outp[3] = 0;
+                atomicAdd(&A.ln_stats[1], 1);
+            }
+            return;
+        }
+        if (tid == 0 && n_pairs_s > 0) {  // union-find over the names that occur (a few dozen)
+            int nn = 0;
+            bool over = false;
+            auto idx_of = [&](int name) -> int {
+                for (int t = 0; t < nn; ++t)
+                    if (L.cname[t] == name) return t;
+                if (nn >= kLnNames) {
+                    over = true;
+                    return 0;
+                }
+                L.cname[nn] = name;
+                L.crep[nn] = nn;
+                return nn++;
+            };
+            auto fnd = [&](int x) {
+                while (L.crep[x] != x) x = L.crep[x] = L.crep[L.crep[x]];
+                return x;
+            };
+            for (int t = 0; t < n_pairs_s; ++t) {
+                const int a = fnd(idx_of(pairs[t].x)), b = fnd(idx_of(pairs[t].y));
+                if (a != b) {  // the class is called after its smallest name (= its birth)
+                    if (L.cname[a] < L.cname[b])
+                        L.crep[b] = a;
+                    else
+                        L.crep[a] = b;
+                }
+            }
+            for (int t = 0; t < nn; ++t) pairs[t] = make_int2(L.cname[t], L.cname[fnd(t)]);
+            // sorted by name for cls_of
+            for (int a = 1; a < nn; ++a) {
+                const int2 v = pairs[a];
+                int b = a - 1;
+                while (b >= 0 && pairs[b].x > v.x) {
+                    pairs[b + 1] = pairs[b];
+                    --b;
+                }
+                pairs[b + 1] = v;
+            }
+            for (int t = 0; t < nn; ++t) {
+                L.cname[t] = pairs[t].x;
+                L.crep[t] = pairs[t].y;
+            }
+            bc[0] = over ? -1 : nn;
+        } else if (tid == 0) {
+            bc[0] = 0;
+        }
+        __syncthreads();
+        if (bc[0] < 0) {
+            if (tid == 0) {
+                outp[0] = outp[1] = -1, outp[2] = 2, outp[3] = 0;
+                atomicAdd(&A.ln_stats[1], 1);
+            }
+            return;
+        }
+        L.n_names = bc[0];
+        __syncthreads();
+        for (int j = tid; j < L.n_irr; j += kLnThreads) L.irr_cls[j] = cls_of(L, L.irr_cls[j]);
+        __syncthreads();
+    }
+
+    // ---- A: closure class of every voxel (through its first point), the latest-born class ----
+    int lmax = -1;
+    for (int v0 = 0; v0 < L.nv; v0 += kLnThreads * 4) {
+        int f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = L.vbeg[min(v0 + u * kLnThreads + tid, L.nv - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = L.vpts[f[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = v0 + u * kLnThreads + tid;
+            if (v < L.nv) L.fp[v] = f[u];
+            f[u] = L.ptc[f[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = v0 + u * kLnThreads + tid;
+            if (v < L.nv) {
+                const int c = L.n_names ? cls_of(L, f[u]) : f[u];
+                L.vcl[v] = c;
+                L.loc[v] = -1;
+                lmax = max(lmax, c);
+            }
+        }
+    }
+    for (int j = tid; j < L.n_irr; j += kLnThreads) lmax = max(lmax, L.irr_cls[j]);
+    for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, __shfl_xor(lmax, d));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    for (int w = 0; w < kLnWaves; ++w) lmax = max(lmax, red[w]);
+    __syncthreads();
+    const int CL = lmax;
+
+    // ---- B: the latest-born class, replayed ----
+    RpOut best = replay_class<CAP>(L, T, CL, -1, wsum, bc);
+    int events = best.n_events;
+    bool unknown = best.too_big != 0;
+    int best_cls = CL;
+
+    // ---- C: later points of the other classes that could still open a cluster ----
+    if (!unknown) {
+        const int t_best = best.last_open;
+        // candidates: voxels whose first regular point comes after t_best (a few), irregular points after it -- listed first
+        if (tid == 0) bc[5] = 0;
+        __syncthreads();
+        for (int v = tid; v < L.nv; v += kLnThreads) {
+            const int f = L.fp[v];
+            bool c = f > t_best && L.vcl[v] != CL;
+            if (L.irregular && holds_irregular(L, v)) {  // (irregular points may lead the voxel)
+                const int r0 = reg_of(L, v, 0);
+                c = r0 != kInf && r0 > t_best && (L.n_names ? cls_of(L, L.ptc[r0]) : L.ptc[r0]) != CL;
+            }
+            if (c) L.evl[atomicAdd(&bc[5], 1)] = v;
+        }
+        for (int j = tid; j < L.n_irr; j += kLnThreads)
+            if (L.irr_pt[j] > t_best && L.irr_cls[j] != CL) L.evl[atomicAdd(&bc[5], 1)] = L.nv + j;
+        __syncthreads();
+        const int n_cand = bc[5];
+        for (int c0 = wave; c0 < n_cand; c0 += kLnWaves) {
+            int ti = kInf, cr = 0, cs = 0, ca = 0, ccls = -1;
+            bool cand = false;
+            const int item = __hip_atomic_load(&L.evl[c0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (item < L.nv) {
+                const int v = item;
+                const int r0 = reg_of(L, v, 0);
+                cand = cell_of_voxel(L, v, cr, cs, ca);
+                ti = r0;
+                ccls = L.n_names ? cls_of(L, L.ptc[r0]) : L.ptc[r0];
+            } else {
+                const int j = item - L.nv;
+                cand = true;
+                ti = L.irr_pt[j];
+                decode3(L.idx3[ti], cr, cs, ca);
+                ccls = L.irr_cls[j];
+            }
+            if (!cand) continue;
+            // the block of cells around it
+            for (int c = lane; c < 125; c += 64) {
+                const int dx = c / 25 - 2, dy = (c / 5) % 5 - 2, dz = c % 5 - 2;
+                const int k = slot_of_cell(L, cr + dx, cs + dy, ca + dz);
+                blk->fa[c] = k >= 0 ? L.vpts[L.vbeg[k]] : kInf;
+                for (int e = 0; e < 3; ++e) blk->reg[c][e] = k >= 0 ? reg_of(L, k, e) : kInf;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            bool possible = true, cert = false;
+            if (lane < 27) {
+                const int wx = lane / 9 - 1, wy = (lane / 3) % 3 - 1, wz = lane % 3 - 1;
+                const int cw = (wx + 2) * 25 + (wy + 2) * 5 + (wz + 2);
+                const int faw = blk->fa[cw];
+                if (faw != kInf) {
+                    if (faw < ti) possible = false;  // a visited point in the list: the candidate takes its label
+                    // who lists w: the regular points of the cells around it
+                    for (int u = 0; u < 27 && !cert; ++u) {
+                        const int ux = wx + u / 9 - 1, uy = wy + (u / 3) % 3 - 1, uz = wz + u % 3 - 1;  // cell of the lister
+                        if (ux < -2 || ux > 2 || uy < -2 || uy > 2 || uz < -2 || uz > 2) continue;
+                        const int cu = (ux + 2) * 25 + (uy + 2) * 5 + (uz + 2);
+                        const int* rg = blk->reg[cu];
+                        if (rg[0] >= ti) continue;
+                        if (rg[2] < ti) {  // the third visit labels the whole list
+                            cert = true;
+                            break;
+                        }
+                        const int posw = (wx - ux + 1) * 9 + (wy - uy + 1) * 3 + (wz - uz + 1);  // w's place in u's list
+                        if (rg[1] < ti && posw >= 13) {  // the second visit finds its own voxel labelled: everything from there on joins
+                            cert = true;
+                            break;
+                        }
+                        for (int e = 0; e < 2 && !cert; ++e) {
+                            const int te = rg[e];
+                            if (te >= ti) break;
+                            for (int z = 0; z <= posw; ++z) {  // a voxel at or before w in u's list that held a visited point at the time
+                                const int kx = ux + z / 9 - 1, ky = uy + (z / 3) % 3 - 1, kz = uz + z % 3 - 1;
+                                if (kx < -2 || kx > 2 || ky < -2 || ky > 2 || kz < -2 || kz > 2) continue;
+                                if (blk->fa[(kx + 2) * 25 + (ky + 2) * 5 + (kz + 2)] < te) {
+                                    cert = true;
+                                    break;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            possible = !__any(!possible);
+            cert = __any(cert);
+            if (possible && !cert && lane == 0) {
+                // its class has to be replayed
+                int at = -1;
+                const int cur = atomicAdd(&n_mk, 0);
+                for (int t = 0; t < min(cur, kLnMarked); ++t)
+                    if (mk_cls[t] == ccls) at = t;
+                if (at >= 0) {
+                    atomicMax(&mk_t[at], ti);
+                } else {
+                    const int x = atomicAdd(&n_mk, 1);
+                    if (x < kLnMarked) {
+                        mk_cls[x] = ccls;
+                        mk_t[x] = ti;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        if (n_mk > kLnMarked) unknown = true;
+        // ---- D: those classes (duplicates from racing waves are harmless: the second replay changes nothing) ----
+        for (int t = 0; t < min(n_mk, kLnMarked) && !unknown; ++t) {
+            if (mk_t[t] <= best.last_open || mk_cls[t] == best_cls) continue;
+            const RpOut r = replay_class<CAP>(L, T, mk_cls[t], best.last_open, wsum, bc);
+            events += r.n_events;
+            if (r.too_big) {
+                unknown = true;
+                break;
+            }
+            if (r.last_open > best.last_open) {
+                best = r;
+                best_cls = mk_cls[t];
+            }
+        }
+    }
+    if (tid == 0) {
+        if (unknown) {
+            if (redo) {  // a larger table may hold it
+                redo[atomicAdd(n_redo, 1)] = s;
+                outp[0] = outp[1] = -1, outp[2] = 3, outp[3] = events;
+            } else {
+                outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = events;
+                atomicAdd(&A.ln_stats[0], 1);
+            }
+        } else {
+            outp[0] = best.fin ? best.canon : -1;
+            outp[1] = best.fin ? best.slot : -1;
+            outp[2] = 0;
+            outp[3] = events;
+        }
+    }
+}
+
+}  // namespace
+
+constexpr int kLnCapSmall = 2048, kLnCapBig = 10240;
+
+void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
+    const int B = A.n_scans;
+    if (B <= 0 || A.max_scan_pts <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
+        attr_set = true;
+    }
+    if (th) th(tu, "cc_lastname", 1);
+    hipMemsetAsync(A.cc_redo + B, 0, sizeof(int32_t), st);
+    hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_cc_lastname<kLnCapSmall>, dim3(B), dim3(kLnThreads), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, A.cc_redo, A.cc_redo + B);
+    // the scans whose replay did not fit: once more with the largest tables a CU holds (the grid is the batch, the idle
+    // workgroups leave at once: nothing is read back on the host)
+    hipLaunchKernelGGL(k_cc_lastname<kLnCapBig>, dim3(B), dim3(kLnThreads), ln_lds_bytes<kLnCapBig>(), st, P, A, (const int32_t*)A.cc_redo,
+                       (const int32_t*)(A.cc_redo + B), (int32_t*)nullptr, (int32_t*)nullptr);
+    if (th) th(tu, "cc_lastname", 0);
+}
+
+}  // namespace scvod

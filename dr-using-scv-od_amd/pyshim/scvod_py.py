@@ -127,6 +127,8 @@ def load_lib():
         "scvod_set_track_mode": (C.c_int, [vp, i32, i32, i32]),
         "scvod_set_cluster_exact": (C.c_int, [vp, i32]),
         "scvod_batch_cluster_stats": (C.c_int, [vp, vp]),
+        "scvod_set_max_name_literal": (C.c_int, [vp, i32]),
+        "scvod_batch_cluster_last_name": (C.c_int, [vp, vp, i32, vp]),
         "scvod_set_chain_capacity": (C.c_int, [vp, i64]),
         "scvod_batch_track_stats": (C.c_int, [vp, vp]),
         "scvod_batch_track_tables": (C.c_int, [vp, vp]),
@@ -163,7 +165,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_chain_capacity", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
@@ -399,6 +401,19 @@ class Ctx:
         out = np.zeros(4, np.int32)
         self._chk(self.lib.scvod_batch_cluster_stats(self.h, out.ctypes.data_as(C.c_void_p)))
         return dict(scans_approximated=int(out[0]), nodes_concerned=int(out[1]), exact=bool(out[2]), scans_on_hbm_forest=int(out[3]))
+
+    def set_max_name_literal(self, literal=True):
+        """ssc.cpp:354 keeps the LAST USED running number in Frame::max_name; False = fresh numbers (rounds 1-3)"""
+        self._chk(self.lib.scvod_set_max_name_literal(self.h, 1 if literal else 0))
+
+    def batch_cluster_last_name(self, n_scans):
+        """per scan {name of the cluster that still carries Frame::max_name or -1, voxel slot, status, events}, and the batch's counters"""
+        out = np.zeros((max(n_scans, 1), 4), np.int32)
+        st = np.zeros(4, np.int32)
+        rc = self.lib.scvod_batch_cluster_last_name(self.h, out.ctypes.data_as(C.c_void_p), n_scans, st.ctypes.data_as(C.c_void_p))
+        if rc < 0:
+            self._chk(rc)
+        return out[:n_scans], dict(unknown_too_large=int(st[0]), unknown_irregular=int(st[1]))
 
     def set_chain_capacity(self, pool_points):
         self._chk(self.lib.scvod_set_chain_capacity(self.h, int(pool_points)))

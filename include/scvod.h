@@ -350,6 +350,18 @@ int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
  * too large for the windowed search and were joined on a forest in HBM instead (slower, same result)}.  Synchronises. */
 int scvod_set_cluster_exact(scvod_ctx* ctx, int32_t on);
 int scvod_batch_cluster_stats(scvod_ctx* ctx, int32_t* h_out4);
+/* Frame::max_name.  clusterAndCreateFrame ends with `frame_ssc.max_name = cluster_name ++;` (ssc.cpp:354): the frame keeps
+ * the LAST USED running number K, and the first cluster SSC::tracking splits off or fuses in that frame is called K again
+ * (ssc.cpp:1357, :1401) -- when a cluster K is still alive the insert (:1372, :1419) is a no-op and the new cluster is lost.
+ * scvod_batch_cluster therefore also determines, per scan, which cluster (canonical name) still carries K when the visiting
+ * loop ends (csrc/scvod_lastname.hip), and the tracking chain hands that name out first.  literal = 0 switches both off:
+ * every new cluster gets a fresh number (rounds 1-3 of this library).  Default 1.
+ * scvod_batch_cluster_last_name: h_out4[s] = {canonical name of the cluster carrying K or -1 (K was merged away),
+ * lowest voxel slot whose first point belongs to it or -1, status, events replayed}; status 0 = exact; 1 = a component
+ * that had to be replayed holds more voxels than a CU's LDS (about 2200): reported as "none"; 2 = more than 256 points with
+ * an index triple outside the grid: reported as "none".  h_stats4 (optional) = {scans with status 1, with status 2, 0, 0}. */
+int scvod_set_max_name_literal(scvod_ctx* ctx, int32_t literal);
+int scvod_batch_cluster_last_name(scvod_ctx* ctx, int32_t* h_out4, int32_t cap_scans, int32_t* h_stats4);
 /* copies the cluster name of every apri point of scan s into h_pt_cluster[cap]; returns the count (>= 0)
  * or a negative status */
 int scvod_batch_fetch_clusters(scvod_ctx* ctx, int32_t s, int32_t* h_pt_cluster, int32_t cap);

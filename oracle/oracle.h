@@ -49,6 +49,10 @@ int oracle_track_probe(const scvod_params* params, const float* xyzi, const int3
 int oracle_cluster(const scvod_params* params, const scvod_apri* apri, int32_t n, int32_t* pt_cluster,
                    int32_t* max_name);
 
+/* the cluster that still carries the last running number K = Frame::max_name as ssc.cpp:354 stores it (smallest point
+ * index, -1 if none); info[6]: see ssc_oracle.cpp */
+int oracle_cluster_last_name(const scvod_params* params, const scvod_apri* apri, int32_t n, int64_t* info);
+
 /* refineClusterByBoundingBox + bounding-box part of recognize (ssc.cpp:437-467, 723-751, 849-872) */
 int oracle_cluster_types(const scvod_params* params, const scvod_apri* apri, int32_t n, const int32_t* pt_cluster,
                          int32_t car_label, int32_t other_label, int32_t* pt_type);
@@ -67,6 +71,11 @@ int oracle_track_decide(const scvod_params* params, const scvod_apri* apri_a, in
 int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
                              const int32_t* pt_cluster, const int32_t* pt_type, const float* poses, int32_t car, int32_t chain,
                              uint8_t* pt_dyn, int32_t* dynamic_clusters);
+
+/* the same loop with the reference's literal max_name (first new cluster of a frame re-uses running number K) */
+int oracle_sequence_tracking_literal(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
+                                     const int32_t* pt_cluster, const int32_t* pt_type, const int32_t* collide, const float* poses,
+                                     int32_t car, int32_t chain, uint8_t* pt_dyn, int32_t* dynamic_clusters, int64_t* literal_stats);
 
 /* brute-force nearest neighbour / radius test (src/evaluate.cpp:79-145 analogue) */
 int oracle_nn_search(const float* map_xyz, int32_t n_map, const float* query_xyz, int32_t n_query, float radius,

@@ -349,9 +349,15 @@ int oracle_track_probe(const scvod_params* params, const float* xyzi, const int3
     return 0;
 }
 
-int oracle_cluster(const scvod_params* params, const scvod_apri* apri_vec_, int32_t n, int32_t* pt_cluster,
-                   int32_t* max_name) {
+// info (optional), for the LITERAL max_name of ssc.cpp:354: {K = last running number handed out, index of the point that
+// opened K, running number the opener's cluster carries at the end, openers whose clusters ended up in that cluster,
+// mergeClusters calls that renamed K away, mergeClusters calls in total}
+static int cluster_and_create_frame(const scvod_params* params, const scvod_apri* apri_vec_, int32_t n, int32_t* pt_cluster,
+                                    int32_t* max_name, int64_t* info) {
     Grid g = grid_of(*params);
+    std::vector<int> opened(n + 6, 1);  // per running number: how many openers' clusters it holds
+    int last_opener = -1;
+    int64_t merges = 0, k_renamed = 0;
     std::unordered_map<int, VoxelO> hash_cloud_;
     make_hash_cloud(*params, apri_vec_, n, hash_cloud_);
     int cluster_name = 4;
@@ -376,6 +382,9 @@ int oracle_cluster(const scvod_params* params, const scvod_apri* apri_vec_, int3
                     if (oc != nc) {
                         for (int q = 0; q < n; q++)  // mergeClusters(clusterIdxs, oc, nc)
                             if (clusterIdxs[q] == oc) clusterIdxs[q] = nc;
+                        opened[nc] += opened[oc];
+                        merges++;
+                        if (oc == cluster_name) k_renamed++;  // (cluster_name is the last number so far: only the final K matters, see below)
                     }
                 } else {
                     if (nc != -1) {
@@ -390,14 +399,40 @@ int oracle_cluster(const scvod_params* params, const scvod_apri* apri_vec_, int3
             cluster_name++;
             clusterIdxs[i] = cluster_name;
             for (size_t m = 0; m < neighbors.size(); m++) clusterIdxs[neighbors[m]] = cluster_name;
+            last_opener = i;
+            k_renamed = 0;
         }
     }
     if (max_name) *max_name = cluster_name;
+    if (info) {
+        info[0] = cluster_name;
+        info[1] = last_opener;
+        info[2] = last_opener >= 0 ? clusterIdxs[last_opener] : -1;
+        info[3] = last_opener >= 0 ? opened[clusterIdxs[last_opener]] : 0;
+        info[4] = k_renamed;
+        info[5] = merges;
+    }
     std::vector<int> names(clusterIdxs);
     std::sort(names.begin(), names.end());
     names.erase(std::unique(names.begin(), names.end()), names.end());
     std::memcpy(pt_cluster, clusterIdxs.data(), n * sizeof(int));
     return (int)names.size();
+}
+
+int oracle_cluster(const scvod_params* params, const scvod_apri* apri_vec_, int32_t n, int32_t* pt_cluster, int32_t* max_name) {
+    return cluster_and_create_frame(params, apri_vec_, n, pt_cluster, max_name, nullptr);
+}
+
+// ssc.cpp:354 `frame_ssc.max_name = cluster_name ++;`: max_name is the LAST USED running number K.  Returns the smallest
+// point index of the cluster that carries K when clusterAndCreateFrame ends (its canonical name in the product's naming), or
+// -1 when no point carries K any more; info[6] as documented at cluster_and_create_frame.
+int oracle_cluster_last_name(const scvod_params* params, const scvod_apri* apri_vec_, int32_t n, int64_t* info) {
+    std::vector<int32_t> cl(n ? n : 1);
+    int32_t K = 4;
+    cluster_and_create_frame(params, apri_vec_, n, cl.data(), &K, info);
+    for (int i = 0; i < n; ++i)
+        if (cl[i] == K) return i;
+    return -1;
 }
 
 // refineClusterByBoundingBox (ssc.cpp:437-467) + the bounding-box branch of recognize (ssc.cpp:849-872, features of

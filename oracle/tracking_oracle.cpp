@@ -30,11 +30,18 @@ struct VoxelT {
 };
 struct ClusterT {
     int track_id = -1, name = -1, type = -1, state = -1;
+    int order = 0;  // walk position for the `ordered` mode: the name for a frame's own clusters, 2^30 + creation number for the ones a call made
     std::vector<int> occupy_pts, occupy_voxels;
     std::vector<P3> cloud;
 };
 struct FrameT {
     int max_name = 0;
+    // LITERAL max_name (ssc.cpp:354 `frame_ssc.max_name = cluster_name ++;` stores the LAST USED running number K, not
+    // K + 1): collide_name = the name, in the names this frame was built with, of the cluster that still carries running
+    // number K when clusterAndCreateFrame ends, or -1 when K was merged away (mergeClusters renames oc -> nc).
+    int collide_name = -1;
+    bool literal = false, first_name_used = false;
+    int created = 0;
     std::vector<P3> cloud_use;
     std::unordered_map<int, VoxelT> hash_cloud;
     std::unordered_map<int, ClusterT> cluster_set;
@@ -70,7 +77,7 @@ void toy_segment(FrameT& f, int car, int tree) {
         int name = 5 + (v.range_idx / 6) * 64 + (v.sector_idx / 12);
         v.label = name;
         ClusterT& c = f.cluster_set[name];
-        c.name = name;
+        c.name = c.order = name;
         c.occupy_voxels.push_back(key);
         c.occupy_pts.insert(c.occupy_pts.end(), v.ptIdx.begin(), v.ptIdx.end());
     }
@@ -104,6 +111,29 @@ float getPolarAngle(const P3& p) {
 }
 float getAzimuth(const P3& p) { return rad2deg_f((float)atan2f(p.z, (float)pointDistance2d(p))); }
 
+// `cluster_new.name = frame_next_.max_name ++` (ssc.cpp:1357, :1401).  Literal mode: the first name a frame hands out is K
+// itself.  If cluster K is alive in cluster_set, `cluster_set.insert` at :1372 / :1419 is a no-op: the voxels were already
+// re-labelled K (:1366, :1417), the source clusters were reduced (:1364, :1370) or erased (:1411), and cluster_new -- the
+// split-off part or the fused car cluster -- is dropped: its points sit in no cluster any more and nothing walks it in the
+// next call, while cluster K keeps its own occupy_voxels / type / cloud and now answers for more voxels.  If K is not in
+// cluster_set (merged away during clustering, erased by refineClusterByBoundingBox, or erased by this very fuse) the insert
+// succeeds and the only difference to a fresh number is the name.
+int next_name(FrameT& f) {
+    if (f.literal && !f.first_name_used) {
+        f.first_name_used = true;
+        if (f.collide_name != -1) return f.collide_name;
+    }
+    f.first_name_used = true;
+    return f.max_name++;
+}
+long long g_literal[4];  // {splits whose insert was a no-op, fuses whose insert was a no-op, car clusters lost that way, their points}
+void insert_new(FrameT& f, ClusterT& cluster_new, bool fuse) {
+    cluster_new.order = (1 << 30) + f.created++;
+    if (f.cluster_set.insert(std::make_pair(cluster_new.name, cluster_new)).second) return;
+    g_literal[fuse ? 1 : 0]++;
+    if (fuse) g_literal[3] += (long long)cluster_new.occupy_pts.size();
+}
+
 // ordered: walk frame_pre_.cluster_set in ascending cluster name instead of the container's order (the reference's order
 // is the one of ITS names and ITS libstdc++, neither reproducible: DESIGN.md section 2); stats (optional): counters of
 // the branches taken, see oracle_sequence_tracking_stats.
@@ -116,7 +146,7 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
     int dynamic_num = 0;
     std::vector<std::pair<const int, ClusterT>*> walk;
     for (auto& c : frame_pre_.cluster_set) walk.push_back(&c);
-    if (ordered) std::sort(walk.begin(), walk.end(), [](auto* a, auto* b) { return a->first < b->first; });
+    if (ordered) std::sort(walk.begin(), walk.end(), [](auto* a, auto* b) { return a->second.order < b->second.order; });
     for (auto* cp : walk) {
         auto& c = *cp;
         if (c.second.type != car) continue;
@@ -187,7 +217,7 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
                     c.second.type = frame_next_.cluster_set[it->first].type;
                     ClusterT cluster_new;
                     cluster_new.track_id = c.second.track_id;
-                    cluster_new.name = frame_next_.max_name++;
+                    cluster_new.name = next_name(frame_next_);
                     cluster_new.type = frame_next_.cluster_set[it->first].type;
                     cluster_new.occupy_voxels = it->second;
                     reduceVec(frame_next_.cluster_set[it->first].occupy_voxels, cluster_new.occupy_voxels);
@@ -198,7 +228,7 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
                     }
                     for (int p : cluster_new.occupy_pts) cluster_new.cloud.push_back(frame_next_.cloud_use[p]);
                     reduceVec(frame_next_.cluster_set[it->first].occupy_pts, cluster_new.occupy_pts);
-                    frame_next_.cluster_set.insert(std::make_pair(cluster_new.name, cluster_new));
+                    insert_new(frame_next_, cluster_new, false);
                 }
             } else {
                 if (frame_next_.cluster_set[it->first].type == car) {
@@ -216,7 +246,7 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
             c.second.state = 0;
             ClusterT cluster_new;
             cluster_new.track_id = c.second.track_id;
-            cluster_new.name = frame_next_.max_name++;
+            cluster_new.name = next_name(frame_next_);
             cluster_new.type = car;
             for (auto& re : remap_name) {
                 if (frame_next_.cluster_set[re.first].type == car &&
@@ -225,12 +255,13 @@ int tracking(const scvod_params& P, FrameT& frame_pre_, FrameT& frame_next_, con
                     cluster_new.occupy_pts.insert(cluster_new.occupy_pts.end(), src.occupy_pts.begin(), src.occupy_pts.end());
                     cluster_new.occupy_voxels.insert(cluster_new.occupy_voxels.end(), src.occupy_voxels.begin(), src.occupy_voxels.end());
                     if (stats) stats[9]++;
+                    if (frame_next_.literal && re.first != cluster_new.name && frame_next_.cluster_set.count(cluster_new.name)) g_literal[2]++;
                     frame_next_.cluster_set.erase(re.first);
                 }
             }
             for (int p : cluster_new.occupy_pts) cluster_new.cloud.push_back(frame_next_.cloud_use[p]);
             for (auto& v : cluster_new.occupy_voxels) frame_next_.hash_cloud[v].label = cluster_new.name;
-            frame_next_.cluster_set.insert(std::make_pair(cluster_new.name, cluster_new));
+            insert_new(frame_next_, cluster_new, true);
         }
     }
     return dynamic_num;
@@ -252,10 +283,11 @@ void build_frame_seg(const scvod_params& P, const scvod_apri* apri, int n, const
         kv.second.label = pt_type[first] == -1 ? -1 : pt_cluster[first];
     }
     for (int i = 0; i < n; ++i) {
+        if (pt_cluster[i] > max_name) max_name = pt_cluster[i];  // (fresh numbers must stay clear of an erased cluster's name too)
         if (pt_type[i] == -1) continue;
         ClusterT& c = f.cluster_set[pt_cluster[i]];
         if (c.name == -1) {
-            c.name = pt_cluster[i];
+            c.name = c.order = pt_cluster[i];
             c.type = pt_type[i];
             if (c.name > max_name) max_name = c.name;
         }
@@ -407,13 +439,18 @@ int oracle_track_decide(const scvod_params* params, const scvod_apri* apri_a, in
 // (the clusters of one pair still see each other's re-labelling).  chain == 2: every cluster on its own against the
 // untouched successor (first-order; the device path).  pt_dyn per apri point: 1 = member of a cluster with state == 1 after the loop
 // (saveSegCloud's dynamic_pt, ssc.cpp:479-481), 2 = in no cluster, 0 otherwise.
-int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
-                             const int32_t* pt_cluster, const int32_t* pt_type, const float* poses, int32_t car, int32_t chain,
-                             uint8_t* pt_dyn, int32_t* dynamic_clusters) {
+static int sequence_tracking(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
+                             const int32_t* pt_cluster, const int32_t* pt_type, const int32_t* collide, const float* poses, int32_t car,
+                             int32_t chain, uint8_t* pt_dyn, int32_t* dynamic_clusters) {
     const scvod_params& P = *params;
     std::vector<FrameT> frames(n_scans);
-    for (int s = 0; s < n_scans; ++s)
+    for (int s = 0; s < n_scans; ++s) {
         build_frame_seg(P, apri + offs[s], offs[s + 1] - offs[s], pt_cluster + offs[s], pt_type + offs[s], frames[s]);
+        if (collide) {
+            frames[s].literal = true;
+            frames[s].collide_name = collide[s];
+        }
+    }
     int name = 0, dyn = 0;
     for (int i = 0; i + 1 < n_scans; ++i) {
         if (chain == 2) {  // every cluster on its own against the untouched successor (what the device computes)
@@ -438,6 +475,27 @@ int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri,
     for (int s = 0; s < n_scans; ++s) dyn_of_frame(frames[s], offs[s + 1] - offs[s], pt_type + offs[s], pt_dyn + offs[s]);
     if (dynamic_clusters) *dynamic_clusters = dyn;
     return 0;
+}
+
+int oracle_sequence_tracking(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
+                             const int32_t* pt_cluster, const int32_t* pt_type, const float* poses, int32_t car, int32_t chain,
+                             uint8_t* pt_dyn, int32_t* dynamic_clusters) {
+    return sequence_tracking(params, apri, offs, n_scans, pt_cluster, pt_type, nullptr, poses, car, chain, pt_dyn, dynamic_clusters);
+}
+
+// The same loop with the reference's LITERAL `max_name` (ssc.cpp:354: the last USED running number K, so the first
+// `max_name ++` of every frame hands out K again, ssc.cpp:1357 / :1401).  collide[s] = name (in pt_cluster's names) of the
+// cluster of scan s that carries running number K when clusterAndCreateFrame ends, -1 if none does
+// (oracle_cluster_last_name).  literal_stats[4] (optional): {split-offs dropped by the no-op insert, fuses dropped, car
+// clusters that left cluster_set that way, their points}.
+int oracle_sequence_tracking_literal(const scvod_params* params, const scvod_apri* apri, const int32_t* offs, int32_t n_scans,
+                                     const int32_t* pt_cluster, const int32_t* pt_type, const int32_t* collide, const float* poses,
+                                     int32_t car, int32_t chain, uint8_t* pt_dyn, int32_t* dynamic_clusters, int64_t* literal_stats) {
+    for (auto& v : g_literal) v = 0;
+    const int rc = sequence_tracking(params, apri, offs, n_scans, pt_cluster, pt_type, collide, poses, car, chain, pt_dyn, dynamic_clusters);
+    if (literal_stats)
+        for (int k = 0; k < 4; ++k) literal_stats[k] = g_literal[k];
+    return rc;
 }
 
 
@@ -497,7 +555,7 @@ int oracle_time_sequence(const scvod_params* params, const float* xyzi, const in
             if (ty[i] == -1) continue;
             ClusterT& c = f.cluster_set[cl[i]];
             if (c.name == -1) {
-                c.name = cl[i];
+                c.name = c.order = cl[i];
                 c.type = ty[i];
                 if (c.name > max_name) max_name = c.name;
             }

@@ -128,6 +128,13 @@ class Oracle:
         nc = self.lib.oracle_cluster(C.byref(params), _p(a), n, _p(out), C.byref(mx))
         return out[:n], nc, mx.value
 
+    def cluster_last_name(self, params, apri):
+        """canonical name (smallest point index) of the cluster that carries Frame::max_name as ssc.cpp:354 stores it, or -1;
+        info = {K, opener of K, final number of the opener's cluster, openers in it, renames of K, merges}"""
+        a = np.ascontiguousarray(apri)
+        info = np.zeros(6, np.int64)
+        return int(self.lib.oracle_cluster_last_name(C.byref(params), _p(a), a.shape[0], _p(info))), info
+
     def cluster_types(self, params, apri, pt_cluster, car_label=2, other_label=1):
         a = np.ascontiguousarray(apri)
         c = np.ascontiguousarray(pt_cluster, np.int32)
@@ -195,6 +202,21 @@ class Oracle:
         self.lib.oracle_sequence_tracking(C.byref(params), _p(a), _p(o), len(o) - 1, _p(cl), _p(ty), _p(ps), car, int(chain),
                                           _p(dyn), C.byref(nd))
         return dyn[:len(a)], nd.value
+
+    def sequence_tracking_literal(self, params, apri, offs, pt_cluster, pt_type, collide, poses, car=2, chain=3):
+        """SSC::segDF's loop with the reference's literal max_name (ssc.cpp:354, 1357, 1401); collide[s] from cluster_last_name"""
+        a = np.ascontiguousarray(apri)
+        o = np.ascontiguousarray(offs, np.int32)
+        cl, ty = np.ascontiguousarray(pt_cluster, np.int32), np.ascontiguousarray(pt_type, np.int32)
+        co = np.ascontiguousarray(collide, np.int32)
+        assert len(co) == len(o) - 1
+        ps = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        dyn = np.zeros(max(len(a), 1), np.uint8)
+        nd = C.c_int32()
+        st = np.zeros(4, np.int64)
+        self.lib.oracle_sequence_tracking_literal(C.byref(params), _p(a), _p(o), len(o) - 1, _p(cl), _p(ty), _p(co), _p(ps), car,
+                                                  int(chain), _p(dyn), C.byref(nd), _p(st))
+        return dyn[:len(a)], nd.value, st
 
     def time_sequence(self, params, xyzi, offsets, poses, car=2, other=1, want_labels=True):
         a = np.ascontiguousarray(xyzi, np.float32)

@@ -1,0 +1,89 @@
+"""Frame::max_name as the reference stores it (ssc.cpp:354: the LAST USED running number K): which cluster of a scan still
+carries K when clusterAndCreateFrame ends.  Device (csrc/scvod_lastname.hip, through the C-ABI) against the oracle's literal
+loop (oracle_cluster_last_name), and the tracking chain with that name handed out first (ssc.cpp:1357, :1401) against the
+oracle's literal chain."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(scvod, preset, kind, seq, first, count, stride=1):
+    import synth
+    import torch
+    P = scvod.make_params(preset)
+    scans = [synth.make_scan(seq, first + k * stride, kind, device="cuda") for k in range(count)]
+    d = torch.cat([sc[0] for sc in scans]).contiguous()
+    offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int32)
+    poses = np.asarray([sc[2] for sc in scans], np.float32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    return P, ctx, d, offs, poses
+
+
+@pytest.mark.parametrize("kind,preset,count,stride,first", [("K64", "semantickitti", 60, 7, 300), ("PARK", "parkinglot", 80, 3, 30),
+                                                           ("OS128", "os128_fine", 12, 17, 700)])
+def test_last_name_equals_the_literal_loop(scvod, oracle, kind, preset, count, stride, first):
+    P, ctx, d, offs, poses = _batch(scvod, preset, kind, 5, first, count, stride)
+    ln, st = ctx.batch_cluster_last_name(count)
+    alive = exact = 0
+    for s in range(count):
+        r = ctx.batch_fetch(s)
+        names = ctx.batch_fetch_clusters(s, r["n_apri"])
+        want, info = oracle.cluster_last_name(P, r["apri"])
+        if ln[s, 2] != 0:
+            continue  # reported unknown (counted below)
+        exact += 1
+        assert ln[s, 0] == want, f"{kind} scan {s}: device says cluster {ln[s, 0]} carries max_name, the literal loop {want} (info {info})"
+        if want >= 0:
+            alive += 1
+            assert names[want] == want
+            u = ln[s, 1]
+            assert 0 <= u < r["n_voxels"] and names[r["vox_pts"][r["vox_pt_begin"][u]]] == want
+    assert exact >= count - 1 and st["unknown_too_large"] + st["unknown_irregular"] == count - exact
+    assert alive > 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind,preset,skip,count,first", [("K64", "semantickitti", 5, 120, 300), ("PARK", "parkinglot", 1, 200, 30),
+                                                         ("OS128", "os128_fine", 5, 50, 700)])
+def test_chain_with_the_literal_max_name(scvod, oracle, kind, preset, skip, count, first):
+    """the device chain hands out K first, like `frame_next_.max_name ++` does: per-point bytes array_equal with the oracle's
+    literal chain; and the two readings of max_name differ on these sequences (the test would not notice otherwise)"""
+    P, ctx, d, offs, poses = _batch(scvod, preset, kind, 5, first, count, skip)
+    res = [ctx.batch_fetch(s) for s in range(count)]
+    names = [ctx.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(count)]
+    types = [ctx.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(count)]
+    ln, st = ctx.batch_cluster_last_name(count)
+    assert st["unknown_too_large"] + st["unknown_irregular"] == int((ln[:, 2] != 0).sum())
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    assert ctx.batch_track_stats()["error_bits"] == 0
+    tr = [ctx.batch_fetch_track(s) for s in range(count)]
+    got = np.concatenate([t["pt_dyn"] for t in tr])
+    apri = np.concatenate([r["apri"] for r in res])
+    ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
+    nm, ty = np.concatenate(names), np.concatenate(types)
+    # the oracle's own reading of which cluster carries K, scan by scan; where the device reported "unknown" the chain used none
+    collide = np.asarray([oracle.cluster_last_name(P, r["apri"])[0] for r in res], np.int32)
+    known = ln[:, 2] == 0
+    assert np.array_equal(ln[known, 0], collide[known])
+    collide[~known] = -1
+    dynL, ndL, lit = oracle.sequence_tracking_literal(P, apri, ao, nm, ty, collide, poses, chain=3)
+    assert np.array_equal(got, dynL), f"{int((got != dynL).sum())} of {len(dynL)} per-point bytes differ from the literal chain"
+    assert sum(t["n_dynamic_clusters"] for t in tr) == ndL
+    dyn3, nd3 = oracle.sequence_tracking(P, apri, ao, nm, ty, poses, chain=3)
+    if kind != "OS128":
+        assert int((dyn3 != dynL).sum()) > 0 and lit[0] + lit[1] > 0
+    # fresh numbers on request: the chain of rounds 1-3
+    ctx.set_max_name_literal(False)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    ctx.batch_track(T)
+    got0 = np.concatenate([ctx.batch_fetch_track(s)["pt_dyn"] for s in range(count)])
+    assert np.array_equal(got0, dyn3)
+    ctx.close()
