@@ -222,6 +222,8 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cc_last = k.take<int32_t>(B * 4);
     A.cc_redo = k.take<int32_t>(B + 1);
     A.ln_stats = k.take<int32_t>(4);
+    A.ln_prof = k.take<int32_t>(B * 8);
+    A.ln_prof2 = k.take<int32_t>(B * 8);
     A.vg_par = k.take<int32_t>(B * 16);
     A.vg_range = k.take<int32_t>(2);  // [0] largest cell-index range of the batch, [1] bin shift of the bucket table
     A.vg_outoff = k.take<int32_t>(B + 1);
@@ -1258,6 +1260,15 @@ int scvod_batch_cluster_last_name(scvod_ctx* c, int32_t* h_out4, int32_t cap_sca
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy(h_out4, c->A.cc_last, sizeof(int32_t) * 4 * (size_t)c->A.n_scans, hipMemcpyDeviceToHost));
     if (h_stats4) HIPCHK(c, hipMemcpy(h_stats4, c->A.ln_stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (getenv("SCVOD_LN_PROF")) {  // development: phase clocks of the first scans
+        std::vector<int32_t> pr(8 * (size_t)c->A.n_scans);
+        HIPCHK(c, hipMemcpy(pr.data(), c->A.ln_prof, pr.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> pr2(pr.size());
+        HIPCHK(c, hipMemcpy(pr2.data(), c->A.ln_prof2, pr2.size() * 4, hipMemcpyDeviceToHost));
+        for (int s = 0; s < c->A.n_scans && s < 64; ++s)
+            fprintf(stderr, "ln_big scan %d: nodes %d rounds %d build %d jacobi %d open %d cc %d walk %d events %d\n", s, pr2[8 * s], pr2[8 * s + 1], pr2[8 * s + 2], pr2[8 * s + 3], pr2[8 * s + 4], pr2[8 * s + 5], pr2[8 * s + 6], pr2[8 * s + 7]),
+            fprintf(stderr, "ln_prof scan %d: setup %d A+irr.. CL %d cand %d marked %d (x10ns) n_cand %d n_mk %d n_irr %d cap %d\n", s, pr[8 * s], pr[8 * s + 1], pr[8 * s + 2], pr[8 * s + 3], pr[8 * s + 4], pr[8 * s + 5], pr[8 * s + 6], pr[8 * s + 7]);
+    }
     return c->A.n_scans;
 }
 

@@ -126,6 +126,8 @@ struct Arena {
     int32_t* cc_last;         // [B][4] {canonical name or -1, lowest voxel slot whose first point belongs to it or -1,
                               //         status: 0 exact, 1 a replay did not fit the LDS, 2 too many index triples outside the grid, events replayed}
     int32_t* cc_redo;         // [B + 1] scans handed to the second pass (larger tables), [B] = how many
+    int32_t* ln_prof;         // [B][8] phase clocks (10 ns ticks) and counts of the last pass over a scan: tools/lastname_lat.py
+    int32_t* ln_prof2;        // [B][8] the largest class walked: nodes, Jacobi rounds, clocks of build / rounds / openers / partition / walk, events
     int32_t* ln_stats;        // [4] per clustering call: scans with status 1, with status 2, 0, 0
     // sequence differencing on the device (scvod_batch_track, scvod_track.hip)
     int4* vox_track;          // [N] per voxel: {key, label = cluster root of its points or -1, |occupy_voxels| of that

@@ -31,8 +31,7 @@ namespace scvod {
 
 namespace {
 
-constexpr int kLnThreads = 256;
-constexpr int kLnWaves = kLnThreads / 64;
+constexpr int kLnMaxWaves = 16;
 constexpr int kLnIrr = 256;       // index triples outside the grid handled per scan (a 128-beam scan holds 36)
 constexpr int kLnPairs = 1024;    // links between clusters that such points create
 constexpr int kLnNames = 512;     // distinct cluster names in those links
@@ -66,6 +65,7 @@ struct Ln {  // per-scan view
     // LDS
     int32_t* skey;
     int sshift, ns;
+    const int32_t* lkeys;  // all voxel keys in LDS while a class's lists are built (nullptr: sampled keys + the table in HBM)
     int32_t* irr_pt;    // [kLnIrr] sorted by point
     int32_t* irr_home;  // voxel slot
     int32_t* irr_cls;   // closure class
@@ -107,6 +107,37 @@ __device__ __forceinline__ int slot_of_key(const Ln& L, int key) {
             b = mid;
     }
     return (a < L.nv && L.vkey[a] == key) ? a : -1;
+}
+// first voxel slot whose key is >= key
+__device__ __forceinline__ int lower_slot(const Ln& L, int key) {
+    if (L.lkeys) {
+        int a = 0, b = L.nv;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (L.lkeys[mid] < key)
+                a = mid + 1;
+            else
+                b = mid;
+        }
+        return a;
+    }
+    int lo = 0, hi = L.ns;  // first sample >= key
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.skey[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    int a = lo == 0 ? 0 : ((lo - 1) << L.sshift) + 1, b = lo >= L.ns ? L.nv : min(lo << L.sshift, L.nv);
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (L.vkey[mid] < key)
+            a = mid + 1;
+        else
+            b = mid;
+    }
+    return a;
 }
 __device__ __forceinline__ int slot_of_cell(const Ln& L, int r, int s, int a) {
     if (!in_grid(L, r, s, a)) return -1;
@@ -154,6 +185,7 @@ template <int CAP>
 struct Rp {  // tables of one class (LDS unless said otherwise)
     int32_t* T;      // [CAP] voxel node: time of the visit that labelled it FULLY, kInf never
     int32_t* fa;     // [CAP] voxel node: its first point (of any kind), kInf for the nodes of irregular points
+    int32_t* Tn;     // [CAP] next round's times
     int32_t* par;    // [CAP] classes at / after the last opener
     uint8_t* fl;     // [CAP]
     int16_t* inext;  // [kLnIrr] next irregular point of the same voxel
@@ -163,7 +195,7 @@ struct Rp {  // tables of one class (LDS unless said otherwise)
     int32_t* ev_x;   // [kLnChunk]
     // arena scratch
     int16_t* rows;   // [nodes][32] listed nodes in findVoxelNeighbors order (ssc.cpp:400-410: range outermost, azimuth innermost), -1 none
-    int32_t* Tn;     // [nodes] next round's times
+    int32_t* ev3;    // [nodes][3] times of a node's visits
     int32_t* ifirst; // [nodes] voxel node -> its first irregular point of this class (index into the scan's irr list), -1
 };
 
@@ -174,6 +206,7 @@ struct RpOut {
     int slot;        // lowest voxel slot whose first point belongs to it
     int n_events;    // events walked one by one (after the last opener)
     int too_big;
+    int nodes, rounds, c_build, c_jacobi, c_open, c_cc, c_walk;  // development: size, Jacobi rounds, phase clocks (10 ns)
 };
 
 template <int CAP>
@@ -191,19 +224,30 @@ __device__ __forceinline__ int rp_find_ro(const Rp<CAP>& T, int x) {
     while ((p = __hip_atomic_load(&T.par[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != x) x = p;
     return x;
 }
-// concurrent union (the partition at the time of the last opener: names do not matter there)
+// concurrent union-find for the partition at the time of the last opener (names do not matter there): a root is hooked under
+// a SMALLER root, so parents only decrease and path halving by plain stores is safe
 template <int CAP>
-__device__ __forceinline__ void rp_union(const Rp<CAP>& T, int a, int b) {
+__device__ __forceinline__ int rp_find_c(const Rp<CAP>& T, int x) {
     for (;;) {
-        a = rp_find_ro(T, a);
-        b = rp_find_ro(T, b);
-        if (a == b) return;
+        const int p = __hip_atomic_load(&T.par[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p == x) return x;
+        const int g = __hip_atomic_load(&T.par[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (g != p) __hip_atomic_store(&T.par[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        x = p;
+    }
+}
+template <int CAP>
+__device__ __forceinline__ int rp_union(const Rp<CAP>& T, int a, int b) {  // returns the common root
+    for (;;) {
+        a = rp_find_c(T, a);
+        b = rp_find_c(T, b);
+        if (a == b) return a;
         if (a < b) {
             const int t = a;
             a = b;
             b = t;
         }
-        if (atomicCAS(&T.par[a], a, b) == a) return;
+        if (atomicCAS(&T.par[a], a, b) == a) return b;
     }
 }
 // the visiting point (class oc, -1 = no label yet) meets the points of voxel k in index order (ssc.cpp:322-340); kroot: the
@@ -252,45 +296,76 @@ __device__ __forceinline__ void rp_meet(const Ln& L, const Rp<CAP>& T, int& oc, 
     T.fl[k] |= F_FULL;
 }
 
-// what one visit does, given the labelling times: is the visitor labelled when it starts; q = first listed voxel that holds a
-// label (-1 none: the visit opens a cluster when the visitor carries none either).  The listed voxels from q on are joined.
+// what the visits of one node do, given the labelling times: is the visitor labelled when visit e starts (cs); q[e] = first
+// listed voxel that holds a label by then (-1 none: the visit opens a cluster when the visitor carries none either).  The listed
+// voxels from q on are joined.  One walk over the list serves the node's (up to three) visits.
 template <int CAP>
-__device__ __forceinline__ void rp_visit(const Rp<CAP>& T, const int16_t* row16, int home, int t, bool optimistic, bool& cs, int& q, int (&nb)[27]) {
+__device__ __forceinline__ void rp_visit3(const Rp<CAP>& T, const int16_t* row16, int home, const int (&ie)[3], bool optimistic, bool (&cs)[3],
+                                          int (&q)[3], int (&nb)[27]) {
     const uint4* row = reinterpret_cast<const uint4*>(row16);
     const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
     const unsigned w[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-    cs = optimistic || (home >= 0 && T.T[home] < t);
-    q = -1;
+    const int th = home >= 0 ? T.T[home] : kInf;
 #pragma unroll
-    for (int e = 0; e < 27; ++e) {
-        const int u = (int)(int16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-        nb[e] = u;
-        if (u >= 0 && q < 0 && (T.T[u] < t || T.fa[u] < t)) q = e;
+    for (int e = 0; e < 3; ++e) {
+        cs[e] = ie[e] != kInf && (optimistic || th < ie[e]);
+        q[e] = -1;
+    }
+#pragma unroll
+    for (int p = 0; p < 27; ++p) {
+        const int u = (int)(int16_t)((w[p >> 1] >> ((p & 1) * 16)) & 0xffffu);
+        nb[p] = u;
+        if (u >= 0) {
+            const int lab = min(T.T[u], T.fa[u]);  // labelled before time t <=> lab < t
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (q[e] < 0 && lab < ie[e] && ie[e] != kInf) q[e] = p;
+        }
     }
 }
 
-// Class `cls`: the time of its last opener; and, when that is later than `t_beat`, whether the cluster this point ends in still
+// The classes of `set` together (classes never list each other, so walking several at once is walking each): the time of
+// their last opener; and, when that is later than `t_beat`, whether the cluster this point ends in still
 // carries the number it created.  All threads of the workgroup.
 //   1. labelling times by Jacobi rounds over the class's visits (the fixed point is the sequential loop's: a time depends on
 //      earlier times only), 2. openers = visits that start without a label and find none, 3. the partition right after the
 //      last opener = unions of what every visit up to it joined, 4. the visits after it walked one by one (ssc.cpp:322-350).
-template <int CAP>
-__device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat, int* wsum, int* bc) {
+template <int CAP, int TH>
+__device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int n_set, int t_beat, int* wsum, int* bc) {
+    auto in_set = [&](int c) {
+        for (int t = 0; t < n_set; ++t)
+            if (set[t] == c) return true;
+        return false;
+    };
     const int tid = threadIdx.x;
-    RpOut out = {-1, 0, -1, -1, 0, 0};
-    // ---- nodes: the class's voxels in slot order, then its irregular points ----
-    int m = 0;
-    for (int v0 = 0; v0 < L.nv; v0 += kLnThreads) {
+    RpOut out = {-1, 0, -1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long ck = wall_clock64();
+    auto lap = [&](int& dst) {
+        const long long now = wall_clock64();
+        dst = (int)(now - ck);
+        ck = now;
+    };
+    // ---- nodes: the class's voxels (any order), then its irregular points ----
+    if (tid == 0) bc[0] = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < L.nv; v0 += TH) {
         const int v = v0 + tid;
-        const int in = (v < L.nv && L.vcl[v] == cls) ? 1 : 0;
-        int total;
-        const int ex = block_excl_scan<kLnThreads>(in, total, wsum);
-        if (in && m + ex < CAP) {
-            L.cvl[m + ex] = v;
-            L.loc[v] = m + ex;
+        const bool in = v < L.nv && in_set(L.vcl[v]);
+        const unsigned long long mask = __ballot(in);
+        if (mask) {
+            const int lane = tid & 63, lead = __ffsll((long long)mask) - 1;
+            int b0 = 0;
+            if (lane == lead) b0 = atomicAdd(&bc[0], __popcll(mask));
+            b0 = __shfl(b0, lead);
+            const int at = b0 + __popcll(mask & ((1ull << lane) - 1ull));
+            if (in && at < CAP) {
+                L.cvl[at] = v;
+                L.loc[v] = at;
+            }
         }
-        m += total;
     }
+    __syncthreads();
+    const int m = bc[0];
     __syncthreads();
     if (tid == 0) {
         int nn = m;
@@ -298,26 +373,23 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
             T.inode[j] = -1;
             T.inext[j] = -1;
             T.ivis[j] = 0;
-            if (L.irr_cls[j] == cls) T.inode[j] = (int16_t)min(nn++, CAP - 1);
+            if (in_set(L.irr_cls[j])) T.inode[j] = (int16_t)min(nn++, CAP - 1);
         }
         bc[0] = nn;
     }
     __syncthreads();
     const int nn = bc[0];
     auto leave = [&]() {
-        for (int l = tid; l < min(m, CAP); l += kLnThreads) L.loc[L.cvl[l]] = -1;
+        for (int l = tid; l < min(m, CAP); l += TH) L.loc[L.cvl[l]] = -1;
         __syncthreads();
     };
-    if (nn > CAP || m > CAP || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || nn > L.n_raw) {  // does not fit
+    if (nn > CAP || m > CAP || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || 3 * nn > L.n_raw) {  // does not fit
         leave();
         out.too_big = 1;
         return out;
     }
-    for (int x = tid; x < nn; x += kLnThreads) {
-        T.T[x] = kInf;
-        T.fa[x] = x < m ? L.fp[L.cvl[x]] : kInf;
-        if (L.irregular) T.ifirst[x] = -1;
-    }
+    if (L.irregular)
+        for (int x = tid; x < nn; x += TH) T.ifirst[x] = -1;
     __syncthreads();
     if (tid == 0 && L.n_irr > 0) {  // per voxel: its irregular points of this class in index order (irr_pt is sorted)
         for (int j = L.n_irr - 1; j >= 0; --j) {
@@ -335,75 +407,114 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
         while (T.inode[j] != x) ++j;
         return j;
     };
-    // ---- lists: 27 cells around a voxel's own cell / around an irregular point's triple ----
-    for (int w = tid; w < nn * 32; w += kLnThreads) {
-        const int x = w >> 5, pos = w & 31;
-        int node = -1;
-        if (pos < 27) {
-            int r, s, a;
+    // ---- lists: 27 cells around a voxel's own cell / around an irregular point's triple, found row by row (the three
+    // sectors of a (range, azimuth) pair are consecutive keys: one search, then the records behind it) ----
+    {
+        const bool keys_fit = nn >= 96 && (size_t)L.nv * 4 <= (size_t)CAP * 16;  // (T / fa / Tn / par are not in use yet)
+        int32_t* lk = T.T;
+        if (keys_fit)
+            for (int v = tid; v < L.nv; v += TH) lk[v] = L.vkey[v];
+        __syncthreads();
+        Ln Lk = L;
+        Lk.lkeys = keys_fit ? lk : nullptr;
+        const int32_t* kk = keys_fit ? lk : L.vkey;
+        for (int w = tid; w < nn * 9; w += TH) {
+            const int x = w / 9, rw = w - x * 9;
+            const int dx = rw / 3 - 1, dz = rw % 3 - 1;
+            int r, s3, a;
             bool ok;
             if (x < m) {
-                ok = cell_of_voxel(L, L.cvl[x], r, s, a);
+                ok = cell_of_voxel(L, L.cvl[x], r, s3, a);
             } else {
-                decode3(L.idx3[L.irr_pt[irr_of_node(x)]], r, s, a);
+                decode3(L.idx3[L.irr_pt[irr_of_node(x)]], r, s3, a);
                 ok = true;
             }
-            if (ok) {
-                const int dx = pos / 9 - 1, dy = (pos / 3) % 3 - 1, dz = pos % 3 - 1;
-                const int k = slot_of_cell(L, r + dx, s + dy, a + dz);
-                if (k >= 0) node = L.loc[k];  // (closure: a listed voxel belongs to the lister's class)
+            int16_t* row = T.rows + (size_t)x * 32;
+            int got[3] = {-1, -1, -1};
+            const int rr = r + dx, aa = a + dz;
+            if (ok && rr >= 0 && rr < L.R && aa >= 0 && aa < L.Az) {
+                const int s_lo = max(s3 - 1, 0), s_hi = min(s3 + 1, L.S - 1);
+                if (s_lo <= s_hi) {
+                    const int k_lo = aa * L.R * L.S + rr * L.S + s_lo, k_hi = k_lo + (s_hi - s_lo);
+                    for (int j = lower_slot(Lk, k_lo); j < L.nv; ++j) {
+                        const int key = kk[j];
+                        if (key > k_hi) break;
+                        got[key - k_lo + (s_lo - (s3 - 1))] = L.loc[j];  // (closure: a listed voxel belongs to the lister's class)
+                    }
+                }
             }
+            for (int dy = 0; dy < 3; ++dy) row[(dx + 1) * 9 + dy * 3 + (dz + 1)] = (int16_t)got[dy];
+            if (rw == 0)
+                for (int pad = 27; pad < 32; ++pad) row[pad] = -1;
         }
-        T.rows[w] = (int16_t)node;
+        __syncthreads();
     }
-    __syncthreads();
-    // the visits of node x: a voxel's first three regular points, an irregular point itself; `home` = the voxel whose full
-    // labelling labels the visitor before it starts
-    auto visits_of = [&](int x, int (&ie)[3], int& home) {
-        ie[0] = ie[1] = ie[2] = kInf;
+    for (int x = tid; x < nn; x += TH) {
+        T.T[x] = kInf;
+        T.fa[x] = x < m ? L.fp[L.cvl[x]] : kInf;
+    }
+    // the visits of node x: a voxel's first three regular points, an irregular point itself (cached); `home` = the voxel whose
+    // full labelling labels the visitor before it starts
+    for (int x = tid; x < nn; x += TH) {
+        int ie[3] = {kInf, kInf, kInf};
         if (x < m) {
             const int v = L.cvl[x];
             for (int e = 0; e < 3; ++e) {
                 ie[e] = reg_of(L, v, e);
                 if (ie[e] == kInf) break;
             }
+        } else {
+            ie[0] = L.irr_pt[irr_of_node(x)];
+        }
+        for (int e = 0; e < 3; ++e) T.ev3[3 * x + e] = ie[e];
+    }
+    __syncthreads();
+    auto visits_of = [&](int x, int (&ie)[3], int& home) {
+        for (int e = 0; e < 3; ++e) ie[e] = T.ev3[3 * x + e];
+        if (x < m) {
             home = x;
         } else {
-            const int j = irr_of_node(x);
-            ie[0] = L.irr_pt[j];
-            const int hv = L.irr_home[j];
+            const int hv = L.irr_home[irr_of_node(x)];
             home = hv >= 0 ? L.loc[hv] : -1;
         }
     };
+    out.nodes = nn;
+    lap(out.c_build);
     // ---- 1. labelling times ----
     bool converged = false;
     for (int round = 0; round < 96 && !converged; ++round) {
-        for (int x = tid; x < nn; x += kLnThreads) T.Tn[x] = kInf;
+        for (int x = tid; x < nn; x += TH) T.Tn[x] = kInf;
         __syncthreads();
-        for (int x = tid; x < nn; x += kLnThreads) {
-            int ie[3], home;
+        for (int x = tid; x < nn; x += TH) {
+            int ie[3], home, q[3], nb[27];
+            bool cs[3];
             visits_of(x, ie, home);
-            for (int e = 0; e < 3 && ie[e] != kInf; ++e) {
-                bool cs;
-                int q, nb[27];
-                // round 0 starts from the optimistic end (every visit labels its whole list): any start reaches the same fixed
-                // point, this one in fewer rounds than "nothing is ever labelled"
-                rp_visit(T, T.rows + (size_t)x * 32, home, ie[e], round == 0, cs, q, nb);
-                const int from = (cs || q < 0) ? 0 : q;
+            if (ie[0] == kInf) continue;
+            // round 0 starts from the optimistic end (every visit labels its whole list): any start reaches the same fixed
+            // point, this one in fewer rounds than "nothing is ever labelled"
+            rp_visit3(T, T.rows + (size_t)x * 32, home, ie, round == 0, cs, q, nb);
+            int from[3];
 #pragma unroll
-                for (int p = 0; p < 27; ++p)
-                    if (p >= from && nb[p] >= 0 && nb[p] < m) atomicMin(&T.Tn[nb[p]], ie[e]);
+            for (int e = 0; e < 3; ++e) from[e] = ie[e] == kInf ? 99 : ((cs[e] || q[e] < 0) ? 0 : q[e]);
+#pragma unroll
+            for (int p = 0; p < 27; ++p) {
+                const int u = nb[p];
+                if (u < 0 || u >= m) continue;
+                const int te = p >= from[0] ? ie[0] : (p >= from[1] ? ie[1] : (p >= from[2] ? ie[2] : kInf));  // the earliest visit that joins it
+                if (te < T.Tn[u]) atomicMin(&T.Tn[u], te);
             }
         }
         __syncthreads();
         int changed = 0;
-        for (int x = tid; x < m; x += kLnThreads) {
-            const int tv = __hip_atomic_load(&T.Tn[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int x = tid; x < m; x += TH) {
+            const int tv = T.Tn[x];
             changed |= tv != T.T[x];
             T.T[x] = tv;
         }
         converged = !__syncthreads_or(changed);
+        out.rounds = round + 1;
     }
+    lap(out.c_jacobi);
     if (!converged) {  // (never seen; reported like a class that does not fit)
         leave();
         out.too_big = 1;
@@ -412,59 +523,63 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
     // ---- 2. the last opener ----
     if (tid == 0) bc[1] = -1;
     __syncthreads();
-    for (int x = tid; x < nn; x += kLnThreads) {
-        int ie[3], home;
+    for (int x = tid; x < nn; x += TH) {
+        int ie[3], home, q[3], nb[27];
+        bool cs[3];
         visits_of(x, ie, home);
-        bool cs;
-        int q, nb[27];
-        if (ie[0] != kInf) {  // (only a voxel's first regular point or an irregular point can open a cluster)
-            rp_visit(T, T.rows + (size_t)x * 32, home, ie[0], false, cs, q, nb);
-            if (!cs && q < 0) atomicMax(&bc[1], ie[0]);
-        }
+        if (ie[0] == kInf) continue;
+        ie[1] = ie[2] = kInf;  // (only a voxel's first regular point or an irregular point can open a cluster)
+        rp_visit3(T, T.rows + (size_t)x * 32, home, ie, false, cs, q, nb);
+        if (!cs[0] && q[0] < 0) atomicMax(&bc[1], ie[0]);
     }
     __syncthreads();
     const int t_open = bc[1];
     out.last_open = t_open;
+    lap(out.c_open);
     if (t_open <= t_beat) {
         leave();
         return out;
     }
     // ---- 3. the partition right after the last opener's visit ----
-    for (int x = tid; x < nn; x += kLnThreads) T.par[x] = x;
+    for (int x = tid; x < nn; x += TH) T.par[x] = x;
     if (tid == 0) bc[2] = -1;
     __syncthreads();
-    for (int x = tid; x < nn; x += kLnThreads) {
-        int ie[3], home;
+    for (int x = tid; x < nn; x += TH) {
+        int ie[3], home, q[3], nb[27];
+        bool cs[3];
         visits_of(x, ie, home);
-        for (int e = 0; e < 3 && ie[e] <= t_open; ++e) {
-            bool cs;
-            int q, nb[27];
-            rp_visit(T, T.rows + (size_t)x * 32, home, ie[e], false, cs, q, nb);
-            const int from = (cs || q < 0) ? 0 : q;
-            if (ie[e] == t_open) bc[2] = x;
-            for (int p = from; p < 27; ++p) {
-                const int u = nb[p];
-                if (u < 0) continue;
-                rp_union(T, x, u);
-                if (L.irregular)
-                    for (int j = T.ifirst[u]; j >= 0; j = T.inext[j]) rp_union(T, u, T.inode[j]);
-            }
+        if (ie[0] > t_open) continue;
+        // what a later visit joins contains what the earlier ones joined (labels only spread): the last visit up to t_open decides
+        const int el = ie[2] <= t_open ? 2 : (ie[1] <= t_open ? 1 : 0);
+        if (ie[el] == t_open) bc[2] = x;
+        ie[0] = ie[el];
+        ie[1] = ie[2] = kInf;
+        rp_visit3(T, T.rows + (size_t)x * 32, home, ie, false, cs, q, nb);
+        const int from = (cs[0] || q[0] < 0) ? 0 : q[0];
+        int r = x;
+        for (int p = from; p < 27; ++p) {
+            const int u = nb[p];
+            if (u < 0) continue;
+            r = rp_union(T, r, u);
+            if (L.irregular)
+                for (int j = T.ifirst[u]; j >= 0; j = T.inext[j]) r = rp_union(T, r, T.inode[j]);
         }
     }
     __syncthreads();
-    for (int x = tid; x < nn; x += kLnThreads) {
+    for (int x = tid; x < nn; x += TH) {
         uint8_t f = 0;
         if (x < m) {
             if (T.T[x] <= t_open) f |= F_FULL;
-            if (reg_of(L, L.cvl[x], 0) <= t_open) f |= F_REGVIS;
+            if (T.ev3[3 * x] <= t_open) f |= F_REGVIS;
         } else {
             T.ivis[irr_of_node(x)] = L.irr_pt[irr_of_node(x)] <= t_open;
         }
         T.fl[x] = f;
     }
+    lap(out.c_cc);
     // ---- 4. the visits after it, in order ----
     int tmax = -1;
-    for (int x = tid; x < nn; x += kLnThreads) {
+    for (int x = tid; x < nn; x += TH) {
         int ie[3], home;
         visits_of(x, ie, home);
         for (int e = 0; e < 3 && ie[e] != kInf; ++e)
@@ -474,14 +589,14 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
     __syncthreads();
     if ((tid & 63) == 0) wsum[tid >> 6] = tmax;
     __syncthreads();
-    for (int w = 0; w < kLnWaves; ++w) tmax = max(tmax, wsum[w]);
+    for (int w = 0; w < (TH / 64); ++w) tmax = max(tmax, wsum[w]);
     __syncthreads();
     int n_ev = 0;
     if (tmax > t_open) {
         const int w_lo = (t_open + 1) >> 5, w_hi = tmax >> 5;
-        for (int w = w_lo + tid; w <= w_hi; w += kLnThreads) L.bits[w] = 0u;
+        for (int w = w_lo + tid; w <= w_hi; w += TH) L.bits[w] = 0u;
         __syncthreads();
-        for (int x = tid; x < nn; x += kLnThreads) {
+        for (int x = tid; x < nn; x += TH) {
             int ie[3], home;
             visits_of(x, ie, home);
             for (int e = 0; e < 3 && ie[e] != kInf; ++e)
@@ -491,11 +606,11 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
                 }
         }
         __syncthreads();
-        for (int w0 = w_lo; w0 <= w_hi; w0 += kLnThreads) {
+        for (int w0 = w_lo; w0 <= w_hi; w0 += TH) {
             const int w = w0 + tid;
             uint32_t word = (w <= w_hi) ? __hip_atomic_load(&L.bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             int total;
-            int o = n_ev + block_excl_scan<kLnThreads>(__popc(word), total, wsum);
+            int o = n_ev + block_excl_scan<TH>(__popc(word), total, wsum);
             while (word) {
                 const int b = __ffs((int)word) - 1;
                 word &= word - 1;
@@ -506,59 +621,120 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
         __syncthreads();
     }
     out.n_events = n_ev;
+    // One wave walks; lane p looks at the p-th listed voxel.  A visit whose list touches irregular points (or that IS one)
+    // takes the scalar routine; every other one reads flags and roots of its 27 voxels at once and only steps through the
+    // DISTINCT classes it meets, in list order (the neighbour's name wins each time, ssc.cpp:329).
     int kroot = -1;
-    if (tid == 0) {
-        kroot = rp_find(T, bc[2]);
-        bc[3] = 0;  // a visit after the "last" opener opened a cluster: the model is broken (never seen; reported as unknown)
-    }
+    if (tid < 64) kroot = rp_find_ro(T, bc[2]);
+    if (tid == 0) bc[3] = 0;  // a visit after the "last" opener opened a cluster: the model is broken (never seen; reported as unknown)
     for (int e0 = 0; e0 < n_ev; e0 += kLnChunk) {
         const int ce = min(kLnChunk, n_ev - e0);
         __syncthreads();
-        for (int e = tid; e < ce; e += kLnThreads) {
+        for (int e = tid; e < ce; e += TH) {
             const int i = __hip_atomic_load(&L.evl[e0 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             T.ev_t[e] = i;
             T.ev_x[e] = __hip_atomic_load(&L.evn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {
+            const int lane = tid;
+            auto wsync = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
             for (int e = 0; e < ce && kroot >= 0; ++e) {  // (once the number is gone nothing brings it back)
                 const int x = T.ev_x[e];
                 const bool reg = x < m;
-                int lv, jirr = -1;
-                if (reg) {
-                    lv = x;
-                } else {
-                    jirr = irr_of_node(x);
-                    const int hv = L.irr_home[jirr];
-                    lv = hv >= 0 ? L.loc[hv] : -1;
-                }
                 const int16_t* row = T.rows + (size_t)x * 32;
-                int nb[27];
-                for (int pos = 0; pos < 27; ++pos) nb[pos] = row[pos];
-                int oc = (lv >= 0 && (T.fl[lv] & F_FULL)) ? rp_find(T, lv) : -1;  // the visiting point's own label
-                for (int pos = 0; pos < 27; ++pos)
-                    if (nb[pos] >= 0) rp_meet(L, T, oc, nb[pos], kroot);
-                if (oc < 0) {
-                    bc[3] = 1;
-                    break;
+                const int k = lane < 27 ? (int)row[lane] : -1;
+                bool slow = !reg;
+                if (L.irregular && k >= 0) slow |= T.ifirst[k] >= 0;
+                if (__any(slow)) {  // every lane runs the same scalar walk (same values stored by all)
+                    int lv, jirr = -1;
+                    if (reg) {
+                        lv = x;
+                    } else {
+                        jirr = irr_of_node(x);
+                        const int hv = L.irr_home[jirr];
+                        lv = hv >= 0 ? L.loc[hv] : -1;
+                    }
+                    int oc = (lv >= 0 && (T.fl[lv] & F_FULL)) ? rp_find_ro(T, lv) : -1;  // the visiting point's own label
+                    for (int pos = 0; pos < 27; ++pos) {
+                        const int u = __shfl(k, pos);
+                        if (u >= 0) rp_meet(L, T, oc, u, kroot);
+                    }
+                    if (oc < 0) {
+                        bc[3] = 1;
+                        break;
+                    }
+                    if (reg) {
+                        if (!(T.fl[x] & (F_FULL | F_REGVIS))) {  // only the visited point carries the label: the voxel node holds its class
+                            const int r = rp_find_ro(T, x);
+                            if (r != oc) T.par[r] = oc;
+                        }
+                        T.fl[x] |= F_REGVIS;
+                    } else {
+                        const int r = rp_find_ro(T, x);
+                        if (r != oc) T.par[r] = oc;
+                        T.ivis[jirr] = 1;
+                    }
+                    wsync();
+                    continue;
                 }
-                if (reg) {
+                const bool valid = k >= 0;
+                const uint8_t f = valid ? T.fl[k] : (uint8_t)0;
+                const bool lab = valid && (f & (F_FULL | F_REGVIS));
+                int root = lab ? rp_find_ro(T, k) : -1;
+                int oc = (T.fl[x] & F_FULL) ? rp_find_ro(T, x) : -1;  // the visiting point's own label
+                const unsigned long long labm = __ballot(lab), valm = __ballot(valid);
+                unsigned long long joined = valm;
+                if (oc < 0) {
+                    if (!labm) {
+                        if (lane == 0) bc[3] = 1;
+                        break;
+                    }
+                    joined = valm & ~((1ull << (__ffsll((long long)labm) - 1)) - 1ull);  // the voxels before the first labelled one are left alone
+                }
+                unsigned long long todo = labm & joined;
+                while (todo) {
+                    const int b = __ffsll((long long)todo) - 1;
+                    const int c = __shfl(root, b);
+                    if (oc < 0) {
+                        oc = c;
+                    } else if (c != oc) {  // mergeClusters(oc, nc), ssc.cpp:329
+                        if (oc == kroot) kroot = -1;
+                        if (lane == 0) T.par[oc] = c;
+                        if (root == oc) root = c;
+                        oc = c;
+                    }
+                    todo &= ~__ballot(root == oc);
+                }
+                wsync();
+                const bool mine = (joined >> lane) & 1ull;
+                if (mine) {
+                    if (!lab) T.par[k] = oc;  // (an unlabelled voxel is a root of its own until now)
+                    T.fl[k] = f | F_FULL;
+                }
+                wsync();
+                if (lane == 0) {
                     if (!(T.fl[x] & (F_FULL | F_REGVIS))) {  // only the visited point carries the label: the voxel node holds its class
-                        const int r = rp_find(T, x);
+                        const int r = rp_find_ro(T, x);
                         if (r != oc) T.par[r] = oc;
                     }
                     T.fl[x] |= F_REGVIS;
-                } else {
-                    const int r = rp_find(T, x);
-                    if (r != oc) T.par[r] = oc;
-                    T.ivis[jirr] = 1;
                 }
+                wsync();
             }
         }
     }
+    if (tid == 0) bc[6] = kroot;
+    __syncthreads();
+    kroot = bc[6];
+    lap(out.c_walk);
     // ---- result ----
     if (tid == 0) {
-        bc[0] = kroot >= 0 ? rp_find(T, kroot) : -1;
+        bc[0] = kroot >= 0 ? rp_find_ro(T, kroot) : -1;
         bc[4] = kInf;  // canon
         bc[5] = kInf;  // slot
     }
@@ -572,7 +748,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
     out.fin = root >= 0;
     if (root >= 0) {
         int canon = kInf, slot = kInf;
-        for (int x = tid; x < nn; x += kLnThreads) {
+        for (int x = tid; x < nn; x += TH) {
             if (rp_find_ro(T, x) != root) continue;
             if (x < m) {
                 const int v = L.cvl[x];
@@ -597,7 +773,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, int cls, int t_beat
 
 template <int CAP>
 constexpr size_t ln_lds_bytes() {
-    return (size_t)CAP * (4 + 4 + 4 + 1) + kLnIrr * (2 + 2 + 1) + kLnChunk * 8  // tables of a class
+    return (size_t)CAP * (4 + 4 + 4 + 4 + 1) + kLnIrr * (2 + 2 + 1) + kLnChunk * 8  // tables of a class
            + kLnSamples * 4 + kLnIrr * 4 * 4 + kLnNames * 8 + 512;
 }
 
@@ -607,20 +783,21 @@ struct Blk {
     int32_t reg[125][3];  // its first three regular points
 };
 
-template <int CAP>
-__global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo,
+template <int CAP, int TH>
+__global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo,
                                                              int32_t* n_redo) {
     extern __shared__ __align__(16) unsigned char ln_smem[];
-    __shared__ int wsum[2 * kLnWaves + 2];
+    __shared__ int wsum[2 * kLnMaxWaves + 2];
     __shared__ int bc[8];
-    __shared__ int mk_cls[kLnMarked], mk_t[kLnMarked], n_mk, n_pairs_s, n_irr_s, fail_s;
-    __shared__ int red[kLnWaves];
+    __shared__ int mk_cls[kLnMarked + 1], mk_t[kLnMarked + 1], n_mk, n_pairs_s, n_irr_s, fail_s;
+    __shared__ int red[kLnMaxWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int s = blockIdx.x;
     if (todo) {
         if (s >= *n_todo) return;
         s = todo[s];
     }
+    const long long pt0 = wall_clock64();
     Ln L;
     const int base = A.scan_off[s];
     L.n = A.counts[s * 8 + 4];
@@ -666,6 +843,7 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
     Rp<CAP> T;
     T.T = (int32_t*)take((size_t)CAP * 4);
     T.fa = (int32_t*)take((size_t)CAP * 4);
+    T.Tn = (int32_t*)take((size_t)CAP * 4);
     T.par = (int32_t*)take((size_t)CAP * 4);
     T.fl = (uint8_t*)take(CAP);
     T.inext = (int16_t*)take(kLnIrr * 2);
@@ -674,25 +852,26 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
     T.ev_t = (int32_t*)take(kLnChunk * 4);
     T.ev_x = (int32_t*)take(kLnChunk * 4);
     T.rows = (int16_t*)(A.keys + base);
-    T.Tn = (int32_t*)A.tmp_vox_av + base;
+    T.ev3 = (int32_t*)A.zkey + base;
     T.ifirst = A.tk_hit + base;
     int2* pairs = (int2*)ovl;        // [kLnPairs]
-    Blk* blk = (Blk*)ovl + wave;     // [kLnWaves]
-    static_assert(sizeof(Blk) * kLnWaves <= 2048 * 12 && kLnPairs * 8 <= 2048 * 12, "overlays fit the smallest replay table");
+    Blk* blk = (Blk*)ovl + wave;     // [(TH / 64)]
+    static_assert(sizeof(Blk) * (TH / 64) <= (size_t)CAP * 16 && kLnPairs * 8 <= (size_t)CAP * 16, "overlays fit the class tables");
 
     L.n_irr = 0;
     L.n_names = 0;
+    L.lkeys = nullptr;
     // sampled keys
     L.sshift = 0;
     while (((L.nv + (1 << L.sshift) - 1) >> L.sshift) > kLnSamples) ++L.sshift;
     L.ns = (L.nv + (1 << L.sshift) - 1) >> L.sshift;
-    for (int j = tid; j < L.ns; j += kLnThreads) L.skey[j] = L.vkey[(size_t)j << L.sshift];
+    for (int j = tid; j < L.ns; j += TH) L.skey[j] = L.vkey[(size_t)j << L.sshift];
     if (tid == 0) n_mk = 0, n_pairs_s = 0, n_irr_s = 0, fail_s = 0;
     __syncthreads();
 
     // ---- index triples outside the grid: the points, then which clusters their lists tie into one closure class ----
     if (L.irregular) {
-        for (int i0 = 0; i0 < L.n; i0 += kLnThreads) {
+        for (int i0 = 0; i0 < L.n; i0 += TH) {
             const int i = i0 + tid;
             if (i < L.n && !regular_point(L, i)) {
                 const int x = atomicAdd(&n_irr_s, 1);
@@ -720,12 +899,12 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
             }
         }
         __syncthreads();
-        for (int j = tid; j < L.n_irr; j += kLnThreads) {
+        for (int j = tid; j < L.n_irr; j += TH) {
             L.irr_home[j] = slot_of_key(L, L.akey[L.irr_pt[j]]);
             L.irr_cls[j] = L.ptc[L.irr_pt[j]];
         }
         __syncthreads();
-        for (int j = tid; j < L.n_irr; j += kLnThreads) L.irr_reg0[j] = L.irr_home[j] >= 0 ? reg_of(L, L.irr_home[j], 0) : kInf;
+        for (int j = tid; j < L.n_irr; j += TH) L.irr_reg0[j] = L.irr_home[j] >= 0 ? reg_of(L, L.irr_home[j], 0) : kInf;
         __syncthreads();
         auto link = [&](int a, int b) {
             if (a == b) return;
@@ -733,7 +912,7 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
             if (x < kLnPairs) pairs[x] = make_int2(a, b);
         };
         // one wave per irregular point: what it lists, and who lists its voxel
-        for (int j = wave; j < L.n_irr; j += kLnWaves) {
+        for (int j = wave; j < L.n_irr; j += (TH / 64)) {
             const int p = L.irr_pt[j], cp = L.ptc[p];
             int r, s3, a;
             decode3(L.idx3[p], r, s3, a);
@@ -822,27 +1001,27 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
         }
         L.n_names = bc[0];
         __syncthreads();
-        for (int j = tid; j < L.n_irr; j += kLnThreads) L.irr_cls[j] = cls_of(L, L.irr_cls[j]);
+        for (int j = tid; j < L.n_irr; j += TH) L.irr_cls[j] = cls_of(L, L.irr_cls[j]);
         __syncthreads();
     }
 
     // ---- A: closure class of every voxel (through its first point), the latest-born class ----
     int lmax = -1;
-    for (int v0 = 0; v0 < L.nv; v0 += kLnThreads * 4) {
+    for (int v0 = 0; v0 < L.nv; v0 += TH * 4) {
         int f[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = L.vbeg[min(v0 + u * kLnThreads + tid, L.nv - 1)];
+        for (int u = 0; u < 4; ++u) f[u] = L.vbeg[min(v0 + u * TH + tid, L.nv - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) f[u] = L.vpts[f[u]];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int v = v0 + u * kLnThreads + tid;
+            const int v = v0 + u * TH + tid;
             if (v < L.nv) L.fp[v] = f[u];
             f[u] = L.ptc[f[u]];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int v = v0 + u * kLnThreads + tid;
+            const int v = v0 + u * TH + tid;
             if (v < L.nv) {
                 const int c = L.n_names ? cls_of(L, f[u]) : f[u];
                 L.vcl[v] = c;
@@ -851,27 +1030,27 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
             }
         }
     }
-    for (int j = tid; j < L.n_irr; j += kLnThreads) lmax = max(lmax, L.irr_cls[j]);
+    for (int j = tid; j < L.n_irr; j += TH) lmax = max(lmax, L.irr_cls[j]);
     for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, __shfl_xor(lmax, d));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
-    for (int w = 0; w < kLnWaves; ++w) lmax = max(lmax, red[w]);
+    for (int w = 0; w < (TH / 64); ++w) lmax = max(lmax, red[w]);
     __syncthreads();
     const int CL = lmax;
 
-    // ---- B: the latest-born class, replayed ----
-    RpOut best = replay_class<CAP>(L, T, CL, -1, wsum, bc);
-    int events = best.n_events;
-    bool unknown = best.too_big != 0;
-    int best_cls = CL;
-
-    // ---- C: later points of the other classes that could still open a cluster ----
-    if (!unknown) {
-        const int t_best = best.last_open;
+    // ---- B: later points of the other classes that could still open a cluster (the latest-born class opens one with its
+    // first point, at time CL: only what comes after that matters) ----
+    const long long pt1 = wall_clock64();
+    const long long pt2 = pt1;
+    long long pt3 = pt2, pt4 = pt2;
+    int prof_cand = 0, prof_mk = 0;
+    bool unknown = false;
+    {
+        const int t_best = CL;
         // candidates: voxels whose first regular point comes after t_best (a few), irregular points after it -- listed first
         if (tid == 0) bc[5] = 0;
         __syncthreads();
-        for (int v = tid; v < L.nv; v += kLnThreads) {
+        for (int v = tid; v < L.nv; v += TH) {
             const int f = L.fp[v];
             bool c = f > t_best && L.vcl[v] != CL;
             if (L.irregular && holds_irregular(L, v)) {  // (irregular points may lead the voxel)
@@ -880,11 +1059,12 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
             }
             if (c) L.evl[atomicAdd(&bc[5], 1)] = v;
         }
-        for (int j = tid; j < L.n_irr; j += kLnThreads)
+        for (int j = tid; j < L.n_irr; j += TH)
             if (L.irr_pt[j] > t_best && L.irr_cls[j] != CL) L.evl[atomicAdd(&bc[5], 1)] = L.nv + j;
         __syncthreads();
         const int n_cand = bc[5];
-        for (int c0 = wave; c0 < n_cand; c0 += kLnWaves) {
+        prof_cand = n_cand;
+        for (int c0 = wave; c0 < n_cand; c0 += (TH / 64)) {
             int ti = kInf, cr = 0, cs = 0, ca = 0, ccls = -1;
             bool cand = false;
             const int item = __hip_atomic_load(&L.evl[c0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -902,11 +1082,18 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
                 ccls = L.irr_cls[j];
             }
             if (!cand) continue;
+            // the cells it lists first: a visited point there and it is no opener (nine in ten stop here)
+            int fa_in = kInf;
+            if (lane < 27) {
+                const int k = slot_of_cell(L, cr + lane / 9 - 1, cs + (lane / 3) % 3 - 1, ca + lane % 3 - 1);
+                if (k >= 0) fa_in = L.fp[k];
+            }
+            if (__any(fa_in < ti)) continue;
             // the block of cells around it
             for (int c = lane; c < 125; c += 64) {
                 const int dx = c / 25 - 2, dy = (c / 5) % 5 - 2, dz = c % 5 - 2;
                 const int k = slot_of_cell(L, cr + dx, cs + dy, ca + dz);
-                blk->fa[c] = k >= 0 ? L.vpts[L.vbeg[k]] : kInf;
+                blk->fa[c] = k >= 0 ? L.fp[k] : kInf;
                 for (int e = 0; e < 3; ++e) blk->reg[c][e] = k >= 0 ? reg_of(L, k, e) : kInf;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -972,19 +1159,31 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
         }
         __syncthreads();
         if (n_mk > kLnMarked) unknown = true;
-        // ---- D: those classes (duplicates from racing waves are harmless: the second replay changes nothing) ----
-        for (int t = 0; t < min(n_mk, kLnMarked) && !unknown; ++t) {
-            if (mk_t[t] <= best.last_open || mk_cls[t] == best_cls) continue;
-            const RpOut r = replay_class<CAP>(L, T, mk_cls[t], best.last_open, wsum, bc);
-            events += r.n_events;
-            if (r.too_big) {
-                unknown = true;
-                break;
-            }
-            if (r.last_open > best.last_open) {
-                best = r;
-                best_cls = mk_cls[t];
-            }
+        pt3 = wall_clock64();
+        prof_mk = n_mk;
+    }
+    // ---- C: the latest-born class and the classes of the candidates no certificate settled, walked together ----
+    RpOut best = {-1, 0, -1, -1, 0, 1, 0, 0, 0, 0, 0, 0, 0};
+    if (!unknown) {
+        if (tid == 0) {  // (racing waves may have listed a class twice: harmless)
+            const int k = min(n_mk, kLnMarked);
+            mk_cls[k] = CL;
+            n_mk = k + 1;
+        }
+        __syncthreads();
+        best = replay_class<CAP, TH>(L, T, mk_cls, n_mk, -1, wsum, bc);
+        unknown = best.too_big != 0;
+    }
+    const RpOut big = best;
+    const int events = best.n_events;
+    pt4 = wall_clock64();
+    if (tid == 0 && A.ln_prof) {
+        int32_t* pp = A.ln_prof + (size_t)s * 8;
+        pp[0] = (int)(pt1 - pt0), pp[1] = (int)(pt2 - pt1), pp[2] = (int)(pt3 - pt2), pp[3] = (int)(pt4 - pt3);
+        pp[4] = prof_cand, pp[5] = prof_mk, pp[6] = L.n_irr, pp[7] = CAP;
+        if (A.ln_prof2) {
+            int32_t* p2 = A.ln_prof2 + (size_t)s * 8;
+            p2[0] = big.nodes, p2[1] = big.rounds, p2[2] = big.c_build, p2[3] = big.c_jacobi, p2[4] = big.c_open, p2[5] = big.c_cc, p2[6] = big.c_walk, p2[7] = big.n_events;
         }
     }
     if (tid == 0) {
@@ -1007,25 +1206,25 @@ __global__ __launch_bounds__(kLnThreads) void k_cc_lastname(DevParams P, Arena A
 
 }  // namespace
 
-constexpr int kLnCapSmall = 2048, kLnCapBig = 10240;
+constexpr int kLnCapSmall = 1792, kLnCapBig = 8192;
 
 void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
-        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
         attr_set = true;
     }
     if (th) th(tu, "cc_lastname", 1);
     hipMemsetAsync(A.cc_redo + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
-    hipLaunchKernelGGL(k_cc_lastname<kLnCapSmall>, dim3(B), dim3(kLnThreads), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
                        (const int32_t*)nullptr, A.cc_redo, A.cc_redo + B);
     // the scans whose replay did not fit: once more with the largest tables a CU holds (the grid is the batch, the idle
     // workgroups leave at once: nothing is read back on the host)
-    hipLaunchKernelGGL(k_cc_lastname<kLnCapBig>, dim3(B), dim3(kLnThreads), ln_lds_bytes<kLnCapBig>(), st, P, A, (const int32_t*)A.cc_redo,
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), st, P, A, (const int32_t*)A.cc_redo,
                        (const int32_t*)(A.cc_redo + B), (int32_t*)nullptr, (int32_t*)nullptr);
     if (th) th(tu, "cc_lastname", 0);
 }

@@ -71,7 +71,7 @@ static void toy_segment(SSC& s, Frame& f) {
         c.occupy_voxels.push_back(key);
         c.occupy_pts.insert(c.occupy_pts.end(), v.ptIdx.begin(), v.ptIdx.end());
     }
-    f.max_name = 5 + 64 * 64;
+    f.max_name = f.name_floor = 5 + 64 * 64;
     for (auto& kv : f.cluster_set) {
         Cluster& c = kv.second;
         std::sort(c.occupy_voxels.begin(), c.occupy_voxels.end());

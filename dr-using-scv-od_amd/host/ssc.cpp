@@ -184,7 +184,13 @@ void SSC::segmentGpu() {
         v.erase(std::unique(v.begin(), v.end()), v.end());
         for (int key : v) hash_cloud[key].label = kv.first;
     }
-    frame_ssc.max_name = max_name + 1;
+    // ssc.cpp:354: max_name = the last running number handed out.  Which cluster still carries it is the device's answer
+    // (scvod_batch_cluster_last_name); -1: the number was merged away, it is as good as a fresh one
+    int32_t last[4] = {-1, -1, 0, 0};
+    rc = scvod_batch_cluster_last_name(ctx_, last, 1, nullptr);
+    if (rc < 0) chk(ctx_, rc, "scvod_batch_cluster_last_name");
+    frame_ssc.name_floor = n + 6;  // (above every canonical name + 5, erased clusters included)
+    frame_ssc.max_name = last[0] >= 0 ? last[0] + 5 : frame_ssc.name_floor;
     frame_ssc.hash_cloud = hash_cloud;  // ssc.cpp:651
 }
 
@@ -253,7 +259,7 @@ void SSC::tracking(Frame& frame_pre_, Frame& frame_next_, Pose pose_pre_, Pose p
                     c.type = nc.type;
                     Cluster cluster_new;
                     cluster_new.track_id = c.track_id;
-                    cluster_new.name = frame_next_.max_name++;
+                    cluster_new.name = frame_next_.takeName();  // frame_next_.max_name ++ (ssc.cpp:1357, 1401)
                     cluster_new.type = nc.type;
                     std::copy(c.color, c.color + 3, cluster_new.color);
                     cluster_new.occupy_voxels = it->second;
@@ -287,7 +293,7 @@ void SSC::tracking(Frame& frame_pre_, Frame& frame_next_, Pose pose_pre_, Pose p
             c.state = 0;
             Cluster cluster_new;
             cluster_new.track_id = c.track_id;
-            cluster_new.name = frame_next_.max_name++;
+            cluster_new.name = frame_next_.takeName();  // frame_next_.max_name ++ (ssc.cpp:1357, 1401)
             cluster_new.type = car;
             std::copy(c.color, c.color + 3, cluster_new.color);
             for (auto& re : remap_name) {

@@ -46,6 +46,15 @@ struct Cluster {  // include/utility.h:142-162 (fields the hot path touches)
 
 struct Frame {  // include/utility.h:165-185
     int id = 0, max_name = 0;
+    // max_name is the LAST USED cluster name when clusterAndCreateFrame ends (ssc.cpp:354 `max_name = cluster_name ++`), and
+    // SSC::tracking hands it out again (ssc.cpp:1357, 1401).  The facade's names are canonical (smallest point + 5), not the
+    // reference's running numbers, so the numbers after that first one start at name_floor, above every name of the frame.
+    int name_floor = 0;
+    int takeName() {  // `frame_next_.max_name ++`
+        const int nm = max_name;
+        max_name = (max_name + 1 > name_floor) ? max_name + 1 : name_floor;
+        return nm;
+    }
     pcl::PointCloud<pcl::PointXYZI>::Ptr cloud_use{new pcl::PointCloud<pcl::PointXYZI>()};
     std::unordered_map<int, Voxel> hash_cloud;
     std::unordered_map<int, Cluster> cluster_set;

@@ -540,6 +540,9 @@ int oracle_time_sequence(const scvod_params* params, const float* xyzi, const in
             // names only order the walk of SSC::tracking, and this is the order the product defines
             std::unordered_map<int, int> first;
             for (int i = 0; i < n_a; ++i) first.emplace(cl[i], i);
+            // Frame::max_name as ssc.cpp:354 stores it: the LAST USED running number (mx); the cluster that still carries it
+            f.literal = true;
+            f.collide_name = first.count(mx) ? first[mx] : -1;
             for (int i = 0; i < n_a; ++i) cl[i] = first[cl[i]];
         }
         auto t4 = clk::now();
@@ -564,7 +567,7 @@ int oracle_time_sequence(const scvod_params* params, const float* xyzi, const in
             c.cloud.push_back(f.cloud_use[i]);
         }
         for (auto& kv : f.cluster_set) sampleVec(kv.second.occupy_voxels);
-        f.max_name = max_name + 1;
+        f.max_name = n_a + 5;  // fresh numbers: clear of every canonical name (erased clusters included)
         auto t5 = clk::now();
         stage_s[0] += secs(t0, t1);
         stage_s[1] += secs(t1, t2);

@@ -218,6 +218,20 @@ class Oracle:
                                                   int(chain), _p(dyn), C.byref(nd), _p(st))
         return dyn[:len(a)], nd.value, st
 
+    def reference_chain(self, params, res, names, types, poses, unknown=None, chain=3):
+        """SSC::segDF's tracking loop as the reference runs it, Frame::max_name included (ssc.cpp:354): per scan the cluster
+        that still carries the last running number (the literal visiting loop), then the literal chain.  res / names / types:
+        per-scan dicts / arrays of a segmented batch; unknown: scans whose name the device reported as undetermined (it then
+        hands out a fresh number there: the comparison follows)."""
+        collide = np.asarray([self.cluster_last_name(params, r["apri"])[0] for r in res], np.int32)
+        if unknown is not None:
+            collide[np.asarray(unknown, bool)] = -1
+        apri = np.concatenate([r["apri"] for r in res])
+        ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
+        dyn, nd, _ = self.sequence_tracking_literal(params, apri, ao, np.concatenate(names), np.concatenate(types), collide,
+                                                    np.asarray(poses, np.float32), chain=chain)
+        return dyn, nd
+
     def time_sequence(self, params, xyzi, offsets, poses, car=2, other=1, want_labels=True):
         a = np.ascontiguousarray(xyzi, np.float32)
         o = np.ascontiguousarray(offsets, np.int32)

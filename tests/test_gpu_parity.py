@@ -460,13 +460,12 @@ def test_batch_track_decision_parity(scvod, oracle, kind, preset, seq, first):
 
 def _assert_chain_equal(ctx, oracle, P, res, names, types, poses, order_free=True):
     """per-point bytes and dynamic-cluster count of the ctx's last scvod_batch_track (chain mode, scan s -> s + 1) against
-    the oracle's literal restatement of SSC::segDF's tracking loop, cluster_set walked in ascending name (chain=3)"""
+    the oracle's literal restatement of SSC::segDF's tracking loop -- Frame::max_name re-used as ssc.cpp:354 / 1357 / 1401 do --,
+    cluster_set walked in ascending name (chain=3)"""
     count = len(res)
     tr = [ctx.batch_fetch_track(s) for s in range(count)]
-    apri = np.concatenate([r["apri"] for r in res])
-    ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
-    nm, ty = np.concatenate(names), np.concatenate(types)
-    dyn, nd = oracle.sequence_tracking(P, apri, ao, nm, ty, np.asarray(poses, np.float32), chain=3)
+    ln, _ = ctx.batch_cluster_last_name(count)
+    dyn, nd = oracle.reference_chain(P, res, names, types, poses, unknown=ln[:, 2] != 0)
     got = np.concatenate([t["pt_dyn"] for t in tr])
     assert np.array_equal(got, dyn), f"{int((got != dyn).sum())} of {len(dyn)} per-point bytes differ from the sequential chain"
     assert sum(t["n_dynamic_clusters"] for t in tr) == nd
@@ -510,8 +509,10 @@ def test_tracking_chain_equals_the_reference_chain(scvod, oracle, kind, preset, 
     # call touch the same successor cluster)
     apri = np.concatenate([r["apri"] for r in res])
     ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])]).astype(np.int32)
+    # (with fresh numbers for new clusters; which cluster meets the re-used Frame::max_name first DOES depend on the order)
     dyn1, nd1 = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), poses, chain=1)
-    assert np.array_equal(dyn1, dyn) and nd1 == nd
+    dyn3, nd3 = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), poses, chain=3)
+    assert np.array_equal(dyn1, dyn3) and nd1 == nd3
     # the chain is not the first-order decision: the sample must contain clusters the appended clouds / re-labelling flip
     dyn2, _ = oracle.sequence_tracking(P, apri, ao, np.concatenate(names), np.concatenate(types), poses, chain=2)
     assert int((dyn2 != dyn).sum()) > 0
@@ -542,12 +543,11 @@ def test_tracking_chain_of_interleaved_subsequences(scvod, oracle):
     st = ctx.batch_track_stats()
     assert st["segments"] == skip * 3 and st["error_bits"] == 0
     tr = [ctx.batch_fetch_track(s) for s in range(count)]
+    ln, _ = ctx.batch_cluster_last_name(count)
     for q in range(skip):
         sub = list(range(q, count, skip))
-        apri = np.concatenate([res[s]["apri"] for s in sub])
-        ao = np.concatenate([[0], np.cumsum([res[s]["n_apri"] for s in sub])]).astype(np.int32)
-        dyn, nd = oracle.sequence_tracking(P, apri, ao, np.concatenate([names[s] for s in sub]), np.concatenate([types[s] for s in sub]),
-                                           np.asarray([poses[s] for s in sub], np.float32), chain=3)
+        dyn, nd = oracle.reference_chain(P, [res[s] for s in sub], [names[s] for s in sub], [types[s] for s in sub],
+                                         [poses[s] for s in sub], unknown=[ln[s, 2] != 0 for s in sub])
         assert np.array_equal(np.concatenate([tr[s]["pt_dyn"] for s in sub]), dyn), q
         assert sum(tr[s]["n_dynamic_clusters"] for s in sub) == nd
     ctx.close()
