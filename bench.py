@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--chain-seg", type=int, default=0, help="steps per chain segment (0: library default)")
     ap.add_argument("--chain-warm", type=int, default=-1, help="warm-up steps in front of a segment (-1: library default)")
     ap.add_argument("--cluster-exact", action="store_true", help="visiting-order model for components of any size in scans beyond the LDS clustering variant (OS128 class)")
+    ap.add_argument("--max-name-fresh", action="store_true", help="new clusters of the tracking chain get fresh numbers instead of the reference's re-used Frame::max_name (ssc.cpp:354): profiling only, the labels then differ from the reference's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (use --backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--dump-map", default="", help="rank 0 writes the merged static map (records sorted by cell key) and the per-scan dynamic counts to this .npz")
@@ -157,6 +158,8 @@ def main():
         ctx.set_track_mode(chain=args.track_mode == "chain", segment_steps=max(args.chain_seg, 0), warmup_steps=max(args.chain_warm, -1))
     if args.cluster_exact:
         ctx.set_cluster_exact(True)
+    if args.max_name_fresh:
+        ctx.set_max_name_literal(False)
     stream = torch.cuda.current_stream().cuda_stream  # torch.distributed orders its work against this stream
     nxt = plan["next_scan"]
     T = np.zeros((n_sc, 12), np.float32)

@@ -91,6 +91,12 @@ struct scvod_ctx {
     std::vector<int32_t> tk_stage;    // host staging of scvod_batch_fetch_track
     // streaming ingest (scvod_sequence_ingest): two device chunk buffers, a copy stream, pinned offsets
     hipStream_t copy_stream = nullptr;
+    // the max_name pass (scvod_lastname.hip) runs beside the kernels that follow the clustering, on a stream of its own; whoever
+    // needs its result or its scratch waits for ln_done (join_lastname)
+    hipStream_t ln_stream = nullptr;
+    hipStream_t ln_stream2 = nullptr;
+    hipEvent_t ln_fork = nullptr, ln_done = nullptr, ln_fork2 = nullptr, ln_join2 = nullptr;
+    bool ln_pending = false;
     void* ingest_buf[2] = {nullptr, nullptr};
     size_t ingest_cap = 0;  // points per buffer
     hipEvent_t ingest_copied[2] = {nullptr, nullptr}, ingest_done[2] = {nullptr, nullptr};
@@ -220,7 +226,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
     A.cc_last = k.take<int32_t>(B * 4);
-    A.cc_redo = k.take<int32_t>(B + 1);
+    A.cc_redo = k.take<int32_t>(2 * (B + 1));
     A.ln_stats = k.take<int32_t>(4);
     A.ln_prof = k.take<int32_t>(B * 8);
     A.ln_prof2 = k.take<int32_t>(B * 8);
@@ -367,6 +373,13 @@ void timer_hook(void* user, const char* name, int begin) {
     }
 }
 
+// Makes `st` wait for the max_name pass of the last clustering (if one is still in flight).
+static void join_lastname(scvod_ctx* c, hipStream_t st) {
+    if (!c->ln_pending) return;
+    hipStreamWaitEvent(st, c->ln_done, 0);
+    c->ln_pending = false;
+}
+
 int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_scans, hipStream_t st,
               int do_patchwork, int apply_filter, int do_voxels, int sync, bool off_pinned = false) {
     if (!c) return SCVOD_ERR_INVALID;
@@ -386,6 +399,7 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     HIPCHK(c, hipSetDevice(c->device));
     if (!st) st = c->stream;
     c->last_stream = st;
+    join_lastname(c, st);
     c->h_scan_off.assign(h_off, h_off + n_scans + 1);
     // (a caller-pinned offset table is read by the copy engine directly: nothing to wait for on the host)
     HIPCHK(c, hipMemcpyAsync(c->d_scan_off, off_pinned ? h_off : c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
@@ -565,6 +579,7 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
     HIPCHK(c, hipSetDevice(c->device));
     if (!st) st = c->stream;
     c->last_stream = st;
+    join_lastname(c, st);
     c->h_scan_off.assign(h_off, h_off + n_scans + 1);
     HIPCHK(c, hipMemcpyAsync(c->d_scan_off, c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
     c->A.pts = (const float4*)d_xyzi;
@@ -892,6 +907,12 @@ void scvod_destroy(scvod_ctx* c) {
         hipEventDestroy(t.e1);
     }
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->ln_stream) hipStreamDestroy(c->ln_stream);
+    if (c->ln_stream2) hipStreamDestroy(c->ln_stream2);
+    if (c->ln_fork2) hipEventDestroy(c->ln_fork2);
+    if (c->ln_join2) hipEventDestroy(c->ln_join2);
+    if (c->ln_fork) hipEventDestroy(c->ln_fork);
+    if (c->ln_done) hipEventDestroy(c->ln_done);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     for (int k = 0; k < 2; ++k) {
         if (c->ingest_buf[k]) hipFree(c->ingest_buf[k]);
@@ -995,6 +1016,7 @@ int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offset
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->last_stream = st;
+    join_lastname(c, st);
     c->tim_used = 0;
     // the one-shot probe writes t_T and scratch that scvod_batch_track's results alias: forget the cached upload of T and
     // the batch's tracking result (a following scvod_batch_track uploads and decides again)
@@ -1071,11 +1093,27 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     if (c->dev.bin.range_num > 2040 || c->dev.bin.sector_num > 2040 || c->dev.bin.azimuth_num > 1016)
         return fail(c, SCVOD_ERR_INVALID, "grid of %d x %d x %d bins is finer than the clustering's packed index triples hold (2040 x 2040 x 1016)",
                     c->dev.bin.range_num, c->dev.bin.sector_num, c->dev.bin.azimuth_num);
+    join_lastname(c, st);
     launch_cluster(c->dev, c->A, c->batch_mode == 2 ? 1 : 0, st, timer_hook, c);
     c->last_name_valid = false;
     if (c->max_name_literal) {
-        launch_lastname(c->dev, c->A, st, timer_hook, c);
+        if (!c->ln_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ln_fork, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ln_done, hipEventDisableTiming));
+            HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream2, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ln_fork2, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ln_join2, hipEventDisableTiming));
+        }
+        HIPCHK(c, hipEventRecord(c->ln_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->ln_stream, c->ln_fork, 0));
+        c->last_stream = c->ln_stream;  // (the timing hook records on last_stream)
+        launch_lastname(c->dev, c->A, c->ln_stream, c->ln_stream2, c->ln_fork2, c->ln_join2, c->timing ? timer_hook : nullptr, c);
+        c->last_stream = st;
+        HIPCHK(c, hipEventRecord(c->ln_done, c->ln_stream));
+        c->ln_pending = true;
         c->last_name_valid = true;
+        if (sync) join_lastname(c, st);
     }
     HIPCHK(c, hipGetLastError());
     c->clusters_valid = true;
@@ -1105,6 +1143,7 @@ int scvod_batch_cluster_types(scvod_ctx* c, void* stream, int32_t sync) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
+    // (nothing is launched here: the max_name pass keeps running beside what follows)
     c->tim_used = 0;
     // the boxes and the type rules are evaluated by the clustering kernel itself (same workgroup, boxes in LDS): nothing to launch
     c->types_valid = true;
@@ -1222,7 +1261,9 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             c->chain_ran = true;
         }
     }
-    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, c->tables_valid ? 2 : 3, st, timer_hook, c, c->chain_ran ? &CJ : nullptr);
+    launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, c->tables_valid ? 2 : 3, st, timer_hook, c, c->chain_ran ? &CJ : nullptr,
+                       c->ln_pending ? c->ln_done : nullptr);
+    if (c->chain_ran) c->ln_pending = false;  // (the chain waited for it)
     HIPCHK(c, hipGetLastError());
     c->tables_valid = true;
     c->track_valid = true;
@@ -1257,6 +1298,7 @@ int scvod_batch_cluster_last_name(scvod_ctx* c, int32_t* h_out4, int32_t cap_sca
     if (!c || !h_out4) return SCVOD_ERR_INVALID;
     if (!c->clusters_valid || !c->last_name_valid) return fail(c, SCVOD_ERR_STATE, "no clustering with max_name tracking for the last batch");
     if (cap_scans < c->A.n_scans) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d scans)", cap_scans, c->A.n_scans);
+    join_lastname(c, c->last_stream);
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy(h_out4, c->A.cc_last, sizeof(int32_t) * 4 * (size_t)c->A.n_scans, hipMemcpyDeviceToHost));
     if (h_stats4) HIPCHK(c, hipMemcpy(h_stats4, c->A.ln_stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1346,6 +1388,7 @@ int scvod_batch_track_tables(scvod_ctx* c, void* stream) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     c->last_stream = st;
+    join_lastname(c, st);
     c->tim_used = 0;
     TrackBatch J;
     memset(&J, 0, sizeof(J));

@@ -125,7 +125,7 @@ struct Arena {
     // the cluster that still carries Frame::max_name as ssc.cpp:354 stores it (scvod_lastname.hip)
     int32_t* cc_last;         // [B][4] {canonical name or -1, lowest voxel slot whose first point belongs to it or -1,
                               //         status: 0 exact, 1 a replay did not fit the LDS, 2 too many index triples outside the grid, events replayed}
-    int32_t* cc_redo;         // [B + 1] scans handed to the second pass (larger tables), [B] = how many
+    int32_t* cc_redo;         // 2 x [B + 1] scans handed to the second / third pass (larger tables), [B] = how many
     int32_t* ln_prof;         // [B][8] phase clocks (10 ns ticks) and counts of the last pass over a scan: tools/lastname_lat.py
     int32_t* ln_prof2;        // [B][8] the largest class walked: nodes, Jacobi rounds, clocks of build / rounds / openers / partition / walk, events
     int32_t* ln_stats;        // [4] per clustering call: scans with status 1, with status 2, 0, 0
@@ -209,12 +209,12 @@ void launch_voxelgrid_lut(const Arena& A, hipStream_t st);
 void launch_voxelgrid_gather(const DevParams& P, const Arena& A, const VgJob& J, long long out_capacity, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu);
-void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu);
+void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
 struct ChainJob;
 void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
-                        TimerHook th, void* tu, const ChainJob* chain = nullptr);
+                        TimerHook th, void* tu, const ChainJob* chain = nullptr, hipEvent_t before_chain = nullptr);
 void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
                float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work, int bounded,

@@ -34,7 +34,7 @@ namespace {
 constexpr int kLnMaxWaves = 16;
 constexpr int kLnIrr = 256;       // index triples outside the grid handled per scan (a 128-beam scan holds 36)
 constexpr int kLnPairs = 1024;    // links between clusters that such points create
-constexpr int kLnNames = 512;     // distinct cluster names in those links
+constexpr int kLnNames = 256;     // distinct cluster names in those links
 constexpr int kLnSamples = 1024;  // sampled voxel keys (LDS)
 constexpr int kLnMarked = 16;     // components to replay besides the latest-born one
 constexpr int kLnChunk = 512;     // events staged per round
@@ -383,6 +383,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
         for (int l = tid; l < min(m, CAP); l += TH) L.loc[L.cvl[l]] = -1;
         __syncthreads();
     };
+    out.nodes = nn;
     if (nn > CAP || m > CAP || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || 3 * nn > L.n_raw) {  // does not fit
         leave();
         out.too_big = 1;
@@ -784,7 +785,7 @@ struct Blk {
 };
 
 template <int CAP, int TH>
-__global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo,
+__global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo, int32_t* redo_big, int big_from,
                                                              int32_t* n_redo) {
     extern __shared__ __align__(16) unsigned char ln_smem[];
     __shared__ int wsum[2 * kLnMaxWaves + 2];
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
     L.evn = (int32_t*)A.tmp_vox_av + base;
     L.bits = (uint32_t*)A.tmp_vox_cov + base;
     L.evl = (int32_t*)(A.vkeys + base);
-    L.cvl = (int32_t*)A.tk_uniq + base;
+    L.cvl = (int32_t*)A.sorted_xyz + 3 * (size_t)base;  // (nothing the tracking kernels touch: this pass runs beside them)
     L.fp = (int32_t*)A.sorted_idx + base;
     L.n_raw = A.scan_off[s + 1] - base;
     L.rows_bytes = 8ll * L.n_raw;
@@ -853,10 +854,11 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
     T.ev_x = (int32_t*)take(kLnChunk * 4);
     T.rows = (int16_t*)(A.keys + base);
     T.ev3 = (int32_t*)A.zkey + base;
-    T.ifirst = A.tk_hit + base;
+    T.ifirst = (int32_t*)A.sorted_xyz + 3 * (size_t)base + L.n_raw;
     int2* pairs = (int2*)ovl;        // [kLnPairs]
     Blk* blk = (Blk*)ovl + wave;     // [(TH / 64)]
-    static_assert(sizeof(Blk) * (TH / 64) <= (size_t)CAP * 16 && kLnPairs * 8 <= (size_t)CAP * 16, "overlays fit the class tables");
+    static_assert(sizeof(Blk) * (TH / 64) <= (size_t)CAP * 17 + kLnIrr * 5 + kLnChunk * 8 && kLnPairs * 8 <= (size_t)CAP * 17 + kLnIrr * 5 + kLnChunk * 8,
+                  "overlays fit the class tables (and the walk's staging behind them: neither is live at the time)");
 
     L.n_irr = 0;
     L.n_names = 0;
@@ -1057,6 +1059,17 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
                 const int r0 = reg_of(L, v, 0);
                 c = r0 != kInf && r0 > t_best && (L.n_names ? cls_of(L, L.ptc[r0]) : L.ptc[r0]) != CL;
             }
+            if (c) {
+                // the cells it lists: a visited point there and it is no opener (nine in ten stop here, in the thread that
+                // found them: the wave-wide certificate below is for the rest)
+                int cr, cs, ca;
+                const int ti = (L.irregular && holds_irregular(L, v)) ? reg_of(L, v, 0) : f;
+                if (cell_of_voxel(L, v, cr, cs, ca))
+                    for (int p = 0; p < 27 && c; ++p) {
+                        const int k = slot_of_cell(L, cr + p / 9 - 1, cs + (p / 3) % 3 - 1, ca + p % 3 - 1);
+                        if (k >= 0 && L.fp[k] < ti) c = false;
+                    }
+            }
             if (c) L.evl[atomicAdd(&bc[5], 1)] = v;
         }
         for (int j = tid; j < L.n_irr; j += TH)
@@ -1189,7 +1202,8 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
     if (tid == 0) {
         if (unknown) {
             if (redo) {  // a larger table may hold it
-                redo[atomicAdd(n_redo, 1)] = s;
+                int32_t* list = (redo_big && best.nodes > big_from) ? redo_big : redo;
+                list[atomicAdd(list + A.n_scans, 1)] = s;
                 outp[0] = outp[1] = -1, outp[2] = 3, outp[3] = events;
             } else {
                 outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = events;
@@ -1206,27 +1220,53 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
 
 }  // namespace
 
-constexpr int kLnCapSmall = 1792, kLnCapBig = 8192;
+constexpr int kLnCapTiny = 320, kLnCapSmall = 1792, kLnCapBig = 8192;
 
-void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, TimerHook th, void* tu) {
+// Three passes: nearly every scan is settled by walking a few dozen voxels (tables of 320 nodes: eight workgroups per CU hide
+// each other's look-up latencies); a scan whose classes do not fit is listed on the device for the pass whose tables hold them
+// (the grid stays the batch, idle workgroups leave at once: nothing is read back on the host).  The two later passes are each
+// as long as their slowest scan, so they run side by side: `st2` (optional) takes the one with the largest tables.
+void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
         attr_set = true;
     }
-    if (th) th(tu, "cc_lastname", 1);
-    hipMemsetAsync(A.cc_redo + B, 0, sizeof(int32_t), st);
+    int32_t* redo_mid = A.cc_redo;          // [B] scans, [B] = how many
+    int32_t* redo_big = A.cc_redo + B + 1;
+    hipMemsetAsync(redo_mid + B, 0, sizeof(int32_t), st);
+    hipMemsetAsync(redo_big + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
-    hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr, A.cc_redo, A.cc_redo + B);
-    // the scans whose replay did not fit: once more with the largest tables a CU holds (the grid is the batch, the idle
-    // workgroups leave at once: nothing is read back on the host)
-    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), st, P, A, (const int32_t*)A.cc_redo,
-                       (const int32_t*)(A.cc_redo + B), (int32_t*)nullptr, (int32_t*)nullptr);
+    if (th) th(tu, "cc_lastname", 1);
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, redo_mid, redo_big, kLnCapSmall, (int32_t*)nullptr);
     if (th) th(tu, "cc_lastname", 0);
+    const bool side = st2 && ev_fork && ev_join && !th;  // (timed runs keep one stream: the hook records on one)
+    hipStream_t sb = side ? st2 : st;
+    if (side) {
+        hipEventRecord(ev_fork, st);
+        hipStreamWaitEvent(st2, ev_fork, 0);
+    } else {  // one stream: the mid pass first, what it cannot hold joins the last list
+        if (th) th(tu, "cc_lastname_mid", 1);
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)redo_mid,
+                           (const int32_t*)(redo_mid + B), redo_big, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+        if (th) th(tu, "cc_lastname_mid", 0);
+    }
+    if (th) th(tu, "cc_lastname_big", 1);
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), sb, P, A, (const int32_t*)redo_big,
+                       (const int32_t*)(redo_big + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+    if (th) th(tu, "cc_lastname_big", 0);
+    if (side) {
+        // beside it: the mid pass; the (rare) scan it cannot hold after all is reported unknown rather than waited for
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)redo_mid,
+                           (const int32_t*)(redo_mid + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+        hipEventRecord(ev_join, st2);
+        hipStreamWaitEvent(st, ev_join, 0);
+    }
 }
 
 }  // namespace scvod

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_tk_export(Arena A, int s, int4* out, lo
 // phases: 1 = successor tables only (labels, cluster sizes: what scvod_batch_export_table hands to another shard),
 // 2 = member lists, probe, decision, per-point bytes (needs phase 1 of the same clustering), 3 = both
 void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
-                        TimerHook th, void* tu, const ChainJob* chain) {
+                        TimerHook th, void* tu, const ChainJob* chain, hipEvent_t before_chain) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     const dim3 g((A.max_scan_pts + 2047) / 2048, B);
@@ -388,7 +388,10 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     TH_END("tk_decide");
     // the reference's sequential chain on top of the first-order results (scvod_chain.hip): states and dynamic counters of
     // every frame that has a successor in the batch become those of SSC::segDF's loop
-    if (chain) launch_track_chain(P, A, J, *chain, from_apri, st, th, tu);
+    if (chain) {
+        if (before_chain) hipStreamWaitEvent(st, before_chain, 0);  // (Frame::max_name of every scan: scvod_lastname.hip, on its own stream)
+        launch_track_chain(P, A, J, *chain, from_apri, st, th, tu);
+    }
     TH_BEGIN("tk_dyn");
     hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A, from_apri);
     TH_END("tk_dyn");
