@@ -70,7 +70,8 @@ struct Ln {  // per-scan view
     int32_t* irr_home;  // voxel slot
     int32_t* irr_cls;   // closure class
     int32_t* irr_reg0;  // first regular point of the home voxel
-    int n_irr;
+    int32_t* irr_xs;    // the voxels that hold such points: sorted, unique
+    int n_irr, n_xs;
     int32_t* cname;  // class table: sorted names
     int32_t* crep;
     int n_names;
@@ -153,10 +154,16 @@ __device__ __forceinline__ bool cell_of_voxel(const Ln& L, int v, int& r, int& s
     s = rem - r * L.S;
     return true;
 }
-__device__ __forceinline__ bool holds_irregular(const Ln& L, int v) {  // (irr_home is not sorted: a few hundred entries at most)
-    for (int j = 0; j < L.n_irr; ++j)
-        if (L.irr_home[j] == v) return true;
-    return false;
+__device__ __forceinline__ bool holds_irregular(const Ln& L, int v) {
+    int lo = 0, hi = L.n_xs;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (L.irr_xs[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < L.n_xs && L.irr_xs[lo] == v;
 }
 // e-th REGULAR point of voxel v (e = 0, 1, 2), kInf when it has fewer
 __device__ __forceinline__ int reg_of(const Ln& L, int v, int e) {
@@ -775,7 +782,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
 template <int CAP>
 constexpr size_t ln_lds_bytes() {
     return (size_t)CAP * (4 + 4 + 4 + 4 + 1) + kLnIrr * (2 + 2 + 1) + kLnChunk * 8  // tables of a class
-           + kLnSamples * 4 + kLnIrr * 4 * 4 + kLnNames * 8 + 512;
+           + kLnSamples * 4 + kLnIrr * 5 * 4 + kLnNames * 8 + 512;
 }
 
 // per wave: the 5 x 5 x 5 block of cells around a candidate
@@ -838,6 +845,7 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
     L.irr_home = (int32_t*)take(kLnIrr * 4);
     L.irr_cls = (int32_t*)take(kLnIrr * 4);
     L.irr_reg0 = (int32_t*)take(kLnIrr * 4);
+    L.irr_xs = (int32_t*)take(kLnIrr * 4);
     L.cname = (int32_t*)take(kLnNames * 4);
     L.crep = (int32_t*)take(kLnNames * 4);
     unsigned char* ovl = q;  // from here on: the replay tables, overlaid by the link pairs / the candidates' blocks
@@ -861,6 +869,7 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
                   "overlays fit the class tables (and the walk's staging behind them: neither is live at the time)");
 
     L.n_irr = 0;
+    L.n_xs = 0;
     L.n_names = 0;
     L.lkeys = nullptr;
     // sampled keys
@@ -906,6 +915,26 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
             L.irr_cls[j] = L.ptc[L.irr_pt[j]];
         }
         __syncthreads();
+        if (tid == 0) {  // the voxels concerned: sorted, unique
+            int nx = 0;
+            for (int j = 0; j < L.n_irr; ++j) {
+                const int h = L.irr_home[j];
+                if (h < 0) continue;
+                int b = nx - 1;
+                bool dup = false;
+                for (int t = 0; t < nx; ++t) dup |= L.irr_xs[t] == h;
+                if (dup) continue;
+                while (b >= 0 && L.irr_xs[b] > h) {
+                    L.irr_xs[b + 1] = L.irr_xs[b];
+                    --b;
+                }
+                L.irr_xs[b + 1] = h;
+                ++nx;
+            }
+            bc[7] = nx;
+        }
+        __syncthreads();
+        L.n_xs = bc[7];
         for (int j = tid; j < L.n_irr; j += TH) L.irr_reg0[j] = L.irr_home[j] >= 0 ? reg_of(L, L.irr_home[j], 0) : kInf;
         __syncthreads();
         auto link = [&](int a, int b) {
@@ -1052,25 +1081,27 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
         // candidates: voxels whose first regular point comes after t_best (a few), irregular points after it -- listed first
         if (tid == 0) bc[5] = 0;
         __syncthreads();
+        // (a voxel that holds irregular points goes by its first REGULAR point: those few voxels take the second loop)
+        auto list_voxel = [&](int v, int ti) {
+            int cr, cs, ca;
+            bool c = true;
+            // the cells it lists: a visited point there and it is no opener (nine in ten stop here, in the thread that found
+            // them: the wave-wide certificate below is for the rest)
+            if (cell_of_voxel(L, v, cr, cs, ca))
+                for (int p = 0; p < 27 && c; ++p) {
+                    const int k = slot_of_cell(L, cr + p / 9 - 1, cs + (p / 3) % 3 - 1, ca + p % 3 - 1);
+                    if (k >= 0 && L.fp[k] < ti) c = false;
+                }
+            if (c) L.evl[atomicAdd(&bc[5], 1)] = v;
+        };
         for (int v = tid; v < L.nv; v += TH) {
             const int f = L.fp[v];
-            bool c = f > t_best && L.vcl[v] != CL;
-            if (L.irregular && holds_irregular(L, v)) {  // (irregular points may lead the voxel)
-                const int r0 = reg_of(L, v, 0);
-                c = r0 != kInf && r0 > t_best && (L.n_names ? cls_of(L, L.ptc[r0]) : L.ptc[r0]) != CL;
-            }
-            if (c) {
-                // the cells it lists: a visited point there and it is no opener (nine in ten stop here, in the thread that
-                // found them: the wave-wide certificate below is for the rest)
-                int cr, cs, ca;
-                const int ti = (L.irregular && holds_irregular(L, v)) ? reg_of(L, v, 0) : f;
-                if (cell_of_voxel(L, v, cr, cs, ca))
-                    for (int p = 0; p < 27 && c; ++p) {
-                        const int k = slot_of_cell(L, cr + p / 9 - 1, cs + (p / 3) % 3 - 1, ca + p % 3 - 1);
-                        if (k >= 0 && L.fp[k] < ti) c = false;
-                    }
-            }
-            if (c) L.evl[atomicAdd(&bc[5], 1)] = v;
+            if (f > t_best && L.vcl[v] != CL && !(L.n_xs && holds_irregular(L, v))) list_voxel(v, f);
+        }
+        for (int t = tid; t < L.n_xs; t += TH) {
+            const int v = L.irr_xs[t];
+            const int r0 = reg_of(L, v, 0);
+            if (r0 != kInf && r0 > t_best && (L.n_names ? cls_of(L, L.ptc[r0]) : L.ptc[r0]) != CL) list_voxel(v, r0);
         }
         for (int j = tid; j < L.n_irr; j += TH)
             if (L.irr_pt[j] > t_best && L.irr_cls[j] != CL) L.evl[atomicAdd(&bc[5], 1)] = L.nv + j;
@@ -1233,6 +1264,7 @@ void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStre
     if (!attr_set) {
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
         attr_set = true;
     }
@@ -1241,9 +1273,14 @@ void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStre
     hipMemsetAsync(redo_mid + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(redo_big + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
+    const bool large = A.max_scan_pts > 100000;  // (128-beam class: a scan's tables are passed over by 1024 threads from the start)
     if (th) th(tu, "cc_lastname", 1);
-    hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr, redo_mid, redo_big, kLnCapSmall, (int32_t*)nullptr);
+    if (!large)
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, redo_mid, redo_big, kLnCapSmall, (int32_t*)nullptr);
+    else
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 1024>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, redo_big, (int32_t*)nullptr, 0, (int32_t*)nullptr);
     if (th) th(tu, "cc_lastname", 0);
     const bool side = st2 && ev_fork && ev_join && !th;  // (timed runs keep one stream: the hook records on one)
     hipStream_t sb = side ? st2 : st;

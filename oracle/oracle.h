@@ -90,6 +90,9 @@ int oracle_voxelgrid(const float* xyzi, const uint32_t* labels, int32_t n, float
 /* one poses.txt line -> velodyne-frame pose, SSC::getPose KITTI branch (src/ssc.cpp:960-989, utility.h:488-505) */
 int oracle_kitti_pose(const float tr[16], const float cam12[12], float pose6[6], float velo_to_cam[16]);
 
+/* index flips between the two readings of the unqualified atan2 in utility.h:382-391 (float overload vs double + rounding) */
+int oracle_atan2_overload_flips(const scvod_params* params, const float* xyzi, int32_t n, int64_t* counts);
+
 /* libm probes for tests/test_math_spec.py */
 float oracle_libm_atan2f(float y, float x);
 double oracle_libm_atan2(double y, double x);

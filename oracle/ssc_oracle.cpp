@@ -419,6 +419,44 @@ static int cluster_and_create_frame(const scvod_params* params, const scvod_apri
     return (int)names.size();
 }
 
+// `atan2` in utility.h:382,385,391 is unqualified inside a function template.  With libstdc++'s <cmath> / <math.h>
+// in scope the float overload is chosen (= atan2f, what the restatement uses); a build that only saw the C prototype would
+// promote to double and round the result, `float(atan2(double, double))`.  Counts how many points of a cloud change an INDEX
+// between the two readings: counts[4] = {points inside the range / FOV filter under the float reading, of those: sector_idx
+// differs, azimuth_idx differs, kept-or-rejected verdict differs}.
+int oracle_atan2_overload_flips(const scvod_params* params, const float* xyzi, int32_t n, int64_t* counts) {
+    const scvod_params& P = *params;
+    for (int k = 0; k < 4; ++k) counts[k] = 0;
+    auto deg = [](float rad) { return (float)((float)rad * 180.0 / M_PI); };
+    for (int i = 0; i < n; ++i) {
+        const float x = xyzi[4 * i], y = xyzi[4 * i + 1], z = xyzi[4 * i + 2];
+        const float dis = (float)sqrt(x * x + y * y);
+        float ang[2], azi[2];
+        for (int v = 0; v < 2; ++v) {
+            const float a = v == 0 ? atan2f(y, x) : (float)atan2((double)y, (double)x);
+            if (x == 0 && y == 0)
+                ang[v] = 0.f;
+            else if (y >= 0)
+                ang[v] = deg(a);
+            else
+                ang[v] = (float)((float)((float)a + 2 * M_PI) * 180.0 / M_PI);
+            azi[v] = deg(v == 0 ? atan2f(z, dis) : (float)atan2((double)z, (double)dis));
+        }
+        auto kept = [&](int v) {
+            return !(dis < P.min_dis || dis > P.max_dis || ang[v] < P.min_angle || ang[v] > P.max_angle || azi[v] < P.min_azimuth || azi[v] > P.max_azimuth);
+        };
+        const bool k0 = kept(0), k1 = kept(1);
+        if (k0 != k1) counts[3]++;
+        if (!k0) continue;
+        counts[0]++;
+        const int s0 = (int)(std::ceil((ang[0] - P.min_angle) / P.sector_res) - 1), s1 = (int)(std::ceil((ang[1] - P.min_angle) / P.sector_res) - 1);
+        const int a0 = (int)(std::ceil((azi[0] - P.min_azimuth) / P.azimuth_res) - 1), a1 = (int)(std::ceil((azi[1] - P.min_azimuth) / P.azimuth_res) - 1);
+        if (s0 != s1) counts[1]++;
+        if (a0 != a1) counts[2]++;
+    }
+    return 0;
+}
+
 int oracle_cluster(const scvod_params* params, const scvod_apri* apri_vec_, int32_t n, int32_t* pt_cluster, int32_t* max_name) {
     return cluster_and_create_frame(params, apri_vec_, n, pt_cluster, max_name, nullptr);
 }

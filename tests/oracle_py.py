@@ -135,6 +135,13 @@ class Oracle:
         info = np.zeros(6, np.int64)
         return int(self.lib.oracle_cluster_last_name(C.byref(params), _p(a), a.shape[0], _p(info))), info
 
+    def atan2_overload_flips(self, params, xyzi):
+        """{kept points, sector_idx flips, azimuth_idx flips, filter-verdict flips} between atan2f and float(atan2(double, double))"""
+        a = np.ascontiguousarray(xyzi, np.float32)
+        out = np.zeros(4, np.int64)
+        self.lib.oracle_atan2_overload_flips(C.byref(params), _p(a), a.shape[0], _p(out))
+        return out
+
     def cluster_types(self, params, apri, pt_cluster, car_label=2, other_label=1):
         a = np.ascontiguousarray(apri)
         c = np.ascontiguousarray(pt_cluster, np.int32)

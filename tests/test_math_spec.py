@@ -201,3 +201,21 @@ def test_voxel_index_estimate_never_disagrees_with_the_reference_arithmetic(spec
                      [1.0, np.inf, 1.0], [1e30, 1e30, 1.0]], np.float32)
     bad, frac, _ = run(grids[0][0], grids[0][1], edge)
     assert bad == 0
+
+
+def test_atan2_overload_decision_moves_a_handful_of_indices(oracle, scvod):
+    """the unqualified `atan2` of utility.h:382-391 is atan2f when <cmath>'s float overload is in scope (the
+    reading this library and its oracle follow) and float(atan2(double, double)) otherwise.  The two round differently in the
+    last place on a few arguments; an index only flips when such an argument sits on a bin edge.  Counted on 4 M uniform
+    points per grid (same seed as DESIGN.md section 2 quotes): a few per million, never the range / FOV verdict."""
+    rng = np.random.default_rng(20241026)
+    for preset, want in (("semantickitti", (2571252, 3, 0, 0)), ("parkinglot", (3441127, 5, 0, 0)), ("os128_fine", (2571808, 5, 0, 0))):
+        P = scvod.make_params(preset)
+        n = 4_000_000
+        r = rng.uniform(1.0, 45.0, n)
+        th = rng.uniform(0, 2 * np.pi, n)
+        z = rng.uniform(-3, 6, n)
+        x = np.stack([r * np.cos(th), r * np.sin(th), z, np.zeros(n)], 1).astype(np.float32)
+        got = oracle.atan2_overload_flips(P, x)
+        assert got[0] > 2_000_000 and got[1] + got[2] < 1e-5 * got[0] and got[3] == 0, (preset, got)
+        assert tuple(int(v) for v in got) == want, (preset, got)  # (glibc 2.35 of this image; pins the number DESIGN.md quotes)
