@@ -24,7 +24,7 @@
 //   * a replay lives in LDS (one thread walks the events in order, all threads build its tables); a component with more
 //     nodes than the LDS holds is not replayed: the scan reports "unknown" (counted, scvod_batch_cluster_stats), the chain
 //     then hands out a fresh number as if K had been merged away.
-// Validated against the oracle's literal loop (oracle_cluster_last_name) in tests/test_gpu_lastname.py.
+// Checked against a literal restatement of the loop in tests/test_gpu_lastname.py.
 #include "scvod_dev.h"
 
 namespace scvod {
