@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the multi-threaded CPU context number")
     ap.add_argument("--no-quality", action="store_true", help="skip the PR/RR comparison")
     ap.add_argument("--no-extras", action="store_true", help="skip the separately reported stages (VoxelGrid, ingest): profiling runs")
+    ap.add_argument("--split-sequence", action="store_true", help="strong scaling: ONE sequence of --scans scans over the ranks (contiguous blocks, a halo of 12 x skip scans for the tracking chain's warm-up, the chain's state handed from rank to rank: pyshim/shard.py plan_split)")
+    ap.add_argument("--split-halo", type=int, default=12, help="warm-up steps of the halo in front of a rank's block (--split-sequence)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short PARK / OS128 sub-runs that the default invocation appends under extras.configs")
     ap.add_argument("--no-map", action="store_true", help="leave the static map out of the step (profiling)")
     ap.add_argument("--track-mode", default="chain", choices=["chain", "first-order"], help="chain: the reference's sequential tracking chain (default); first-order: every pair independent")
@@ -156,8 +158,15 @@ def main():
     if args.skip <= 0:
         args.skip = 1 if args.preset == "parkinglot" else 5
     job = shard.weak_scaling_sequences(args.sequences or world, args.scans)
-    plan = shard.plan_job(world, job, skip=args.skip)[rank]
+    split = None
+    if args.split_sequence:  # one sequence, contiguous blocks (+ halo) per rank
+        job = job[:1]
+        split = shard.plan_split(world, args.scans, skip=args.skip, warm=args.split_halo)[rank]
+        plan = dict(scans=[(job[0][0], job[0][1] + i) for i in range(split["lo"], split["hi"])], next_scan=split["next_scan"], skip=args.skip)
+    else:
+        plan = shard.plan_job(world, job, skip=args.skip)[rank]
     n_sc = len(plan["scans"])
+    own_first, own_count = (split["own_first"], split["own_count"]) if split else (0, n_sc)
 
     # ---- the rank's scans, resident in HBM ----
     t0 = time.time()
@@ -184,6 +193,8 @@ def main():
         ctx.set_cluster_exact(True)
     if args.max_name_fresh:
         ctx.set_max_name_literal(False)
+    if split:
+        ctx.set_track_owned(own_first)
     stream = torch.cuda.current_stream().cuda_stream  # torch.distributed orders its work against this stream
     nxt = plan["next_scan"]
     T = np.zeros((n_sc, 12), np.float32)
@@ -219,12 +230,17 @@ def main():
         after()
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         after()
+        if split and world > 1:  # the chain's state at the block boundaries: from rank to rank, walked again where the warm-up missed it
+            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
         if smap is not None:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             smap.clear(stream=stream)
-            smap.accumulate(ctx, poses, stream=stream)
+            if split:
+                smap.accumulate_range(ctx, poses, own_first, own_count, stream=stream)
+            else:
+                smap.accumulate(ctx, poses, stream=stream)
             if timed:
                 e1.record()
                 e1.synchronize()
@@ -264,7 +280,12 @@ def main():
         ctx.batch_cluster_types(stream=stream, sync=False)
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         smap.clear(stream=stream)
-        smap.accumulate(ctx, poses, stream=stream)
+        if split:
+            if world > 1:
+                shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            smap.accumulate_range(ctx, poses, own_first, own_count, stream=stream)
+        else:
+            smap.accumulate(ctx, poses, stream=stream)
         _, counts0 = smap.export_parts(world, stream=stream)
         t_cap = torch.tensor([max(counts0)], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t_cap, op=dist.ReduceOp.MAX)
@@ -324,13 +345,14 @@ def main():
         dist.all_reduce(t_cells)
         map_cells = int(t_cells.item())
     if args.dump_map:
-        dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(n_sc)], np.int64)
+        dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(own_first, own_first + own_count)], np.int64)
         gathered = [None] * world
         mine = (pmap if multi else smap).export().cpu().numpy().view(np.uint64)
+        own_scans = [list(map(int, q)) for q in plan["scans"][own_first:own_first + own_count]]
         if dist is not None:
-            dist.all_gather_object(gathered, (rank, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist(), mine))
+            dist.all_gather_object(gathered, (rank, own_scans, dynpts.tolist(), mine))
         else:
-            gathered = [(0, [list(map(int, q)) for q in plan["scans"]], dynpts.tolist(), mine)]
+            gathered = [(0, own_scans, dynpts.tolist(), mine)]
         if rank == 0:
             rec = np.concatenate([g[3] for g in gathered])
             assert len(np.unique(rec[:, 0])) == len(rec), "a cell is owned by exactly one rank"
@@ -368,7 +390,8 @@ def main():
         except Exception as e:
             extras["ingest_error"] = str(e)[:200]
 
-    dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, n_sc, total_pts)
+    own_pts = int(offs[own_first + own_count] - offs[own_first])
+    dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, own_count, own_pts)
 
     if rank == 0:
         scans_per_s = all_scans * args.steps / dt
@@ -452,15 +475,19 @@ def main():
         extras["cpu_all_threads"] = cpu_all
         out = {"metric": "scans/sec on SemanticKITTI-seq-05-shaped input (SCV-OD dynamic-removal path, raw scans -> per-point labels + static map)",
                "value": scans_per_s, "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 and len(job) == 1 else
+                                       f"seq05-shaped {args.kind} sequence, {args.scans} scans, {args.preset}.yaml grid, split over {world} ranks" if split else
                                        f"{len(job)} sequences of {args.scans} {args.kind} scans (seeded like seq 05, 00, 02, 08, ...), {int(all_scans)} scans in total, whole sequences per rank, {args.preset}.yaml grid"),
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
                           "static_map_cells": map_cells, "static_map_table_cells": info.get("map_table_cells", (cells if smap is not None else None)), "tracking": args.track_mode, "tracking_chain": chain_stats, "clustering": cluster_stats, "max_name": max_name_stats,
                           "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
-                          "tracking_stride": args.skip, "sharding": "whole sequences per rank (longest first to the least loaded rank)"},
+                          "tracking_stride": args.skip,
+                          "sharding": (f"one sequence, contiguous blocks per rank + a halo of {args.split_halo} x {args.skip} scans; the tracking chain's state at a block boundary is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else
+                                       "whole sequences per rank (longest first to the least loaded rank)"),
+                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary")} if split else None)},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
         if multi:

@@ -78,6 +78,10 @@ struct scvod_ctx {
     ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
     int32_t* d_chain_fw = nullptr;           // [cap_scans + 1]
     int32_t* d_chain_stats = nullptr;        // [8]
+    std::vector<uint8_t> halo;               // per scan of a batch: 1 = halo (warmed up over, never decided): scvod_set_track_owned / _halo
+    ChainJob last_cj;                        // the chain job of the last scvod_batch_track (export / resume)
+    TrackBatch last_tb;
+    const unsigned char** d_ext_state = nullptr;  // [cap_scans] device array of the states a resume compares with
     std::vector<int32_t> up_chain_scans, up_chain_fw, up_chain_walkers;
     void* chain_ws = nullptr;                // walkers' workspace (own allocation, grows on demand)
     size_t chain_ws_bytes = 0;
@@ -271,6 +275,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     c->d_chain_walkers = k.take<ChainWalker>(B);
     c->d_chain_fw = k.take<int32_t>(B + 1);
     c->d_chain_stats = k.take<int32_t>(8);
+    c->d_ext_state = k.take<const unsigned char*>(B);
     *total = align_up(k.off, 256);
 }
 
@@ -743,10 +748,14 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
     for (size_t ci = 0; ci < chain_len.size(); ++ci) {
         const int first = chain_first[ci], n = chain_len[ci];
         const int steps = n - 1;
-        for (int a = 0; a < steps; a += seg) {
+        // frames of a halo (scvod_set_track_owned): the chain's own steps start at its first frame that is not one; the steps before
+        // are only ever a warm-up (the whole halo for the first walker: its start state has no other source on this shard)
+        int a0 = 0;
+        while (a0 < steps && (size_t)scans[first + a0] < c->halo.size() && c->halo[scans[first + a0]]) ++a0;
+        for (int a = a0; a < steps; a += seg) {
             const int b = a + seg < steps ? a + seg : steps;
-            const int t0 = a - warm > 0 ? a - warm : 0;
-            const int32_t w[8] = {first, n, a, b, t0, n_chains, 0, 0};
+            const int t0 = (a == a0 && a0 > 0) ? 0 : (a - warm > 0 ? a - warm : 0);
+            const int32_t w[8] = {first, n, a, b, t0, n_chains, (a == a0 && a0 > 0) ? 1 : 0, 0};
             walkers.insert(walkers.end(), w, w + 8);
         }
         fw.push_back((int32_t)(walkers.size() / 8));
@@ -1258,6 +1267,10 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             if ((size_t)CJ.words * 4 > lds_bits) return fail(c, SCVOD_ERR_CAPACITY, "scan too large for the chain's LDS bitset");
             CJ.force_generic = c->chain_generic ? 1 : 0;
             CJ.literal_max_name = (c->max_name_literal && c->last_name_valid) ? 1 : 0;
+            CJ.ext_state = nullptr;
+            CJ.resume = 0;
+            c->last_cj = CJ;
+            c->last_tb = J;
             c->chain_ran = true;
         }
     }
@@ -1268,6 +1281,71 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     c->tables_valid = true;
     c->track_valid = true;
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
+    return SCVOD_OK;
+}
+
+int scvod_set_track_owned(scvod_ctx* c, int32_t first_owned_scan) {
+    if (!c || first_owned_scan < 0) return fail(c, SCVOD_ERR_INVALID, "bad first owned scan");
+    c->halo.assign((size_t)first_owned_scan, 1);
+    c->track_valid = false;
+    return SCVOD_OK;
+}
+
+int scvod_set_track_halo(scvod_ctx* c, const uint8_t* h_is_halo, int32_t n_scans) {
+    if (!c || n_scans < 0 || (n_scans > 0 && !h_is_halo)) return fail(c, SCVOD_ERR_INVALID, "bad halo mask");
+    c->halo.assign(h_is_halo, h_is_halo + n_scans);
+    c->track_valid = false;
+    return SCVOD_OK;
+}
+
+int64_t scvod_chain_state_bytes(scvod_ctx* c) {
+    if (!c || !c->chain_ran) return 0;
+    return (int64_t)chain_state_bytes(c->last_cj.ws);
+}
+
+int scvod_chain_export_state(scvod_ctx* c, int32_t chain, int32_t which, void* d_dst, int64_t cap_bytes, void* stream) {
+    if (!c || !d_dst || (which != 0 && which != 1)) return SCVOD_ERR_INVALID;
+    if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "no tracking chain of the last batch");
+    if (chain < 0 || chain >= c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "chain %d out of range (%d chains)", chain, c->last_cj.n_chains);
+    if (cap_bytes < 16) return fail(c, SCVOD_ERR_CAPACITY, "state buffer too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    launch_chain_export_state(c->last_cj, chain, which, (unsigned char*)d_dst, cap_bytes, st);
+    HIPCHK(c, hipGetLastError());
+    return SCVOD_OK;
+}
+
+int scvod_batch_track_chains(scvod_ctx* c, int32_t* h_first_scan, int32_t cap) {
+    if (!c || !h_first_scan) return SCVOD_ERR_INVALID;
+    if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "no tracking chain of the last batch");
+    const int nc = c->last_cj.n_chains;
+    if (cap < nc) return fail(c, SCVOD_ERR_CAPACITY, "output buffer too small (%d < %d chains)", cap, nc);
+    // a chain without a step of its own has no walker: its head is reported all the same (up_chain_fw / up_chain_scans hold the plan)
+    int k = 0;
+    std::vector<char> is_succ(c->up_next.size(), 0);
+    for (size_t s = 0; s < c->up_next.size(); ++s)
+        if (c->up_next[s] >= 0) is_succ[c->up_next[s]] = 1;
+    for (size_t s = 0; s < c->up_next.size() && k < nc; ++s)
+        if (!is_succ[s] && c->up_next[s] >= 0) h_first_scan[k++] = (int32_t)s;
+    return nc;
+}
+
+int scvod_batch_track_resume(scvod_ctx* c, const void* const* h_d_states, int32_t n_states, void* stream, int32_t sync) {
+    if (!c || !h_d_states) return SCVOD_ERR_INVALID;
+    if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track_resume needs a chain-mode scvod_batch_track first");
+    if (n_states != c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "%d states for %d chains", n_states, c->last_cj.n_chains);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->last_stream = st;
+    HIPCHK(c, hipMemcpyAsync((void*)c->d_ext_state, h_d_states, sizeof(void*) * (size_t)n_states, hipMemcpyHostToDevice, st));
+    ChainJob CJ = c->last_cj;
+    CJ.ext_state = c->d_ext_state;
+    CJ.resume = 1;
+    launch_track_chain_resume(c->dev, c->A, c->last_tb, CJ, c->batch_mode == 2 ? 1 : 0, st);
+    launch_track_dyn(c->A, c->batch_mode == 2 ? 1 : 0, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));  // (the pointer table is a pageable host array)
+    (void)sync;
     return SCVOD_OK;
 }
 

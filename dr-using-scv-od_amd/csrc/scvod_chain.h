@@ -10,7 +10,9 @@ struct ChainWalker {      // one workgroup of k_tk_chain: steps [a, b) of a chai
     int32_t n_frames;     // frames of the chain (steps: n_frames - 1)
     int32_t a, b, t0;
     int32_t chain;
-    int32_t pad0, pad1;
+    int32_t ext;          // 1: the chain's first walker, and the chain continues one that another shard walked: its steps [t0, a) are a
+                          //    warm-up like any other walker's, the state it has to match at step a arrives later (scvod_batch_track_resume)
+    int32_t pad1;
 };
 
 struct ChainWs {          // geometry of the walkers' workspace: walker w lives at base + w * stride
@@ -33,6 +35,8 @@ struct ChainJob {
     int32_t words;        // bitset words of an evaluating wave
     int32_t n_eval_waves;
     int32_t force_generic;  // testing: every step through the HBM-resident generic path
+    const unsigned char* const* ext_state;  // [n_chains] resume: the state the chain's predecessor (on another shard) really ended in, or nullptr
+    int32_t resume;       // k_tk_chain_fix: compare the first walker's warm-up snapshot with ext_state first, walk it again when they differ
     int32_t literal_max_name;  // 1: a frame's first new cluster re-uses Frame::max_name as ssc.cpp:354 stores it (Arena::cc_last)
 };
 
@@ -59,6 +63,13 @@ __device__ __forceinline__ int tk_find_slot(const int4* __restrict__ tab, int a0
 
 void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st,
                         TimerHook th, void* tu);
+// the verification pass again, first walkers against the states of ChainJob::ext_state (C.resume = 1)
+void launch_track_chain_resume(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st);
+// a chain's boundary state as one record: int32 {entries, carried points, parts, valid}, then entries (2 int4 each), parts (int32,
+// padded to 16 bytes), carried points (float4).  which = 0: what the chain's first walker assumed at its first own step (its
+// warm-up snapshot), 1: what the chain's last walker ended in.
+void launch_chain_export_state(const ChainJob& C, int chain, int which, unsigned char* dst, long long cap_bytes, hipStream_t st);
+size_t chain_state_bytes(const ChainWs& ws);
 
 }  // namespace scvod
 #endif

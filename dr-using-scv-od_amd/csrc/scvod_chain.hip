@@ -232,6 +232,57 @@ __device__ __forceinline__ bool same_state(const Wk& A, int sa, const Wk& B, int
     return __syncthreads_or(diff) == 0;
 }
 
+// a state as an external record (scvod_chain.h): header {ne, nc, np, valid}, entries, parts (padded to 16 bytes), carried points
+struct ExtRec {
+    const int32_t* hdr;
+    const int4* ent;
+    const int32_t* parts;
+    const float4* pool;
+};
+__device__ __forceinline__ ExtRec ext_of(const unsigned char* b) {
+    ExtRec r;
+    r.hdr = (const int32_t*)b;
+    const int ne = r.hdr[0], np = r.hdr[2];
+    r.ent = (const int4*)(b + 16);
+    r.parts = (const int32_t*)(b + 16 + (size_t)32 * ne);
+    r.pool = (const float4*)(b + 16 + (size_t)32 * ne + (((size_t)4 * np + 15) & ~(size_t)15));
+    return r;
+}
+__device__ __forceinline__ bool same_state_ext(const Wk& A, int sa, const ExtRec& B) {
+    const int ne = A.hdr[H_NENT + sa], nc = A.hdr[H_NCARRIED + sa], np = A.hdr[H_NPARTS + sa];
+    int diff = (ne != B.hdr[0]) || (nc != B.hdr[1]) || (np != B.hdr[2]);
+    if (!diff) {
+        for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) {
+            const int4 x = A.ent[sa][i], y = B.ent[i];
+            diff |= (int)(x.x != y.x) | (int)(x.y != y.y) | (int)(x.z != y.z) | (int)(x.w != y.w);
+        }
+        for (int i = threadIdx.x; i < np; i += kChThreads) diff |= A.parts[sa][i] != B.parts[i];
+        for (int i = threadIdx.x; i < nc; i += kChThreads) {
+            const float4 x = A.pool[sa][i], y = B.pool[i];
+            diff |= (int)(__float_as_uint(x.x) != __float_as_uint(y.x)) | (int)(__float_as_uint(x.y) != __float_as_uint(y.y)) |
+                    (int)(__float_as_uint(x.z) != __float_as_uint(y.z));
+        }
+    }
+    return __syncthreads_or(diff) == 0;
+}
+__device__ __forceinline__ void copy_from_ext(const ExtRec& B, const Wk& K, int dst, int cap_ent, int cap_pool, int32_t* stats) {
+    int ne = B.hdr[0], nc = B.hdr[1], np = B.hdr[2];
+    if (ne > cap_ent || np > cap_ent || nc > cap_pool) {  // (a state of another shard that outgrows this one's workspace: flagged)
+        if (threadIdx.x == 0) atomicOr(&stats[0], nc > cap_pool ? 1 : 2);
+        ne = min(ne, cap_ent), np = min(np, cap_ent), nc = 0;
+    }
+    for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) K.ent[dst][i] = B.ent[i];
+    for (int i = threadIdx.x; i < np; i += kChThreads) K.parts[dst][i] = B.parts[i];
+    for (int i = threadIdx.x; i < nc; i += kChThreads) K.pool[dst][i] = B.pool[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        K.hdr[H_NENT + dst] = ne;
+        K.hdr[H_NCARRIED + dst] = nc;
+        K.hdr[H_NPARTS + dst] = np;
+    }
+    __syncthreads();
+}
+
 // the freshly segmented car clusters of scan s as a state: one entry per cluster, nothing carried
 __device__ __forceinline__ void fresh_state(const Arena& A, const Wk& K, int slot, int s, int cap_ent, int32_t* stats) {
     const int base = A.scan_off[s];
@@ -1266,7 +1317,7 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_cmp(ChainJob C) {
     const ChainWalker W = C.walkers[w];
     const Wk K = wk_of(C.ws, w);
     int ok = 1;
-    if (W.a > 0) {  // (the first segment of a chain starts from the true state)
+    if (W.a > 0 && !W.ext) {  // (the first segment of a chain starts from the true state -- or from the one another shard sends later)
         const Wk Kp = wk_of(C.ws, w - 1);
         ok = K.hdr[H_HAS_SNAP] != 0 && same_state(Kp, Kp.hdr[H_END_SLOT], K, 2);
     }
@@ -1285,7 +1336,7 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_spec(DevParams P, Arena
     extern __shared__ uint32_t ch_bits[];
     const int w = blockIdx.x;
     const ChainWalker W = C.walkers[w];
-    if (W.a == 0) return;  // the first segment of a chain
+    if (W.a == 0 || W.ext) return;  // the first segment of a chain
     const Wk K = wk_of(C.ws, w), Kp = wk_of(C.ws, w - 1);
     if (K.hdr[H_SNAP_OK] != 0 || Kp.hdr[H_SNAP_OK] == 0) return;  // passed / the predecessor is being walked again itself
     for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
@@ -1305,6 +1356,28 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
     __shared__ Shared sh;
     extern __shared__ uint32_t ch_bits[];
     const int w0 = C.chain_first_walker[blockIdx.x], w1 = C.chain_first_walker[blockIdx.x + 1];
+    if (w1 <= w0) return;  // (a chain without a step of its own)
+    // resume: the state this chain's first walker had to match has arrived from the shard that walked the frames before
+    bool first_rewalked = false;
+    if (C.resume) {
+        const ChainWalker W0 = C.walkers[w0];
+        const unsigned char* ext = C.ext_state ? C.ext_state[blockIdx.x] : nullptr;
+        if (!W0.ext || !ext) return;
+        const Wk K0 = wk_of(C.ws, w0);
+        const ExtRec R = ext_of(ext);
+        if (threadIdx.x == 0) atomicAdd(&C.stats[2], 1);
+        const bool ok = R.hdr[3] != 0 && K0.hdr[H_HAS_SNAP] != 0 && same_state_ext(K0, 2, R);
+        if (ok) return;  // the warm-up reproduced it: everything behind stands
+        if (R.hdr[3] == 0) return;  // (no state to start from: nothing to do)
+        for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
+        copy_from_ext(R, K0, 0, C.ws.cap_ent, C.ws.cap_pool, C.stats);
+        const int end = walk(P, A, J, C, K0, sh, ch_bits, W0, 0, W0.a, W0.b, W0.a, -1, from_apri);
+        if (threadIdx.x == 0) K0.hdr[H_END_SLOT] = end;
+        __syncthreads();
+        first_rewalked = true;
+    }
     // the verdicts of k_tk_chain_cmp, fetched by all threads at once: next_bad[i] = first walker >= w0 + 1 + i whose check failed
     constexpr int kFixLds = 1024;
     __shared__ int32_t next_bad[kFixLds + 1];
@@ -1316,8 +1389,8 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
         if (i < nchk) next_bad[i] = ok ? 0x7fffffff : w0 + 1 + i;
     }
     all_ok = __syncthreads_and(all_ok);
-    if (threadIdx.x == 0) atomicAdd(&C.stats[2], w1 - w0 - 1);
-    if (all_ok) return;
+    if (threadIdx.x == 0 && !C.resume) atomicAdd(&C.stats[2], w1 - w0 - 1);
+    if (all_ok && !first_rewalked) return;
     if (threadIdx.x == 0) {  // suffix minimum (a chain has a few hundred segments)
         next_bad[nchk] = (w0 + 1 + nchk < w1) ? w0 + 1 + nchk : 0x7fffffff;  // (beyond the table: taken one by one)
         for (int i = nchk - 1; i >= 0; --i) next_bad[i] = min(next_bad[i], next_bad[i + 1]);
@@ -1325,7 +1398,7 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
     for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
     __syncthreads();
     int w = w0 + 1;
-    bool prev_rewalked = false;
+    bool prev_rewalked = first_rewalked;
     while (w < w1) {
         if (!prev_rewalked) {  // jump to the next segment whose check failed
             const int i = w - (w0 + 1);
@@ -1357,6 +1430,51 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
         __syncthreads();
         ++w;
     }
+}
+
+size_t chain_state_bytes(const ChainWs& ws) { return 16 + (size_t)32 * ws.cap_ent + (((size_t)4 * ws.cap_ent + 15) & ~(size_t)15) + (size_t)16 * ws.cap_pool; }
+
+__global__ __launch_bounds__(kChThreads) void k_tk_chain_export(ChainJob C, int chain, int which, unsigned char* dst, long long cap_bytes) {
+    const int w0 = C.chain_first_walker[chain], w1 = C.chain_first_walker[chain + 1];
+    int32_t* hdr = (int32_t*)dst;
+    bool valid = w1 > w0;
+    Wk K = wk_of(C.ws, valid ? (which == 0 ? w0 : w1 - 1) : 0);
+    int slot = 0;
+    if (valid) {
+        if (which == 0) {
+            valid = C.walkers[w0].ext != 0 && K.hdr[H_HAS_SNAP] != 0;
+            slot = 2;
+        } else {
+            slot = K.hdr[H_END_SLOT];
+        }
+    }
+    const int ne = valid ? K.hdr[H_NENT + slot] : 0, nc = valid ? K.hdr[H_NCARRIED + slot] : 0, np = valid ? K.hdr[H_NPARTS + slot] : 0;
+    const size_t need = 16 + (size_t)32 * ne + (((size_t)4 * np + 15) & ~(size_t)15) + (size_t)16 * nc;
+    if ((long long)need > cap_bytes) valid = false;
+    if (threadIdx.x == 0) {
+        hdr[0] = valid ? ne : 0;
+        hdr[1] = valid ? nc : 0;
+        hdr[2] = valid ? np : 0;
+        hdr[3] = valid ? 1 : 0;
+    }
+    if (!valid) return;
+    int4* ent = (int4*)(dst + 16);
+    int32_t* parts = (int32_t*)(dst + 16 + (size_t)32 * ne);
+    float4* pool = (float4*)(dst + 16 + (size_t)32 * ne + (((size_t)4 * np + 15) & ~(size_t)15));
+    for (int i = threadIdx.x; i < 2 * ne; i += kChThreads) ent[i] = K.ent[slot][i];
+    for (int i = threadIdx.x; i < np; i += kChThreads) parts[i] = K.parts[slot][i];
+    for (int i = threadIdx.x; i < nc; i += kChThreads) pool[i] = K.pool[slot][i];
+}
+
+void launch_chain_export_state(const ChainJob& C, int chain, int which, unsigned char* dst, long long cap_bytes, hipStream_t st) {
+    hipLaunchKernelGGL(k_tk_chain_export, dim3(1), dim3(kChThreads), 0, st, C, chain, which, dst, cap_bytes);
+}
+
+void launch_track_chain_resume(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st) {
+    if (C.n_walkers <= 0) return;
+    const size_t dyn = (size_t)C.n_eval_waves * C.words * 4;
+    hipFuncSetAttribute((const void*)k_tk_chain_fix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(k_tk_chain_fix, dim3(C.n_chains), dim3(kChThreads), dyn, st, P, A, J, C, from_apri);
 }
 
 void launch_track_chain(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, int from_apri, hipStream_t st,

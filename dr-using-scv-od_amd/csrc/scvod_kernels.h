@@ -215,6 +215,7 @@ void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int bat
 struct ChainJob;
 void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J, int from_apri, int phases, hipStream_t st,
                         TimerHook th, void* tu, const ChainJob* chain = nullptr, hipEvent_t before_chain = nullptr);
+void launch_track_dyn(const Arena& A, int from_apri, hipStream_t st);  // per-point bytes from the cluster states (again, after a resume)
 void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st);
 void launch_nn(const float* map_xyz, int32_t n_map, const float* q_xyz, int32_t n_q, float radius, int32_t* nn_idx,
                float* nn_sq, uint8_t* within, const float origin[3], float cell, int32_t buckets, int* work, int bounded,

@@ -144,10 +144,10 @@ __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mas
 // from the byte k_emit / k_tk_dyn left per input point): a sweep's neighbours in memory are neighbours in space, so runs of
 // consecutive lanes that fall into the same cell are reduced in the wave first (segmented min over the run) and only the
 // head of a run probes the table in HBM.
-__global__ __launch_bounds__(256) void k_map_accumulate(Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
+__global__ __launch_bounds__(256) void k_map_accumulate(int s_first, Arena A, const float* __restrict__ pose, MapRec* table, unsigned long long mask,
                                                         float inv_leaf, int with_ground, int with_rejected, int have_dyn, int have_pid,
                                                         int min_pts, int marks, int part, unsigned long long* counters) {
-    const int s = blockIdx.y;
+    const int s = s_first + blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.scan_off[s + 1] - base;
     const int lane = threadIdx.x & 63;
@@ -489,6 +489,10 @@ void scvod_pose_matrix(const float p[6], float t[12]) {
 }
 
 int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_poses, int32_t flags, void* stream) {
+    return scvod_batch_map_accumulate_range(ctx, m, h_poses, flags, 0, -1, stream);
+}
+
+int scvod_batch_map_accumulate_range(scvod_ctx* ctx, scvod_map* m, const float* h_poses, int32_t flags, int32_t first, int32_t count, void* stream) {
     if (!ctx || !m || !h_poses) return mfail(m, SCVOD_ERR_INVALID, "bad arguments");
     Arena A;
     int device = 0, track_valid = 0, batch_valid = 0, n_scans = 0, max_pts = 0, mode = 0, min_pts = 0;
@@ -518,12 +522,14 @@ int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* m, const float* h_pose
         m->up_pose = T;
         MHIP(m, hipMemcpyAsync(m->d_pose, m->up_pose.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice, st));
     }
-    if (max_pts > 0) {
+    if (count < 0) count = n_scans - first;
+    if (first < 0 || count < 0 || first + count > n_scans) return mfail(m, SCVOD_ERR_INVALID, "scan range [%d, %d) outside the batch of %d", first, first + count, n_scans);
+    if (max_pts > 0 && count > 0) {
         const int need_lists = (flags & (SCVOD_MAP_NO_GROUND | SCVOD_MAP_NO_REJECTED)) ? 1 : 0;
         if (need_lists) {  // rare: a map without the ground / without the range-FOV rejects needs those two lists marked
             hipLaunchKernelGGL(k_map_mark_lists, dim3((max_pts + 2047) / 2048, n_scans), dim3(256), 0, st, A);
         }
-        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + kMapPts - 1) / kMapPts, n_scans), dim3(256), 0, st, A, m->d_pose, m->table,
+        hipLaunchKernelGGL(k_map_accumulate, dim3((max_pts + kMapPts - 1) / kMapPts, count), dim3(256), 0, st, first, A, m->d_pose, m->table,
                            (unsigned long long)(m->capacity - 1), 1.0f / m->leaf, (flags & SCVOD_MAP_NO_GROUND) ? 0 : 1,
                            (flags & SCVOD_MAP_NO_REJECTED) ? 0 : 1, use_dyn, mode == 1 ? 1 : 0, min_pts, (use_dyn || need_lists || part) ? 1 : 0, part, m->counters);
         MHIP(m, hipGetLastError());

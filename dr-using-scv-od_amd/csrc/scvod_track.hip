@@ -397,6 +397,12 @@ void launch_track_batch(const DevParams& P, const Arena& A, const TrackBatch& J,
     TH_END("tk_dyn");
 }
 
+void launch_track_dyn(const Arena& A, int from_apri, hipStream_t st) {
+    if (A.n_scans <= 0 || A.max_scan_pts <= 0) return;
+    const dim3 g((A.max_scan_pts + 2047) / 2048, A.n_scans);
+    hipLaunchKernelGGL(k_tk_dyn, g, dim3(256), 0, st, A, from_apri);
+}
+
 void launch_export_table(const Arena& A, int s, int4* out, long long cap_records, hipStream_t st) {
     hipLaunchKernelGGL(k_tk_export, dim3(64), dim3(256), 0, st, A, s, out, cap_records);
 }

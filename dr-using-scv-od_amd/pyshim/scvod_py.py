@@ -130,6 +130,13 @@ def load_lib():
         "scvod_set_max_name_literal": (C.c_int, [vp, i32]),
         "scvod_batch_cluster_last_name": (C.c_int, [vp, vp, i32, vp]),
         "scvod_set_chain_capacity": (C.c_int, [vp, i64]),
+        "scvod_set_track_owned": (C.c_int, [vp, i32]),
+        "scvod_set_track_halo": (C.c_int, [vp, vp, i32]),
+        "scvod_batch_track_chains": (C.c_int, [vp, vp, i32]),
+        "scvod_chain_state_bytes": (i64, [vp]),
+        "scvod_chain_export_state": (C.c_int, [vp, i32, i32, vp, i64, vp]),
+        "scvod_batch_track_resume": (C.c_int, [vp, vp, i32, vp, i32]),
+        "scvod_batch_map_accumulate_range": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "scvod_batch_track_stats": (C.c_int, [vp, vp]),
         "scvod_batch_track_tables": (C.c_int, [vp, vp]),
         "scvod_map_create": (C.c_int, [C.c_int, i64, f32, C.POINTER(vp)]),
@@ -165,7 +172,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
@@ -233,6 +240,7 @@ class Ctx:
     def __init__(self, params, max_points_total, max_scans=1, device=0, pw=None):
         self.lib = load_lib()
         self.params = params
+        self.device = int(device)
         self.h = C.c_void_p()
         rc = self.lib.scvod_create(C.byref(params), C.byref(pw) if pw is not None else None, device,
                                    int(max_points_total), int(max_scans), C.byref(self.h))
@@ -371,6 +379,39 @@ class Ctx:
         ptrs = (C.c_void_p * max(n_ext, 1))(*[C.c_void_p(e.data_ptr()) for e in (ext_tables or [])])
         self._ext_keep = ext_tables  # the device buffers must outlive the asynchronous launch
         self._chk(self.lib.scvod_batch_track(self.h, pt, pn, ptrs if n_ext else None, n_ext, C.c_void_p(stream or 0), int(sync)))
+
+    # ---- one sequence over several shards (include/scvod.h: scvod_set_track_owned ...) ----
+    def set_track_owned(self, first_owned_scan):
+        self._chk(self.lib.scvod_set_track_owned(self.h, int(first_owned_scan)))
+
+    def set_track_halo(self, is_halo):
+        m = np.ascontiguousarray(is_halo, np.uint8)
+        self._chk(self.lib.scvod_set_track_halo(self.h, m.ctypes.data_as(C.c_void_p), len(m)))
+
+    def batch_track_chains(self):
+        """first scan of every chain of the last batch_track"""
+        out = np.zeros(max(self._n_scans, 1), np.int32)
+        n = self.lib.scvod_batch_track_chains(self.h, out.ctypes.data_as(C.c_void_p), len(out))
+        if n < 0:
+            self._chk(n)
+        return out[:n].copy()
+
+    def chain_export_state(self, chain, which, stream=None):
+        """the state chain `chain` ended in (which=1) / assumed at its first own step (which=0): a torch uint8 device tensor"""
+        import torch
+        nb = int(self.lib.scvod_chain_state_bytes(self.h))
+        buf = torch.zeros(nb, dtype=torch.uint8, device=f"cuda:{self.device}")
+        self._chk(self.lib.scvod_chain_export_state(self.h, int(chain), int(which), C.c_void_p(buf.data_ptr()), nb, C.c_void_p(stream or 0)))
+        torch.cuda.synchronize(self.device)
+        hdr = buf[:16].view(torch.int32).cpu().numpy()
+        used = 16 + 32 * int(hdr[0]) + ((4 * int(hdr[2]) + 15) // 16) * 16 + 16 * int(hdr[1])
+        return buf[:max(used, 16)].clone()
+
+    def batch_track_resume(self, states, stream=None):
+        """states[k]: the record the shard before this one exported (which=1) for chain k, or None"""
+        self._resume_keep = states
+        ptrs = (C.c_void_p * max(len(states), 1))(*[C.c_void_p(t.data_ptr() if t is not None else 0) for t in states])
+        self._chk(self.lib.scvod_batch_track_resume(self.h, ptrs, len(states), C.c_void_p(stream or 0), 1))
 
     def batch_fetch_track(self, s):
         r = TrackResult()
@@ -538,6 +579,12 @@ class StaticMap:
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
         assert p.shape[0] == ctx._n_scans
         self._chk(self.lib.scvod_batch_map_accumulate(ctx.h, self.h, p.ctypes.data_as(C.c_void_p), int(flags), C.c_void_p(stream or 0)))
+
+    def accumulate_range(self, ctx, poses, first, count, flags=0, stream=None):
+        """scans [first, first + count) of the batch only: a shard's own block without its halo"""
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        assert p.shape[0] == ctx._n_scans
+        self._chk(self.lib.scvod_batch_map_accumulate_range(ctx.h, self.h, p.ctypes.data_as(C.c_void_p), int(flags), int(first), int(count), C.c_void_p(stream or 0)))
 
     def count(self, stream=None):
         n = C.c_int64()

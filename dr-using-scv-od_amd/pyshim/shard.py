@@ -59,6 +59,114 @@ def plan_job(world, sequences, skip=1):
     return ranks
 
 
+def plan_split(world, n_scans, skip=1, warm=12):
+    """ONE sequence over `world` ranks (BASELINE north_star: "scans of a sequence shard naturally").  Rank r owns
+    the contiguous block [a_r, a_r+1) -- loop #1 of SSC::segDF (ssc.cpp:1435-1445) is per scan -- and for loop #2 (the
+    tracking chain, :1449-1451) also holds a HALO of warm x skip scans before its block (a warm-up for every interleaved
+    sub-sequence) and `skip` scans behind it (the successor of each sub-sequence's last own scan).  Returns per rank a dict:
+      lo, hi        the scans it loads: [lo, hi) of the sequence
+      own_first     local index of its first own scan (scvod_set_track_owned); own_count
+      next_scan     int32 [hi - lo]: local successor (i + skip), -1 at the end
+    Blocks are equal up to one scan: the halo is the only imbalance (warm x skip of n / world scans)."""
+    world, n, skip, warm = int(world), int(n_scans), int(skip), int(warm)
+    cuts = [(n * r) // world for r in range(world + 1)]
+    out = []
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        lo = max(0, a - warm * skip) if r > 0 else 0
+        hi = min(n, b + skip) if r + 1 < world else n
+        m = hi - lo
+        nxt = np.asarray([i + skip if i + skip < m else -1 for i in range(m)], np.int32)
+        out.append(dict(lo=lo, hi=hi, own_first=a - lo, own_count=b - a, next_scan=nxt, skip=skip))
+    return out
+
+
+def plan_job_split(world, sequences, skip=1, warm=12):
+    """BASELINE.json configs[3] with sequences that may be CUT: the scans of the job, sequence after sequence, are dealt as
+    `world` contiguous runs of equal length (up to one scan); a run that starts inside a sequence gets the halo of warm x skip
+    scans of that sequence in front (plan_split).  Returns per rank a dict:
+      pieces     [(seq_id, lo, own_a, own_b, hi)]: scans [lo, hi) of the sequence are loaded, [own_a, own_b) are the rank's own
+      scans      [(seq_id, idx)] in processing order;  next_scan  int32: local successor or -1;  is_halo  uint8 per local scan
+      own        number of own scans
+    Balance = own scans of the fullest rank against the mean: >= 0.99 by construction; the halo (<= warm x skip scans per cut)
+    is the only extra work."""
+    world, skip, warm = int(world), int(skip), int(warm)
+    total = sum(int(c) for _, _, c in sequences)
+    cuts = [(total * r) // world for r in range(world + 1)]
+    out = []
+    for r in range(world):
+        a, b = cuts[r], cuts[r + 1]
+        pieces, scans, nxt, halo = [], [], [], []
+        g0 = 0
+        for (q, first, count) in sequences:
+            q, first, count = int(q), int(first), int(count)
+            g1 = g0 + count
+            oa, ob = max(a, g0) - g0, min(b, g1) - g0  # own part of this sequence, in its own indices
+            if oa < ob:
+                lo = max(0, oa - warm * skip) if oa > 0 else 0
+                hi = min(count, ob + skip) if ob < count else count
+                base = len(scans)
+                m = hi - lo
+                for i in range(m):
+                    scans.append((q, first + lo + i))
+                    nxt.append(base + i + skip if i + skip < m else -1)
+                    halo.append(1 if lo + i < oa else 0)
+                pieces.append((q, lo, oa, ob, hi))
+            g0 = g1
+        out.append(dict(pieces=pieces, scans=scans, next_scan=np.asarray(nxt, np.int32).reshape(-1), is_halo=np.asarray(halo, np.uint8).reshape(-1),
+                        own=b - a, skip=skip))
+    return out
+
+
+def resolve_chain_boundaries(dist, ctx, plan, rank, world, device):
+    """After every rank ran scvod_batch_track on its block + halo: rank r - 1 sends the state each chain ENDED in, rank r
+    compares it with what its warm-up assumed and walks again what differs (scvod_batch_track_resume), then passes its own
+    end states on.  The ranks take their turn in order, so a correction cascades down the sequence like inside one shard;
+    the states are a few hundred KB and nothing else is exchanged.  Returns the number of chains this rank walked again."""
+    import torch
+    if world <= 1:
+        return 0
+    skip = plan["skip"]
+    backend = dist.get_backend()
+    on_dev = backend == "nccl"
+
+    def residue_of(first_local, lo):  # which interleaved sub-sequence a chain is
+        return (lo + int(first_local)) % skip
+
+    firsts = ctx.batch_track_chains()
+    rewalked = 0
+    if rank > 0:  # what the shard before really ended in, one record per sub-sequence
+        sizes = torch.zeros(skip, dtype=torch.int64, device=device if on_dev else "cpu")
+        dist.recv(sizes, src=rank - 1)
+        recs = []
+        for k in range(skip):
+            t = torch.empty(int(sizes[k].item()), dtype=torch.uint8, device=device if on_dev else "cpu")
+            if t.numel():
+                dist.recv(t, src=rank - 1)
+            recs.append(t)
+        before = ctx.batch_track_stats()["rewalked"]
+        states = [None] * len(firsts)
+        keep = []
+        for c, f in enumerate(firsts):
+            t = recs[residue_of(f, plan["lo"])]
+            if t.numel() >= 16:
+                t = t.to(device)
+                keep.append(t)
+                states[c] = t
+        ctx.batch_track_resume(states)
+        rewalked = ctx.batch_track_stats()["rewalked"] - before
+    if rank + 1 < world:
+        by_res = [torch.zeros(0, dtype=torch.uint8)] * skip
+        for c, f in enumerate(firsts):
+            by_res[residue_of(f, plan["lo"])] = ctx.chain_export_state(c, 1)
+        sizes = torch.tensor([int(t.numel()) for t in by_res], dtype=torch.int64, device=device if on_dev else "cpu")
+        dist.send(sizes, dst=rank + 1)
+        for t in by_res:
+            if t.numel():
+                dist.send(t if on_dev else t.cpu(), dst=rank + 1)
+    return rewalked
+
+
 def reduce_scatter_map(dist, send, recv=None):
     """Static-map reduce over xGMI as ONE all-to-all of equal-sized slots: `send` [world, cap, 2] int64, slot j = the records
     this rank holds for owner j (scvod_map_export_parts_padded: padded with key -1, which scvod_map_merge skips).  Returns

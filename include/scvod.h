@@ -296,6 +296,27 @@ int scvod_set_track_mode(scvod_ctx* ctx, int32_t mode, int32_t segment_steps, in
  * as the object is tracked; a state that outgrows the capacity is reported (SCVOD_ERR_CAPACITY) by scvod_batch_fetch_track /
  * scvod_batch_track_stats, never truncated silently.  Workspace = segments x ~70 bytes x this number. */
 int scvod_set_chain_capacity(scvod_ctx* ctx, int64_t pool_points);
+/* ONE sequence over several shards (SSC::segDF's loop #1, ssc.cpp:1435-1445, is per scan; loop #2, :1449-1451, is a chain).
+ * A shard processes a block of scans plus a HALO of earlier ones (warm-up steps x tracking stride) and one successor per chain
+ * behind the block.  scvod_set_track_owned(first): scans below `first` are that halo -- walked over as a warm-up, never decided
+ * (their per-point bytes stay those of the first-order pass and belong to the shard before).  After scvod_batch_track:
+ *   scvod_batch_track_chains      h_first_scan[k] = first scan of chain k (which interleaved sub-sequence it is), returns the count
+ *   scvod_chain_state_bytes       size of a boundary-state record of this job
+ *   scvod_chain_export_state      which = 1: the state chain k ENDED in (a device buffer: send it to the shard that owns the next
+ *                                 block); which = 0: the state the chain assumed at its first own step (its warm-up's snapshot)
+ *   scvod_batch_track_resume      h_d_states[k] = device pointer of the record the previous shard sent for chain k (NULL: none):
+ *                                 compared bit for bit with that snapshot; a chain whose warm-up did not reproduce it is walked
+ *                                 again from the received state (and verified / walked on segment by segment, like inside one
+ *                                 shard), then the per-point bytes are rebuilt.  scvod_batch_track_stats counts the checks and walks.
+ * The result is the single-shard chain's, whatever the halo length. */
+int scvod_set_track_owned(scvod_ctx* ctx, int32_t first_owned_scan);
+/* the same per scan (a shard that holds blocks of several sequences): h_is_halo[s] != 0 marks scan s as halo; a chain's halo
+ * scans must be its first ones */
+int scvod_set_track_halo(scvod_ctx* ctx, const uint8_t* h_is_halo, int32_t n_scans);
+int scvod_batch_track_chains(scvod_ctx* ctx, int32_t* h_first_scan, int32_t cap);
+int64_t scvod_chain_state_bytes(scvod_ctx* ctx);
+int scvod_chain_export_state(scvod_ctx* ctx, int32_t chain, int32_t which, void* d_dst, int64_t cap_bytes, void* stream);
+int scvod_batch_track_resume(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, void* stream, int32_t sync);
 /* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
  * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.
  * Returns SCVOD_ERR_CAPACITY when a chain state did not fit the walkers' workspace (the result is then invalid). */
@@ -442,6 +463,8 @@ int scvod_map_clear(scvod_map* map, void* stream);
 void scvod_pose_matrix(const float pose[6], float T_out[12]);
 /* adds the static points of every scan of ctx's last batch: h_poses [n_scans][6].  Asynchronous on `stream`. */
 int scvod_batch_map_accumulate(scvod_ctx* ctx, scvod_map* map, const float* h_poses, int32_t flags, void* stream);
+/* the same for scans [first, first + count) of the batch only (a shard's own block, without its halo); h_poses still [n_scans][6] */
+int scvod_batch_map_accumulate_range(scvod_ctx* ctx, scvod_map* map, const float* h_poses, int32_t flags, int32_t first, int32_t count, void* stream);
 /* occupied cells as 16-byte records {uint64 cell key, uint64 packed point} into device memory (NULL: count only);
  * *n_out = number of cells.  Synchronises `stream`.  Record order is unspecified (sort by key for a canonical order). */
 int scvod_map_export(scvod_map* map, void* d_records, int64_t cap_records, int64_t* n_out, void* stream);

@@ -50,3 +50,16 @@ def test_rccl_leg_at_one_rank(tmp_path):
     assert np.array_equal(m0["dynamic_points"], m1["dynamic_points"])
     assert np.array_equal(m0["keys"], m1["keys"]) and np.array_equal(m0["vals"], m1["vals"])
     assert plain["config"]["static_map_cells"] == rccl["config"]["static_map_cells"]
+
+
+def test_one_sequence_split_over_two_ranks(tmp_path):
+    """bench.py --split-sequence: one PARK sequence (one chain, stride 1) in two blocks on two gloo ranks of one device; a halo
+    of two steps cannot rebuild the carried clouds, so the second rank has to walk its chain again from the state the first
+    one sends -- and the per-scan results and the merged map are those of the single-rank run, bit for bit."""
+    one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "60"])
+    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "60", "--same-device", "--split-sequence", "--split-halo", "2"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["split"]["own"] == 30
+    assert np.array_equal(m1["scans"], m2["scans"]) and len(m2["scans"]) == 60
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
+    assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])

@@ -1,0 +1,77 @@
+"""ONE sequence over several shards (north_star: "scans of a sequence shard naturally"): a shard holds its block,
+a halo of earlier scans and one successor per interleaved sub-sequence; the tracking chain's state at the block boundary comes
+from the shard before, is compared with what the halo's warm-up assumed and walked again from when it differs
+(scvod_set_track_owned / scvod_chain_export_state / scvod_batch_track_resume).  The result must be the single-shard chain's,
+whatever the halo length."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tracked(scvod, P, d, offs, poses, lo, hi, skip, owned_first=0):
+    import torch
+    o = (np.asarray(offs[lo:hi + 1]) - offs[lo]).astype(np.int32)
+    n = hi - lo
+    ctx = scvod.Ctx(P, max_points_total=int(o[-1]) + 64, max_scans=n)
+    ctx.batch_process(d[int(offs[lo]):int(offs[hi])].contiguous(), o)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    nxt = np.asarray([i + skip if i + skip < n else -1 for i in range(n)], np.int32)
+    T = np.zeros((n, 12), np.float32)
+    for i in range(n):
+        if nxt[i] >= 0:
+            T[i] = ctx.pose_delta(poses[lo + i], poses[lo + nxt[i]])
+    ctx.set_track_owned(owned_first)
+    ctx.batch_track(T, next_scan=nxt)
+    assert ctx.batch_track_stats()["error_bits"] == 0
+    return ctx
+
+
+@pytest.mark.parametrize("halo_steps", [1, 12])
+def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
+    import synth
+    import torch
+    P = scvod.make_params("semantickitti")
+    skip, count, cut = 5, 110, 70
+    scans = [synth.make_scan(5, 900 + k, "K64", device="cuda") for k in range(count)]  # consecutive scans: parked objects are tracked for tens of frames
+    d = torch.cat([sc[0] for sc in scans]).contiguous()
+    offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int64)
+    poses = np.asarray([sc[2] for sc in scans], np.float32)
+    whole = _tracked(scvod, P, d, offs, poses, 0, count, skip)
+    want = [whole.batch_fetch_track(s) for s in range(count)]
+    assert sum(t["n_dynamic_points"] for t in want) > 0
+    whole.close()
+    # shard A: scans [0, cut + skip): its block and the successor of every sub-sequence's last own scan
+    A = _tracked(scvod, P, d, offs, poses, 0, cut + skip, skip)
+    firsts_a = A.batch_track_chains()
+    assert sorted(firsts_a) == list(range(skip))
+    end = {int(f) % skip: A.chain_export_state(c, 1) for c, f in enumerate(firsts_a)}
+    for s in range(cut):
+        assert np.array_equal(A.batch_fetch_track(s)["pt_dyn"], want[s]["pt_dyn"]), s
+    A.close()
+    # shard B: a halo of halo_steps x skip scans in front of its block
+    lo = cut - halo_steps * skip
+    B = _tracked(scvod, P, d, offs, poses, lo, count, skip, owned_first=cut - lo)
+    firsts_b = B.batch_track_chains()
+    before = [B.batch_fetch_track(s - lo)["pt_dyn"] for s in range(cut, count)]
+    st0 = B.batch_track_stats()
+    B.batch_track_resume([end[(lo + int(f)) % skip] for f in firsts_b])
+    st1 = B.batch_track_stats()
+    assert st1["error_bits"] == 0 and st1["verified"] == st0["verified"] + skip  # every sub-sequence's boundary was compared
+    differ_before = sum(int((before[s - cut] != want[s]["pt_dyn"]).sum()) for s in range(cut, count))
+    for s in range(cut, count):
+        t = B.batch_fetch_track(s - lo)
+        assert np.array_equal(t["pt_dyn"], want[s]["pt_dyn"]), (s, int((t["pt_dyn"] != want[s]["pt_dyn"]).sum()))
+        assert t["n_dynamic_clusters"] == want[s]["n_dynamic_clusters"] and t["n_dynamic_points"] == want[s]["n_dynamic_points"]
+    if halo_steps == 1:  # one warm-up step cannot rebuild clouds that were appended over ten frames: the boundary state differs, chains are walked again
+        assert st1["rewalked"] > st0["rewalked"]
+    else:
+        assert differ_before == 0  # (a full warm-up reproduces the state on this sequence: nothing to walk again ...)
+    B.close()

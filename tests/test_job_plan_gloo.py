@@ -97,3 +97,48 @@ def test_single_process_passthrough():
     x = torch.arange(12, dtype=torch.int64).reshape(1, 6, 2)
     assert shard.reduce_scatter_map(None, x) is x
     assert shard.aggregate(None, torch.device("cpu"), 1.5, 3, 7) == (1.5, 3.0, 7.0)
+
+
+def test_split_plans_cover_every_scan_once_and_balance():
+    """plan_split / plan_job_split: sequences may be cut (the tracking chain's state crosses the cut, scvod_batch_track_resume).
+    Own scans: every scan of the job exactly once, contiguous per sequence; halo = the warm x skip scans of the SAME sequence in
+    front of a cut, never in front of a sequence's start; one successor per interleaved sub-sequence behind a block that ends
+    inside a sequence.  SemanticKITTI seq 00-10 at their real lengths on 8 ranks: the fullest rank owns < 1.001 x the mean
+    (whole sequences reach 62 %), and even counted with its halo it stays above 97 %."""
+    import shard
+    import synth
+    for world in (1, 2, 3, 8):
+        for skip, warm in ((1, 12), (5, 12), (5, 3)):
+            p = shard.plan_split(world, 2761, skip=skip, warm=warm)
+            own = []
+            for r, q in enumerate(p):
+                assert q["own_first"] == (0 if r == 0 else min(warm * skip, q["lo"] + q["own_first"]))
+                own += list(range(q["lo"] + q["own_first"], q["lo"] + q["own_first"] + q["own_count"]))
+                assert q["hi"] == (2761 if r == world - 1 else q["lo"] + q["own_first"] + q["own_count"] + skip)
+                m = q["hi"] - q["lo"]
+                assert list(q["next_scan"]) == [i + skip if i + skip < m else -1 for i in range(m)]
+            assert own == list(range(2761))
+    job = shard.kitti_sequences(synth.SEQ_LEN)
+    total = sum(c for _, _, c in job)
+    for world in (2, 8):
+        plan = shard.plan_job_split(world, job, skip=5, warm=12)
+        seen = []
+        for q in plan:
+            k = 0
+            for (sid, lo, oa, ob, hi) in q["pieces"]:
+                length = dict((s, c) for s, _, c in job)[sid]
+                assert 0 <= lo <= oa < ob <= hi <= length
+                assert lo == (max(0, oa - 60) if oa > 0 else 0) and hi == (min(length, ob + 5) if ob < length else length)
+                for i in range(lo, hi):
+                    assert q["scans"][k] == (sid, i) and q["is_halo"][k] == (1 if i < oa else 0)
+                    assert q["next_scan"][k] == (k + 5 if i + 5 < hi else -1)
+                    if oa <= i < ob:
+                        seen.append((sid, i))
+                    k += 1
+            assert k == len(q["scans"]) and q["own"] == sum(ob - oa for (_, _, oa, ob, _) in q["pieces"])
+        assert sorted(seen) == sorted((s, f + j) for s, f, c in job for j in range(c)) and len(seen) == total
+        mean = total / world
+        assert max(q["own"] for q in plan) <= 1.001 * mean
+        assert mean / max(len(q["scans"]) for q in plan) >= 0.97
+    whole = shard.plan_job(8, job, skip=5)
+    assert (total / 8) / max(len(q["scans"]) for q in whole) < 0.65  # (what cutting sequences buys)
