@@ -69,7 +69,15 @@ struct scvod_ctx {
     bool track_valid = false;
     // sequential tracking chain (scvod_chain.hip)
     int track_mode = SCVOD_TRACK_CHAIN;
-    int chain_seg = 0, chain_warm = 12;      // steps per segment (0: from the job, ~250 segments), warm-up steps in front of it
+    int chain_seg = 0, chain_warm = -1;      // steps per segment (0: from the job, ~250 segments), warm-up steps in front of it (-1: chosen per stream, below)
+    // warm-up chosen per job: 10 steps to begin with; when a batch walked more than a few segments again (its warm-up did not
+    // reproduce their start states) the next batch of the stream warms up 2 steps longer, up to 16.  The counters come back through
+    // a pinned word and an event: never a stream drain.
+    int chain_warm_auto = 10, chain_warm_used = 10;
+    int32_t* h_chain_fb = nullptr;           // pinned [8]
+    hipEvent_t chain_fb_ev = nullptr;
+    bool chain_fb_pending = false;
+    int chain_fb_segments = 0;
     int chain_seg_used = 0;
     bool chain_generic = false;              // testing: every step through the generic (HBM-resident) step function
     bool max_name_literal = true;            // ssc.cpp:354: a frame's first new cluster re-uses the last running number (scvod_lastname.hip)
@@ -743,7 +751,13 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
         }
     }
     c->chain_seg_used = seg;
-    const int warm = c->chain_warm > 0 ? c->chain_warm : 0;
+    if (c->chain_fb_pending && hipEventQuery(c->chain_fb_ev) == hipSuccess) {  // how the last batch of this stream fared
+        c->chain_fb_pending = false;
+        const int rewalked = c->h_chain_fb[1], limit = c->chain_fb_segments / 64 > 2 ? c->chain_fb_segments / 64 : 2;
+        if (rewalked > limit && c->chain_warm_auto < 16) c->chain_warm_auto += 2;
+    }
+    const int warm = c->chain_warm >= 0 ? c->chain_warm : c->chain_warm_auto;
+    c->chain_warm_used = warm;
     int n_chains = 0;
     for (size_t ci = 0; ci < chain_len.size(); ++ci) {
         const int first = chain_first[ci], n = chain_len[ci];
@@ -917,6 +931,8 @@ void scvod_destroy(scvod_ctx* c) {
     }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->ln_stream) hipStreamDestroy(c->ln_stream);
+    if (c->h_chain_fb) hipHostFree(c->h_chain_fb);
+    if (c->chain_fb_ev) hipEventDestroy(c->chain_fb_ev);
     if (c->ln_stream2) hipStreamDestroy(c->ln_stream2);
     if (c->ln_fork2) hipEventDestroy(c->ln_fork2);
     if (c->ln_join2) hipEventDestroy(c->ln_join2);
@@ -1277,6 +1293,18 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     launch_track_batch(c->dev, c->A, J, c->batch_mode == 2 ? 1 : 0, c->tables_valid ? 2 : 3, st, timer_hook, c, c->chain_ran ? &CJ : nullptr,
                        c->ln_pending ? c->ln_done : nullptr);
     if (c->chain_ran) c->ln_pending = false;  // (the chain waited for it)
+    if (c->chain_ran) {  // the counters of this chain, for the warm-up of the stream's next batch
+        if (!c->h_chain_fb) {
+            HIPCHK(c, hipHostMalloc((void**)&c->h_chain_fb, 8 * sizeof(int32_t)));
+            HIPCHK(c, hipEventCreateWithFlags(&c->chain_fb_ev, hipEventDisableTiming));
+        }
+        if (!c->chain_fb_pending) {
+            HIPCHK(c, hipMemcpyAsync(c->h_chain_fb, c->d_chain_stats, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(c->chain_fb_ev, st));
+            c->chain_fb_pending = true;
+            c->chain_fb_segments = CJ.n_walkers;
+        }
+    }
     HIPCHK(c, hipGetLastError());
     c->tables_valid = true;
     c->track_valid = true;
@@ -1434,7 +1462,7 @@ int scvod_batch_track_stats(scvod_ctx* c, int32_t* h_out8) {
     h_out8[3] = st[1];
     h_out8[4] = st[0];
     h_out8[5] = c->chain_seg_used;
-    h_out8[6] = c->chain_warm;
+    h_out8[6] = c->chain_warm_used;
     h_out8[7] = 0;
 #ifdef SCVOD_PROFILE
     fprintf(stderr, "[chain phases, 10 ns ticks summed over walkers x steps] fetch %d  carried %d  eval %d  walk+state %d  copy %d\n", st[3], st[4], st[5], st[6], st[7]);

@@ -283,7 +283,7 @@ int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_sc
  *                            earlier; a segment whose warm-up did not reproduce the state its predecessor really ended
  *                            in is walked again from that state, so the result never depends on the two lengths
  *                            (segment_steps 0 = the shortest segment whose walkers still fit the device one per CU (<= 256), the default;
- *                            warmup_steps -1 = keep, default 12).  A scan tracked against an EXTERNAL table ends its
+ *                            warmup_steps -1 = keep; by default the warm-up is chosen per stream: 10 steps, two more for the next batch whenever more than a few segments had to be walked again, up to 16).  A scan tracked against an EXTERNAL table ends its
  *                            chain: across shard boundaries the decision is first-order -- keep a sequence on one shard.
  *   SCVOD_TRACK_FIRST_ORDER  every cluster against its successor's fresh segmentation (all pairs independent).
  * n_unique / pair_* of scvod_track_result always describe a cluster's OWN points against the fresh successor. */
