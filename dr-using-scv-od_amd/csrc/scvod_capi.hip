@@ -64,7 +64,8 @@ struct scvod_ctx {
     std::vector<float> up_T;          // what the device copies of T / next_scan / ext currently hold (re-uploaded on change only)
     std::vector<int32_t> up_next;
     std::vector<const void*> up_ext;
-    UploadSlot up_ring[4];
+    UploadSlot up_ring[8];                   // (a chain-mode scvod_batch_track can upload six changed tables in one call: ADVICE r3)
+    int n_cu = 256;                          // compute units of the device (hipDeviceProp: the chain plans one segment per CU)
     int up_next_slot = 0;
     bool track_valid = false;
     // sequential tracking chain (scvod_chain.hip)
@@ -125,6 +126,7 @@ struct scvod_ctx {
     bool apri_compact = false;   // PointAPRI records not materialised yet (k_apri_expand on request)
     bool voxels_valid = false;   // the last batch ran the voxel stage in descriptor mode (not VoxelGrid)
     bool clusters_valid = false;
+    bool clustered_this_batch = false;       // the batch's pt_mapcls bytes carry car / dynamic marks of an earlier clustering (cleared before the next one)
     bool types_valid = false;
     hipStream_t last_stream = nullptr;
     // host staging for scvod_scan_result
@@ -437,6 +439,7 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->tables_valid = false;
     // marks per input point for the static map (car-cluster member / dynamic / list marks): clean for every new batch
     if (mx > 0 && do_patchwork != 2 && do_patchwork != 3) HIPCHK(c, hipMemsetAsync(c->A.pt_mapcls, 0, (size_t)total, st));
+    c->clustered_this_batch = false;
     if (mx > 0) launch_process(c->dev, c->A, st, do_patchwork, apply_filter, do_voxels, timer_hook, c);
     HIPCHK(c, hipGetLastError());
     if (mx == 0) {  // every scan empty: no kernel runs (neither here nor in the clustering / tracking launches): clean per-scan words
@@ -638,11 +641,11 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
 
 // Re-upload a small host table only when its contents changed since the last call (steady-state sequence loops pass the
 // same tables every step and upload nothing).
-// A changed table travels through one of four pinned staging slots; a slot is reused only after the copy that read it
+// A changed table travels through one of eight pinned staging slots; a slot is reused only after the copy that read it
 // has completed (its event), so a chunked sequence (scvod_sequence_ingest: new transforms every chunk) never drains the stream.
 int staged_upload(scvod_ctx* c, const void* src, size_t bytes, void* dst, hipStream_t st) {
     UploadSlot& u = c->up_ring[c->up_next_slot];
-    c->up_next_slot = (c->up_next_slot + 1) % 4;
+    c->up_next_slot = (c->up_next_slot + 1) % 8;
     if (!u.ev) HIPCHK(c, hipEventCreateWithFlags(&u.ev, hipEventDisableTiming));
     if (u.used) HIPCHK(c, hipEventSynchronize(u.ev));
     if (bytes > u.cap) {
@@ -741,7 +744,7 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
     // pays the warm-up, so more segments than CUs would run in two rounds) -- 11 steps = 255 walkers for seq 05 with skip_ 5
     int seg = c->chain_seg;
     if (seg <= 0) {
-        const int n_cu = 256;  // MI355X
+        const int n_cu = c->n_cu;
         int longest = 0;
         for (int n : chain_len) longest = n - 1 > longest ? n - 1 : longest;
         for (seg = 4; seg < longest; ++seg) {  // (more chains than CUs: one segment per chain)
@@ -912,6 +915,10 @@ int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int devi
     }
     c->arena_bytes = total;
     carve(c, (unsigned char*)c->arena_base, &total);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     if (hipStreamCreate(&c->stream) != hipSuccess) {
         hipFree(c->arena_base);
         delete c;
@@ -1119,6 +1126,10 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
         return fail(c, SCVOD_ERR_INVALID, "grid of %d x %d x %d bins is finer than the clustering's packed index triples hold (2040 x 2040 x 1016)",
                     c->dev.bin.range_num, c->dev.bin.sector_num, c->dev.bin.azimuth_num);
     join_lastname(c, st);
+    // a second clustering of the same batch (other mode, scvod_set_cluster_exact, cluster - track - cluster): the marks the first one
+    // and its tracking left per input point would otherwise survive on points that are no car members any more
+    if (c->clustered_this_batch && c->A.total_pts > 0) HIPCHK(c, hipMemsetAsync(c->A.pt_mapcls, 0, (size_t)c->A.total_pts, st));
+    c->clustered_this_batch = true;
     launch_cluster(c->dev, c->A, c->batch_mode == 2 ? 1 : 0, st, timer_hook, c);
     c->last_name_valid = false;
     if (c->max_name_literal) {
@@ -1242,9 +1253,13 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
         const int nw = plan_chains(c, next, scans, fw, walkers);
         if (nw < 0) return nw;
         if (nw > 0) {
-            if (c->chain_geom_pts != c->A.max_scan_pts || c->chain_geom_pool != c->chain_pool_points) {
-                chain_layout(c->chain_geom, c->A.max_scan_pts, c->chain_pool_points);
-                c->chain_geom_pts = c->A.max_scan_pts;
+            // The layout follows the LARGEST scan this ctx has tracked so far (rounded up to 4096 points), not the current batch's:
+            // a stream of batches whose largest scan wobbles keeps one layout, one workspace, and is not cleared again
+            const int lay_pts = ((c->A.max_scan_pts + 4095) / 4096) * 4096;
+            if (lay_pts > c->chain_geom_pts || c->chain_geom_pool != c->chain_pool_points) {
+                const int pts = lay_pts > c->chain_geom_pts ? lay_pts : c->chain_geom_pts;
+                chain_layout(c->chain_geom, pts, c->chain_pool_points);
+                c->chain_geom_pts = pts;
                 c->chain_geom_pool = c->chain_pool_points;
                 c->chain_ws_clean = false;
             }
@@ -1259,10 +1274,10 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
                 c->chain_ws_clean = false;
             }
             // the stamped override words compare against a per-walker epoch that only grows: a zeroed workspace is a valid one
-            if (!c->chain_ws_clean || c->chain_ws_layout_pts != c->A.max_scan_pts) {
+            if (!c->chain_ws_clean || c->chain_ws_layout_pts != c->chain_geom_pts) {
                 HIPCHK(c, hipMemsetAsync(c->chain_ws, 0, c->chain_ws_bytes, st));
                 c->chain_ws_clean = true;
-                c->chain_ws_layout_pts = c->A.max_scan_pts;
+                c->chain_ws_layout_pts = c->chain_geom_pts;
             }
             if ((rc = upload_if_changed(c, c->up_chain_scans, scans.data(), scans.size(), c->d_chain_scans, st))) return rc;
             if ((rc = upload_if_changed(c, c->up_chain_fw, fw.data(), fw.size(), c->d_chain_fw, st))) return rc;
@@ -1276,7 +1291,7 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             CJ.ws = c->chain_geom;
             CJ.ws.base = (unsigned char*)c->chain_ws;
             CJ.stats = c->d_chain_stats;
-            CJ.words = (c->A.max_scan_pts + 31) / 32 + 1;
+            CJ.words = (c->chain_geom_pts + 31) / 32 + 1;  // (sized like the layout: one value for the workspace and the bitsets)
             const size_t lds_bits = 72 * 1024;  // next to the 80 KB of per-step tables
             int ev = (int)(lds_bits / ((size_t)CJ.words * 4));
             CJ.n_eval_waves = ev < 1 ? 1 : (ev > 16 ? 16 : ev);
@@ -1311,6 +1326,8 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     if (sync) HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
+
+int64_t scvod_chain_workspace_bytes(scvod_ctx* c) { return c ? (int64_t)c->chain_ws_bytes : 0; }
 
 int scvod_set_track_owned(scvod_ctx* c, int32_t first_owned_scan) {
     if (!c || first_owned_scan < 0) return fail(c, SCVOD_ERR_INVALID, "bad first owned scan");

@@ -130,6 +130,7 @@ def load_lib():
         "scvod_set_max_name_literal": (C.c_int, [vp, i32]),
         "scvod_batch_cluster_last_name": (C.c_int, [vp, vp, i32, vp]),
         "scvod_set_chain_capacity": (C.c_int, [vp, i64]),
+        "scvod_chain_workspace_bytes": (i64, [vp]),
         "scvod_set_track_owned": (C.c_int, [vp, i32]),
         "scvod_set_track_halo": (C.c_int, [vp, vp, i32]),
         "scvod_batch_track_chains": (C.c_int, [vp, vp, i32]),
@@ -172,7 +173,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]

@@ -291,6 +291,11 @@ int scvod_batch_track(scvod_ctx* ctx, const float* h_T, const int32_t* h_next_sc
 #define SCVOD_TRACK_FIRST_ORDER 0
 #define SCVOD_TRACK_CHAIN_GENERIC 3 /* testing: the chain with every step through the kernel's generic (HBM-resident) step */
 int scvod_set_track_mode(scvod_ctx* ctx, int32_t mode, int32_t segment_steps, int32_t warmup_steps);
+/* Chain mode needs CHAINS: every scan is the successor of at most one scan of the batch and the table holds no cycle
+ * (SCVOD_ERR_INVALID otherwise).  Many scans against one reference scan is a first-order question: SCVOD_TRACK_FIRST_ORDER.
+ * The chain's workspace is a separate allocation made by the first scvod_batch_track that needs it (walkers x ~70 bytes x the pool
+ * capacity: 16 GB for a seq-05 job, NOT part of scvod_arena_bytes); scvod_chain_workspace_bytes reports it. */
+int64_t scvod_chain_workspace_bytes(scvod_ctx* ctx);
 /* Points of appended clouds one segment's state can hold (0 = default: 8 x the largest scan of the batch).  The reference
  * appends a static car cluster's whole cloud to its successor at every step (ssc.cpp:1381), so a cloud grows for as long
  * as the object is tracked; a state that outgrows the capacity is reported (SCVOD_ERR_CAPACITY) by scvod_batch_fetch_track /
