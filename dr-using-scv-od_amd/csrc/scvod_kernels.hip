@@ -3419,6 +3419,10 @@ __device__ __forceinline__ bool cc_scan_impl(const DevParams& P, const Arena& A,
         }
         A.vox_track[(size_t)base + v] = rec;
         A.vox_rep[(size_t)base + v] = rep;
+        // for the max_name pass that follows (scvod_lastname.hip): the cluster of the voxel's first point whether the refine erased
+        // it or not (-1: not decided here), and that point -- two arrays the voxel stage no longer needs
+        A.tmp_vox_key[(size_t)base + v] = cid >= 0 ? names[cid] : -1;
+        ((int32_t*)A.sorted_idx)[(size_t)base + v] = vpts[vbeg[v]];
     }
     // ---- member lists of the car clusters (what SSC::tracking walks, ssc.cpp:1274-1321): the car roots in ascending order
     // (tk_clusters), exclusive offsets of their sizes (tk_mbegin at the root), and -- in the per-point pass below -- every
@@ -3545,11 +3549,12 @@ __global__ __launch_bounds__(kCcThreads) void k_cc_scan(DevParams P, Arena A, in
         if (threadIdx.x < 2) A.tk_scan[s * 4 + threadIdx.x] = 0;  // no car clusters, no car points
         return;
     }
+    bool done = false;
     if (n <= kCcSlots && nv <= kCcNodes && (long long)P.bin.range_num * P.bin.sector_num * P.bin.azimuth_num < 0x7fffffffLL) {
-        if (cc_scan_impl<true>(P, A, from_apri, wsum, wlast, n_extra_s, bad_s, s, base, n, nv)) return;
+        done = cc_scan_impl<true>(P, A, from_apri, wsum, wlast, n_extra_s, bad_s, s, base, n, nv);
         __syncthreads();
     }
-    cc_scan_impl<false>(P, A, from_apri, wsum, wlast, n_extra_s, bad_s, s, base, n, nv);
+    if (!done) cc_scan_impl<false>(P, A, from_apri, wsum, wlast, n_extra_s, bad_s, s, base, n, nv);
 }
 
 // ------------------------------------------------------------------------------------------

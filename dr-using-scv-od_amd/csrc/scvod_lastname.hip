@@ -791,20 +791,15 @@ struct Blk {
     int32_t reg[125][3];  // its first three regular points
 };
 
+// One scan: everything above, by the TH threads of one workgroup on `ln_smem` (ln_lds_bytes<CAP>() bytes of LDS).  A scan whose
+// classes do not fit CAP nodes goes to `redo` / `redo_big` (lists on the device, [n_scans] = how many) or is reported unknown.
 template <int CAP, int TH>
-__global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo, int32_t* redo_big, int big_from,
-                                                             int32_t* n_redo) {
-    extern __shared__ __align__(16) unsigned char ln_smem[];
+__device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char* ln_smem, int32_t* redo, int32_t* redo_big, int big_from) {
     __shared__ int wsum[2 * kLnMaxWaves + 2];
     __shared__ int bc[8];
     __shared__ int mk_cls[kLnMarked + 1], mk_t[kLnMarked + 1], n_mk, n_pairs_s, n_irr_s, fail_s;
     __shared__ int red[kLnMaxWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int s = blockIdx.x;
-    if (todo) {
-        if (s >= *n_todo) return;
-        s = todo[s];
-    }
     const long long pt0 = wall_clock64();
     Ln L;
     const int base = A.scan_off[s];
@@ -1036,30 +1031,16 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
         __syncthreads();
     }
 
-    // ---- A: closure class of every voxel (through its first point), the latest-born class ----
+    // ---- A: closure class of every voxel (through its first point), the latest-born class.  k_cc_scan left the cluster of every
+    // voxel's first point in vcl and the point in fp (-1: not settled there, looked up here) ----
     int lmax = -1;
-    for (int v0 = 0; v0 < L.nv; v0 += TH * 4) {
-        int f[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = L.vbeg[min(v0 + u * TH + tid, L.nv - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = L.vpts[f[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int v = v0 + u * TH + tid;
-            if (v < L.nv) L.fp[v] = f[u];
-            f[u] = L.ptc[f[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int v = v0 + u * TH + tid;
-            if (v < L.nv) {
-                const int c = L.n_names ? cls_of(L, f[u]) : f[u];
-                L.vcl[v] = c;
-                L.loc[v] = -1;
-                lmax = max(lmax, c);
-            }
-        }
+    for (int v = tid; v < L.nv; v += TH) {
+        int c = L.vcl[v];
+        if (c < 0) c = L.ptc[L.fp[v]];
+        if (L.n_names) c = cls_of(L, c);
+        L.vcl[v] = c;
+        L.loc[v] = -1;
+        lmax = max(lmax, c);
     }
     for (int j = tid; j < L.n_irr; j += TH) lmax = max(lmax, L.irr_cls[j]);
     for (int d = 32; d > 0; d >>= 1) lmax = max(lmax, __shfl_xor(lmax, d));
@@ -1213,8 +1194,26 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
             const int k = min(n_mk, kLnMarked);
             mk_cls[k] = CL;
             n_mk = k + 1;
+            // Whatever cluster carries the number: if refineClusterByBoundingBox erased every cluster that could (ssc.cpp:437-467: a
+            // class of a regular scan IS a cluster, called after its smallest point, whose type byte says so), no live cluster
+            // carries it and there is nothing to walk.  (Classes tied together by irregular points are walked.)
+            int all_erased = 1;
+            for (int t = 0; t < n_mk; ++t) {
+                const int c = mk_cls[t];
+                bool tied = false;
+                for (int q = 0; q < L.n_names; ++q) tied |= L.crep[q] == c;
+                if (tied || A.pt_type[(size_t)base + c] != 0) all_erased = 0;
+            }
+            bc[6] = all_erased;
         }
         __syncthreads();
+        if (bc[6]) {
+            if (tid == 0) {
+                outp[0] = outp[1] = -1, outp[2] = 0, outp[3] = 0;
+                if (A.ln_prof) A.ln_prof[(size_t)s * 8 + 7] = -CAP;
+            }
+            return;
+        }
         best = replay_class<CAP, TH>(L, T, mk_cls, n_mk, -1, wsum, bc);
         unknown = best.too_big != 0;
     }
@@ -1247,6 +1246,19 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
             outp[3] = events;
         }
     }
+}
+
+
+template <int CAP, int TH>
+__global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo, int32_t* redo_big, int big_from,
+                                                    int32_t* n_redo) {
+    extern __shared__ __align__(16) unsigned char ln_kernel_smem[];
+    int s = blockIdx.x;
+    if (todo) {
+        if (s >= *n_todo) return;
+        s = todo[s];
+    }
+    ln_scan<CAP, TH>(P, A, s, ln_kernel_smem, redo, redo_big, big_from);
 }
 
 }  // namespace

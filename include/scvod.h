@@ -382,7 +382,8 @@ int scvod_batch_cluster_stats(scvod_ctx* ctx, int32_t* h_out4);
  * scvod_batch_cluster therefore also determines, per scan, which cluster (canonical name) still carries K when the visiting
  * loop ends (csrc/scvod_lastname.hip), and the tracking chain hands that name out first.  literal = 0 switches both off:
  * every new cluster gets a fresh number (rounds 1-3 of this library).  Default 1.
- * scvod_batch_cluster_last_name: h_out4[s] = {canonical name of the cluster carrying K or -1 (K was merged away),
+ * scvod_batch_cluster_last_name: h_out4[s] = {canonical name of the cluster carrying K or -1 (K was merged away, or every cluster
+ * that could carry it was erased by the bounding-box refine: such a cluster is no cluster any more and the pass does not walk it),
  * lowest voxel slot whose first point belongs to it or -1, status, events replayed}; status 0 = exact; 1 = a component
  * that had to be replayed holds more voxels than a CU's LDS (about 2200): reported as "none"; 2 = more than 256 points with
  * an index triple outside the grid: reported as "none".  h_stats4 (optional) = {scans with status 1, with status 2, 0, 0}. */

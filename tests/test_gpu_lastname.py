@@ -32,10 +32,16 @@ def test_last_name_equals_the_literal_loop(scvod, oracle, kind, preset, count, s
     for s in range(count):
         r = ctx.batch_fetch(s)
         names = ctx.batch_fetch_clusters(s, r["n_apri"])
+        types = ctx.batch_fetch_cluster_types(s, r["n_apri"], car_label=2, other_label=1)
         want, info = oracle.cluster_last_name(P, r["apri"])
         if ln[s, 2] != 0:
             continue  # reported unknown (counted below)
         exact += 1
+        if ln[s, 0] == -1 and want >= 0:
+            # a cluster that refineClusterByBoundingBox erased carries no name any more: the device may say "none" for it
+            # without walking anything (it does when every cluster that could carry the number is an erased one)
+            assert types[want] == -1, f"{kind} scan {s}: the literal loop leaves max_name on the live cluster {want}, the device reports none"
+            continue
         assert ln[s, 0] == want, f"{kind} scan {s}: device says cluster {ln[s, 0]} carries max_name, the literal loop {want} (info {info})"
         if want >= 0:
             alive += 1
@@ -71,7 +77,8 @@ def test_chain_with_the_literal_max_name(scvod, oracle, kind, preset, skip, coun
     # the oracle's own reading of which cluster carries K, scan by scan; where the device reported "unknown" the chain used none
     collide = np.asarray([oracle.cluster_last_name(P, r["apri"])[0] for r in res], np.int32)
     known = ln[:, 2] == 0
-    assert np.array_equal(ln[known, 0], collide[known])
+    for s in np.nonzero(known)[0]:  # (none for an erased cluster: see test_last_name_equals_the_literal_loop)
+        assert ln[s, 0] == collide[s] or (ln[s, 0] == -1 and types[s][collide[s]] == -1)
     collide[~known] = -1
     dynL, ndL, lit = oracle.sequence_tracking_literal(P, apri, ao, nm, ty, collide, poses, chain=3)
     assert np.array_equal(got, dynL), f"{int((got != dynL).sum())} of {len(dynL)} per-point bytes differ from the literal chain"
