@@ -68,6 +68,29 @@ def _free_port():
     return p
 
 
+def seq05_quality(scvod_py, qmod, orc, x, offs, poses, gt, device):
+    """PR / RR of the device path and of the oracle chain on the labelled sample with preset semantickitti_seq05 (max_z 4.0,
+    min_z 1.0, car_square 50: doc/note.txt:36, the row the reference publishes 98.97 / 96.67 for on the real seq 05)"""
+    import numpy as np
+    import torch
+    P5 = scvod_py.make_params("semantickitti_seq05")
+    ns = len(offs) - 1
+    ctx = scvod_py.Ctx(P5, max_points_total=int(offs[-1]) + 1024, max_scans=ns, device=device)
+    d = torch.from_numpy(x).to(f"cuda:{device}")
+    ctx.batch_process(d, offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    T = np.zeros((ns, 12), np.float32)
+    for s in range(ns - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    dev = [qmod.device_point_labels(ctx, s, int(offs[s + 1] - offs[s])) for s in range(ns - 1)]
+    _, ref_lab, _ = orc.time_sequence(P5, x, offs, poses)
+    q = qmod.compare(scvod_py, ctx, x, offs, poses, gt, ref_lab, np.concatenate(dev), voxelsize=0.2)
+    ctx.close()
+    return {k: q[k] for k in ("device", "reference_chain", "delta_PR", "delta_RR", "labels_equal_fraction")} | {"preset": "semantickitti_seq05 (doc/note.txt:36)"}
+
+
 def other_configs():
     """configs[2] (parking lot, one chain of 1999 steps) and configs[4] (128 beams, 2x finer grid) as sub-runs of this script"""
     res = {}
@@ -453,6 +476,11 @@ def main():
                     quality = qmod.compare(scvod_py, ctx, x, o2, sp, gt, ref_lab, np.concatenate(dev_labels), voxelsize=0.2)
                 except Exception as e:
                     quality = {"error": str(e)[:300]}
+                if quality and "error" not in quality and args.preset == "semantickitti":
+                    try:  # the same sample with the parameters of the reference's published seq-05 row (doc/note.txt:36)
+                        quality["seq05_parameters"] = seq05_quality(scvod_py, qmod, orc, x, o2, sp, gt, local)
+                    except Exception as e:
+                        quality["seq05_parameters"] = {"error": str(e)[:300]}
             if not args.no_cpu_all:
                 try:  # context only: the same oracle with one chunk of scans per host thread (ctypes releases the GIL)
                     from concurrent.futures import ThreadPoolExecutor

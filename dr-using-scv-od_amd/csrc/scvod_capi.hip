@@ -1330,6 +1330,12 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     return SCVOD_OK;
 }
 
+int scvod_get_params(const scvod_ctx* c, scvod_params* out) {
+    if (!c || !out) return SCVOD_ERR_INVALID;
+    *out = c->params;
+    return SCVOD_OK;
+}
+
 int64_t scvod_chain_workspace_bytes(scvod_ctx* c) { return c ? (int64_t)c->chain_ws_bytes : 0; }
 
 int scvod_set_track_owned(scvod_ctx* c, int32_t first_owned_scan) {

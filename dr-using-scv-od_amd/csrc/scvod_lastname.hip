@@ -10,20 +10,28 @@
 // K is the number the last "opener" of the visiting loop created (ssc.cpp:303-350: a point that carries no label after it
 // looked at its neighbours opens a new cluster), and it survives only if no later mergeClusters(oc, nc) call (ssc.cpp:329,
 // :413-419: the VISITING point's cluster takes the NEIGHBOUR's name) renamed it.  Both depend on the visiting order, so the
-// loop has to be replayed -- but only where it matters:
-//   * the loop never looks across a connected component of "lists" (every listed voxel ends up in the lister's component), so
-//     each component can be replayed on its own, at voxel level: a voxel is unlabelled, labelled through its visited points,
-//     or FULLY labelled; only the first three visits from a voxel change anything (the state machine of
-//     k_cc_scan's exact path), points whose index triple lies outside the grid visit one by one with their own lists;
-//   * the last opener is at least as late as the birth (smallest point) of the latest-born component, L: that component is
-//     replayed (it is small: all of its points come after L), and of all other components only a voxel whose first point
-//     comes after the best opener found so far can still hold a later one.  Such a voxel is no opener when one of the voxels
-//     it lists holds a visited point, or CERTAINLY carries a label by then (a lister's third visit labels its whole list,
-//     the second everything from its own cell on, any visit everything behind a voxel that holds a visited point); the
-//     few candidates no certificate settles get their component replayed;
-//   * a replay lives in LDS (one thread walks the events in order, all threads build its tables); a component with more
-//     nodes than the LDS holds is not replayed: the scan reports "unknown" (counted, scvod_batch_cluster_stats), the chain
-//     then hands out a fresh number as if K had been merged away.
+// loop has to be followed -- but only where it matters:
+//   * the loop never looks across a connected component of "lists" (every listed voxel ends up in the lister's component; index
+//     triples outside the grid tie the clusters they touch into one such class), so each class can be followed on its own, at
+//     voxel level: a voxel is unlabelled, labelled through its visited points, or FULLY labelled; only the first three visits
+//     from a voxel change anything (the state machine of k_cc_scan's exact path), irregular points visit
+//     one by one with their own lists;
+//   * the last opener is at least as late as the birth (smallest point) L of the latest-born class.  Of all other classes only a
+//     voxel whose first point comes after L can still hold a later opener, and such a voxel is none when a voxel it lists holds a
+//     visited point, or CERTAINLY carries a label by then (a lister's third visit labels its whole list, the second everything
+//     from its own cell on, any visit everything behind a voxel that holds a visited point): a thread-parallel pass over the
+//     voxels and a wave-wide certificate over the 5 x 5 x 5 cells around the few candidates that are left.  The latest-born class
+//     and the classes of the candidates no certificate settles are followed -- together, they never list each other.  When
+//     refineClusterByBoundingBox erased every cluster among them, no live cluster carries K and nothing is followed;
+//   * following a set of classes: (1) the times at which voxels become fully labelled, by Jacobi rounds over the visits (a
+//     time depends on earlier times only: the fixed point is the sequential loop's, reached in 2-10 rounds); (2) the openers =
+//     visits that start without a label and find none, the last one by a max; (3) the partition right after it = unions of
+//     what the last visit of every voxel up to then joined; (4) the few visits after it walked in order by one wave (lane p
+//     looks at the p-th listed voxel; the walk only steps through the DISTINCT classes a visit meets, the neighbour's name
+//     winning each time) -- K's class either keeps the name or is renamed away;
+//   * the tables of a set live in LDS: 320 nodes for nearly every scan (eight workgroups per CU), 1792 or 8192 for the scans
+//     listed on the device for the larger passes; a set beyond 8192 nodes is not followed: the scan reports "unknown" (counted,
+//     scvod_batch_cluster_last_name) and the chain hands out a fresh number as if K had been merged away.
 // Checked against a literal restatement of the loop in tests/test_gpu_lastname.py.
 #include "scvod_dev.h"
 

@@ -40,8 +40,16 @@ class PatchWork {
         for (int k = 0; k < r.n_nonground; ++k) cloudNonground.points.push_back(cloudIn.points[r.nonground_idx[k]]);
         time_taken = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
-    // the value reaches the GPU through scvod_params.sensor_height at ctx creation (ssc.cpp:93)
-    void set_sensor(const double& height) { sensor_height_ = height; }
+    // patchwork.h:111.  The height reaches the GPU through scvod_params.sensor_height when the ctx is created (SSC's constructor,
+    // ssc.cpp:93 calls set_sensor once with that same value): a DIFFERENT height afterwards cannot be honoured by this ctx and is
+    // refused instead of being ignored silently.
+    void set_sensor(const double& height) {
+        scvod_params p;
+        if (scvod_get_params(ctx_, &p) == SCVOD_OK && (float)height != p.sensor_height)
+            throw std::invalid_argument("PatchWork::set_sensor: the ctx was created for sensor_height " + std::to_string(p.sensor_height) +
+                                        ", not " + std::to_string(height) + " (create the SSC / scvod ctx with the new height)");
+        sensor_height_ = height;
+    }
 
   private:
     scvod_ctx* ctx_;

@@ -69,6 +69,11 @@ PRESETS = {
     "parkinglot": dict(sensor_height=1.83, min_dis=0.8, max_dis=40.0, min_angle=0.0, max_angle=360.0,
                        min_azimuth=-30.0, max_azimuth=60.0, range_res=0.4, sector_res=1.2, azimuth_res=2.0,
                        occupancy=0.8, max_z=1.0, min_z=-1.0, car_square=2.0, toBeClass=6),
+    # the parameters behind the reference's published seq-05 row (doc/note.txt:36: skip 5, max_z 4.0, min_z 1.0, car_square 50; its
+    # refine_height / car_height / car_angle feed code that is commented out or out of scope): the committed YAML with those three
+    "semantickitti_seq05": dict(sensor_height=1.73, min_dis=1.5, max_dis=30.0, min_angle=0.0, max_angle=360.0,
+                                min_azimuth=-40.0, max_azimuth=80.0, range_res=0.4, sector_res=1.2, azimuth_res=2.0,
+                                occupancy=0.4, max_z=4.0, min_z=1.0, car_square=50.0, toBeClass=10),
     # BASELINE.json configs[4]: OS1-128 stream with a 2x finer voxel grid
     "os128_fine": dict(sensor_height=1.73, min_dis=1.5, max_dis=30.0, min_angle=0.0, max_angle=360.0,
                        min_azimuth=-40.0, max_azimuth=80.0, range_res=0.2, sector_res=0.6, azimuth_res=1.0,
@@ -131,6 +136,7 @@ def load_lib():
         "scvod_batch_cluster_last_name": (C.c_int, [vp, vp, i32, vp]),
         "scvod_set_chain_capacity": (C.c_int, [vp, i64]),
         "scvod_chain_workspace_bytes": (i64, [vp]),
+        "scvod_get_params": (C.c_int, [vp, vp]),
         "scvod_set_track_owned": (C.c_int, [vp, i32]),
         "scvod_set_track_halo": (C.c_int, [vp, vp, i32]),
         "scvod_batch_track_chains": (C.c_int, [vp, vp, i32]),
@@ -173,7 +179,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_get_params", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]

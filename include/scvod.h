@@ -166,6 +166,8 @@ typedef struct scvod_ctx scvod_ctx;
 int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int device,
                  int64_t max_points_total, int32_t max_scans, scvod_ctx** out);
 void scvod_destroy(scvod_ctx* ctx);
+/* the parameters the ctx was created with */
+int scvod_get_params(const scvod_ctx* ctx, scvod_params* out);
 const char* scvod_last_error(const scvod_ctx* ctx);
 /* bytes of HBM held by the ctx arena */
 int64_t scvod_arena_bytes(const scvod_ctx* ctx);

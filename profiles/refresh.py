@@ -59,13 +59,17 @@ def label(k):
     for pre, l in (("k_pw_fit_coop", "pw_fit_large"), ("k_pw_arrange", "pw_arrange"), ("k_pw_order", "pw_order"), ("k_vx_order", "vx_order"), ("k_tk_decide", "tk_decide")):
         if k.startswith(pre):
             return l
+    if k.startswith("k_cc_lastname"):  # the three passes of scvod_lastname.hip by table size (<1792, 1024>: the first pass of 128-beam batches)
+        m = re.search(r"<(\d+), *(\d+)", k)
+        cap, th = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        return "cc_lastname_big" if cap > 4096 else ("cc_lastname_mid" if cap > 1024 and th == 256 else "cc_lastname")
     for pre, l in (("k_pw_sort", "pw_sort"), ("k_vx_bucket", "vx_bucket")):
         if k.startswith(pre):
             return l + "_" + str(int(re.search(r"<(\d+)", k).group(1)))
     return k
 
 
-LABELS.update({"k_tk_chain": "tk_chain", "k_tk_chain_cmp": "tk_chain_fix", "k_tk_chain_fix": "tk_chain_fix"})
+LABELS.update({"k_tk_chain": "tk_chain", "k_tk_chain_cmp": "tk_chain_fix", "k_tk_chain_fix": "tk_chain_fix", "k_tk_chain_spec": "tk_chain_fix"})
 total_by = {}
 for name in ("k64", "park", "os128"):
     fp, wp = os.path.join(src, f"FETCH_SIZE_counter_collection_{name}.csv"), os.path.join(src, f"WRITE_SIZE_counter_collection_{name}.csv")
