@@ -107,8 +107,8 @@ struct scvod_ctx {
     // the max_name pass (scvod_lastname.hip) runs beside the kernels that follow the clustering, on a stream of its own; whoever
     // needs its result or its scratch waits for ln_done (join_lastname)
     hipStream_t ln_stream = nullptr;
-    hipStream_t ln_stream2 = nullptr;
-    hipEvent_t ln_fork = nullptr, ln_done = nullptr, ln_fork2 = nullptr, ln_join2 = nullptr;
+    hipStream_t ln_stream2 = nullptr, ln_stream3 = nullptr;
+    hipEvent_t ln_fork = nullptr, ln_done = nullptr, ln_fork2 = nullptr, ln_join2 = nullptr, ln_join3 = nullptr;
     bool ln_pending = false;
     void* ingest_buf[2] = {nullptr, nullptr};
     size_t ingest_cap = 0;  // points per buffer
@@ -240,7 +240,8 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
     A.cc_last = k.take<int32_t>(B * 4);
-    A.cc_redo = k.take<int32_t>(2 * (B + 1));
+    A.cc_redo = k.take<int32_t>(3 * (B + 1));
+    A.ln_state = k.take<int32_t>(B * 2048);
     A.ln_stats = k.take<int32_t>(4);
     A.ln_prof = k.take<int32_t>(B * 8);
     A.ln_prof2 = k.take<int32_t>(B * 8);
@@ -941,6 +942,8 @@ void scvod_destroy(scvod_ctx* c) {
     if (c->h_chain_fb) hipHostFree(c->h_chain_fb);
     if (c->chain_fb_ev) hipEventDestroy(c->chain_fb_ev);
     if (c->ln_stream2) hipStreamDestroy(c->ln_stream2);
+    if (c->ln_stream3) hipStreamDestroy(c->ln_stream3);
+    if (c->ln_join3) hipEventDestroy(c->ln_join3);
     if (c->ln_fork2) hipEventDestroy(c->ln_fork2);
     if (c->ln_join2) hipEventDestroy(c->ln_join2);
     if (c->ln_fork) hipEventDestroy(c->ln_fork);
@@ -1143,14 +1146,18 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
             HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream2, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_fork2, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_join2, hipEventDisableTiming));
+            HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream3, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ln_join3, hipEventDisableTiming));
         }
-        HIPCHK(c, hipEventRecord(c->ln_fork, st));
-        HIPCHK(c, hipStreamWaitEvent(c->ln_stream, c->ln_fork, 0));
-        c->last_stream = c->ln_stream;  // (the timing hook records on last_stream)
-        launch_lastname(c->dev, c->A, c->ln_stream, c->ln_stream2, c->ln_fork2, c->ln_join2, c->timing ? timer_hook : nullptr, c);
-        c->last_stream = st;
-        HIPCHK(c, hipEventRecord(c->ln_done, c->ln_stream));
-        c->ln_pending = true;
+        if (c->timing) {  // attribution runs: one stream, one pair of events per pass
+            launch_lastname(c->dev, c->A, st, nullptr, nullptr, nullptr, nullptr, nullptr, timer_hook, c);
+        } else {
+            HIPCHK(c, hipEventRecord(c->ln_fork, st));
+            HIPCHK(c, hipStreamWaitEvent(c->ln_stream, c->ln_fork, 0));
+            launch_lastname(c->dev, c->A, c->ln_stream, c->ln_stream2, c->ln_stream3, c->ln_fork2, c->ln_join2, c->ln_join3, nullptr, c);
+            HIPCHK(c, hipEventRecord(c->ln_done, c->ln_stream));
+            c->ln_pending = true;
+        }
         c->last_name_valid = true;
         if (sync) join_lastname(c, st);
     }

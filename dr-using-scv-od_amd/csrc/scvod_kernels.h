@@ -125,7 +125,8 @@ struct Arena {
     // the cluster that still carries Frame::max_name as ssc.cpp:354 stores it (scvod_lastname.hip)
     int32_t* cc_last;         // [B][4] {canonical name or -1, lowest voxel slot whose first point belongs to it or -1,
                               //         status: 0 exact, 1 a replay did not fit the LDS, 2 too many index triples outside the grid, events replayed}
-    int32_t* cc_redo;         // 2 x [B + 1] scans handed to the second / third pass (larger tables), [B] = how many
+    int32_t* cc_redo;         // 3 x [B + 1] scans listed by the triage for the pass with the small / mid / large tables, [B] = how many
+    int32_t* ln_state;        // [B][kLnStateWords] what the triage leaves a scan's follow-up pass: the set of classes, the irregular points, the class table
     int32_t* ln_prof;         // [B][8] phase clocks (10 ns ticks) and counts of the last pass over a scan: tools/lastname_lat.py
     int32_t* ln_prof2;        // [B][8] the largest class walked: nodes, Jacobi rounds, clocks of build / rounds / openers / partition / walk, events
     int32_t* ln_stats;        // [4] per clustering call: scans with status 1, with status 2, 0, 0
@@ -209,7 +210,8 @@ void launch_voxelgrid_lut(const Arena& A, hipStream_t st);
 void launch_voxelgrid_gather(const DevParams& P, const Arena& A, const VgJob& J, long long out_capacity, hipStream_t st);
 void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream_t st);
 void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu);
-void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, TimerHook th, void* tu);
+void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStream_t st2, hipStream_t st3, hipEvent_t ev_fork, hipEvent_t ev_join2,
+                     hipEvent_t ev_join3, TimerHook th, void* tu);
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,
                   TimerHook th, void* tu);
 struct ChainJob;

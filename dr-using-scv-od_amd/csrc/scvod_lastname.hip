@@ -45,6 +45,7 @@ constexpr int kLnPairs = 1024;    // links between clusters that such points cre
 constexpr int kLnNames = 256;     // distinct cluster names in those links
 constexpr int kLnSamples = 1024;  // sampled voxel keys (LDS)
 constexpr int kLnMarked = 16;     // components to replay besides the latest-born one
+constexpr int kLnCapTinyNodes = 320, kLnCapSmallNodes = 1792, kLnCapBigNodes = 8192;  // nodes the tables of the three passes hold
 constexpr int kLnChunk = 512;     // events staged per round
 constexpr int kInf = 0x7fffffff;
 
@@ -801,7 +802,11 @@ struct Blk {
 
 // One scan: everything above, by the TH threads of one workgroup on `ln_smem` (ln_lds_bytes<CAP>() bytes of LDS).  A scan whose
 // classes do not fit CAP nodes goes to `redo` / `redo_big` (lists on the device, [n_scans] = how many) or is reported unknown.
-template <int CAP, int TH>
+// MODE 0: the whole pass.  MODE 1 (triage): everything up to the set of classes to follow; the set, the irregular points and the
+// class table are left in A.ln_state and the scan is listed for the pass whose tables hold the set (lists[0 / 1 / 2]: up to
+// kLnCapTiny / kLnCapSmall / kLnCapBig nodes).  MODE 2: follows the set a triage left.
+constexpr int kLnStateWords = 8 + (kLnMarked + 1) + kLnIrr * 5 + kLnNames * 2;
+template <int CAP, int TH, int MODE>
 __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char* ln_smem, int32_t* redo, int32_t* redo_big, int big_from) {
     __shared__ int wsum[2 * kLnMaxWaves + 2];
     __shared__ int bc[8];
@@ -883,6 +888,11 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
     if (tid == 0) n_mk = 0, n_pairs_s = 0, n_irr_s = 0, fail_s = 0;
     __syncthreads();
 
+    int32_t* state = A.ln_state + (size_t)s * kLnStateWords;  // {n_set, n_irr, n_xs, n_names, 0..}, set, irr_pt / home / cls / reg0 / xs, cname, crep
+    bool unknown = false;
+    long long pt1 = pt0, pt2 = pt0, pt3 = pt0, pt4 = pt0;
+    int prof_cand = 0, prof_mk = 0;
+    if (MODE != 2) {
     // ---- index triples outside the grid: the points, then which clusters their lists tie into one closure class ----
     if (L.irregular) {
         for (int i0 = 0; i0 < L.n; i0 += TH) {
@@ -1060,11 +1070,7 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
 
     // ---- B: later points of the other classes that could still open a cluster (the latest-born class opens one with its
     // first point, at time CL: only what comes after that matters) ----
-    const long long pt1 = wall_clock64();
-    const long long pt2 = pt1;
-    long long pt3 = pt2, pt4 = pt2;
-    int prof_cand = 0, prof_mk = 0;
-    bool unknown = false;
+    pt1 = pt2 = pt3 = wall_clock64();
     {
         const int t_best = CL;
         // candidates: voxels whose first regular point comes after t_best (a few), irregular points after it -- listed first
@@ -1196,7 +1202,6 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
         prof_mk = n_mk;
     }
     // ---- C: the latest-born class and the classes of the candidates no certificate settled, walked together ----
-    RpOut best = {-1, 0, -1, -1, 0, 1, 0, 0, 0, 0, 0, 0, 0};
     if (!unknown) {
         if (tid == 0) {  // (racing waves may have listed a class twice: harmless)
             const int k = min(n_mk, kLnMarked);
@@ -1222,6 +1227,80 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
             }
             return;
         }
+    }
+    }  // MODE != 2
+    if (MODE == 1) {
+        // how many nodes the set has decides which pass follows it; the set and what the irregular points need go to A.ln_state
+        if (unknown) {
+            if (tid == 0) {
+                outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = 0;
+                atomicAdd(&A.ln_stats[0], 1);
+            }
+            return;
+        }
+        int cnt = 0;
+        for (int v = tid; v < L.nv; v += TH) {
+            const int c = L.vcl[v];
+            bool in = false;
+            for (int t = 0; t < n_mk; ++t) in |= mk_cls[t] == c;
+            cnt += in ? 1 : 0;
+        }
+        for (int j = tid; j < L.n_irr; j += TH) {
+            bool in = false;
+            for (int t = 0; t < n_mk; ++t) in |= mk_cls[t] == L.irr_cls[j];
+            cnt += in ? 1 : 0;
+        }
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+        __syncthreads();
+        if (lane == 0) red[wave] = cnt;
+        __syncthreads();
+        cnt = 0;
+        for (int w = 0; w < TH / 64; ++w) cnt += red[w];
+        for (int t = tid; t < n_mk; t += TH) state[8 + t] = mk_cls[t];
+        int32_t* sp = state + 8 + kLnMarked + 1;
+        for (int j = tid; j < L.n_irr; j += TH) {
+            sp[j] = L.irr_pt[j];
+            sp[kLnIrr + j] = L.irr_home[j];
+            sp[2 * kLnIrr + j] = L.irr_cls[j];
+            sp[3 * kLnIrr + j] = L.irr_reg0[j];
+        }
+        for (int j = tid; j < L.n_xs; j += TH) sp[4 * kLnIrr + j] = L.irr_xs[j];
+        for (int j = tid; j < L.n_names; j += TH) {
+            sp[5 * kLnIrr + j] = L.cname[j];
+            sp[5 * kLnIrr + kLnNames + j] = L.crep[j];
+        }
+        if (tid == 0) {
+            state[0] = n_mk, state[1] = L.n_irr, state[2] = L.n_xs, state[3] = L.n_names;
+            if (cnt > kLnCapBigNodes) {
+                outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = 0;
+                atomicAdd(&A.ln_stats[0], 1);
+            } else {
+                int32_t* list = redo + (size_t)(cnt <= kLnCapTinyNodes ? 0 : (cnt <= kLnCapSmallNodes ? 1 : 2)) * (A.n_scans + 1);
+                list[atomicAdd(list + A.n_scans, 1)] = s;
+            }
+        }
+        return;
+    }
+    if (MODE == 2) {
+        L.n_irr = state[1], L.n_xs = state[2], L.n_names = state[3];
+        if (tid == 0) n_mk = state[0];
+        for (int t = tid; t < state[0]; t += TH) mk_cls[t] = state[8 + t];
+        const int32_t* sp = state + 8 + kLnMarked + 1;
+        for (int j = tid; j < L.n_irr; j += TH) {
+            L.irr_pt[j] = sp[j];
+            L.irr_home[j] = sp[kLnIrr + j];
+            L.irr_cls[j] = sp[2 * kLnIrr + j];
+            L.irr_reg0[j] = sp[3 * kLnIrr + j];
+        }
+        for (int j = tid; j < L.n_xs; j += TH) L.irr_xs[j] = sp[4 * kLnIrr + j];
+        for (int j = tid; j < L.n_names; j += TH) {
+            L.cname[j] = sp[5 * kLnIrr + j];
+            L.crep[j] = sp[5 * kLnIrr + kLnNames + j];
+        }
+        __syncthreads();
+    }
+    RpOut best = {-1, 0, -1, -1, 0, 1, 0, 0, 0, 0, 0, 0, 0};
+    if (!unknown) {
         best = replay_class<CAP, TH>(L, T, mk_cls, n_mk, -1, wsum, bc);
         unknown = best.too_big != 0;
     }
@@ -1257,7 +1336,7 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
 }
 
 
-template <int CAP, int TH>
+template <int CAP, int TH, int MODE>
 __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo, int32_t* redo_big, int big_from,
                                                     int32_t* n_redo) {
     extern __shared__ __align__(16) unsigned char ln_kernel_smem[];
@@ -1266,63 +1345,66 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
         if (s >= *n_todo) return;
         s = todo[s];
     }
-    ln_scan<CAP, TH>(P, A, s, ln_kernel_smem, redo, redo_big, big_from);
+    ln_scan<CAP, TH, MODE>(P, A, s, ln_kernel_smem, redo, redo_big, big_from);
 }
 
 }  // namespace
 
-constexpr int kLnCapTiny = 320, kLnCapSmall = 1792, kLnCapBig = 8192;
+constexpr int kLnCapTiny = kLnCapTinyNodes, kLnCapSmall = kLnCapSmallNodes, kLnCapBig = kLnCapBigNodes;
 
-// Three passes: nearly every scan is settled by walking a few dozen voxels (tables of 320 nodes: eight workgroups per CU hide
-// each other's look-up latencies); a scan whose classes do not fit is listed on the device for the pass whose tables hold them
-// (the grid stays the batch, idle workgroups leave at once: nothing is read back on the host).  The two later passes are each
-// as long as their slowest scan, so they run side by side: `st2` (optional) takes the one with the largest tables.
-void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join, TimerHook th, void* tu) {
+// A triage pass over every scan (the set of classes to follow, or the answer when there is nothing to follow), then the three
+// passes that follow the sets -- tables of 320 / 1792 / 8192 nodes, each over the scans the triage listed for it on the device
+// (the grid stays the batch, idle workgroups leave at once: nothing is read back on the host).  Each of the three is as long as
+// its slowest scan, so they run side by side on `st`, `st2`, `st3` when those are given.
+void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStream_t st2, hipStream_t st3, hipEvent_t ev_fork, hipEvent_t ev_join2,
+                     hipEvent_t ev_join3, TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
-        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
-        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
-        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
         attr_set = true;
     }
-    int32_t* redo_mid = A.cc_redo;          // [B] scans, [B] = how many
-    int32_t* redo_big = A.cc_redo + B + 1;
-    hipMemsetAsync(redo_mid + B, 0, sizeof(int32_t), st);
-    hipMemsetAsync(redo_big + B, 0, sizeof(int32_t), st);
+    int32_t* lists = A.cc_redo;  // 3 x ([B] scans, [B] = how many)
+    for (int k = 0; k < 3; ++k) hipMemsetAsync(lists + (size_t)k * (B + 1) + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
-    const bool large = A.max_scan_pts > 100000;  // (128-beam class: a scan's tables are passed over by 1024 threads from the start)
+    const bool large = A.max_scan_pts > 100000;  // (128-beam class: a scan's tables are passed over by 1024 threads)
     if (th) th(tu, "cc_lastname", 1);
     if (!large)
-        hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)nullptr,
-                           (const int32_t*)nullptr, redo_mid, redo_big, kLnCapSmall, (int32_t*)nullptr);
-    else
-        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 1024>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
-                           (const int32_t*)nullptr, redo_big, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256, 1>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, lists, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+    else  // (LDS sized like the mid tables: the certificate blocks of 16 waves need the room)
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 1024, 1>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, lists, (int32_t*)nullptr, 0, (int32_t*)nullptr);
     if (th) th(tu, "cc_lastname", 0);
-    const bool side = st2 && ev_fork && ev_join && !th;  // (timed runs keep one stream: the hook records on one)
-    hipStream_t sb = side ? st2 : st;
+    const bool side = st2 && st3 && ev_fork && ev_join2 && ev_join3 && !th;  // (timed runs keep one stream: the hook records on one)
     if (side) {
         hipEventRecord(ev_fork, st);
         hipStreamWaitEvent(st2, ev_fork, 0);
-    } else {  // one stream: the mid pass first, what it cannot hold joins the last list
-        if (th) th(tu, "cc_lastname_mid", 1);
-        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)redo_mid,
-                           (const int32_t*)(redo_mid + B), redo_big, (int32_t*)nullptr, 0, (int32_t*)nullptr);
-        if (th) th(tu, "cc_lastname_mid", 0);
+        hipStreamWaitEvent(st3, ev_fork, 0);
     }
+    int32_t* l0 = lists, *l1 = lists + (B + 1), *l2 = lists + 2 * (size_t)(B + 1);
     if (th) th(tu, "cc_lastname_big", 1);
-    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), sb, P, A, (const int32_t*)redo_big,
-                       (const int32_t*)(redo_big + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024, 2>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), side ? st3 : st, P, A, (const int32_t*)l2,
+                       (const int32_t*)(l2 + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
     if (th) th(tu, "cc_lastname_big", 0);
+    if (th) th(tu, "cc_lastname_mid", 1);
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256, 2>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), side ? st2 : st, P, A, (const int32_t*)l1,
+                       (const int32_t*)(l1 + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+    if (th) th(tu, "cc_lastname_mid", 0);
+    if (th) th(tu, "cc_lastname_small", 1);
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256, 2>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)l0,
+                       (const int32_t*)(l0 + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+    if (th) th(tu, "cc_lastname_small", 0);
     if (side) {
-        // beside it: the mid pass; the (rare) scan it cannot hold after all is reported unknown rather than waited for
-        hipLaunchKernelGGL((k_cc_lastname<kLnCapSmall, 256>), dim3(B), dim3(256), ln_lds_bytes<kLnCapSmall>(), st, P, A, (const int32_t*)redo_mid,
-                           (const int32_t*)(redo_mid + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
-        hipEventRecord(ev_join, st2);
-        hipStreamWaitEvent(st, ev_join, 0);
+        hipEventRecord(ev_join2, st2);
+        hipEventRecord(ev_join3, st3);
+        hipStreamWaitEvent(st, ev_join2, 0);
+        hipStreamWaitEvent(st, ev_join3, 0);
     }
 }
 
