@@ -1372,7 +1372,7 @@ void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStre
     int32_t* lists = A.cc_redo;  // 3 x ([B] scans, [B] = how many)
     for (int k = 0; k < 3; ++k) hipMemsetAsync(lists + (size_t)k * (B + 1) + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
-    const bool large = A.max_scan_pts > 100000;  // (128-beam class: a scan's tables are passed over by 1024 threads)
+    const bool large = A.max_scan_pts > 200000;  // (128-beam class, 262 144 returns per scan: its tables are passed over by 1024 threads)
     if (th) th(tu, "cc_lastname", 1);
     if (!large)
         hipLaunchKernelGGL((k_cc_lastname<kLnCapTiny, 256, 1>), dim3(B), dim3(256), ln_lds_bytes<kLnCapTiny>(), st, P, A, (const int32_t*)nullptr,
