@@ -123,6 +123,37 @@ if os.path.exists(p):
         "tools/kernel_phases.py on the profiling build (make -C dr-using-scv-od_amd/csrc prof): 100 MHz wall clock between phase marks, thread 0 of every\n"
         "workgroup behind a barrier, summed over the workgroups of a kernel and divided by the scans\n\n" + open(p).read())
 d = last_json(os.path.join(src, "bench_full.json"))
+
+# the per-kernel table DESIGN.md section 4 points at: one row per bench label of the K64 line
+if d is not None:
+    sq = {}
+    if os.path.exists(os.path.join(src, "SQ_counter_collection.csv")):
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for k, c in load(os.path.join(src, "SQ_counter_collection.csv")).items():
+            for n, vals in c.items():
+                acc[label(k)][n] += sum(vals)
+        for l, c in acc.items():
+            wc = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            sq[l] = (c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, c.get("SQ_WAIT_ANY", 0.0) / wc,
+                     c.get("SQ_LDS_BANK_CONFLICT", 0.0) / (c.get("SQ_ACTIVE_INST_LDS", 0.0) or 1.0))
+    n_sc = d["config"]["scans_per_rank"]
+    with open(os.path.join(here, f"{tag}_kernel_table.md"), "w") as f:
+        f.write(f"Per-kernel table of the K64 bench line ({n_sc} scans per step; generated by profiles/refresh.py from bench_full.json, the PMC passes and the SQ pass).\n"
+                "ms: hipEvents around the kernel, average per step of the attribution pass.  MB/scan and GB/s: the kernel's OWN HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate\n"
+                "rocprofv3 --pmc passes) over its OWN time.  issue / valu / lds / wait: shares of SQ_WAVE_CYCLES; conflicts: LDS bank conflicts per LDS instruction.  bound: hbm when\n"
+                "the kernel moves > 2.5 TB/s, lds when the LDS share > 0.05 and it waits < 0.5, issue when > 0.45 of the cycles issue, latency otherwise.\n\n")
+        f.write("| kernel | ms / step | share | MB / scan | GB/s | issue | valu | lds | wait | conflicts | bound |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for name, k in d["kernels"].items():
+            mb = k.get("pmc_MB_per_scan")
+            gb = k.get("pmc_GBps")
+            q = sq.get(name)
+            bound = "-"
+            if q:
+                bound = "hbm" if (gb or 0) > 2500 else ("lds" if q[2] > 0.05 and q[3] < 0.5 else ("issue" if q[0] > 0.45 else "latency"))
+            elif gb:
+                bound = "hbm" if gb > 2500 else "latency"
+            f.write(f"| `{name}` | {k['avg_ms']:.3f} | {100 * k['share']:.1f} % | {('%.2f' % mb) if mb is not None else '-'} | {('%.0f' % gb) if gb else '-'} | "
+                    + (" | ".join(f"{v:.2f}" for v in q[:4]) + f" | {q[4]:.1f}" if q else "- | - | - | - | -") + f" | {bound} |\n")
 print("scans/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "roofline frac", round(d["roofline"]["frac"], 4))
 print("cpu", d["cpu_baseline"] and d["cpu_baseline"]["value"], "quality", d.get("quality") and {k: d["quality"][k] for k in ("delta_PR", "delta_RR")})
 print("total HBM MB/scan", round(total / 1e6, 2), "algorithmic MB/scan", round(d["roofline"]["algorithmic_bytes_per_scan"] / 1e6, 2))

@@ -94,3 +94,38 @@ def test_chain_with_the_literal_max_name(scvod, oracle, kind, preset, skip, coun
     got0 = np.concatenate([ctx.batch_fetch_track(s)["pt_dyn"] for s in range(count)])
     assert np.array_equal(got0, dyn3)
     ctx.close()
+
+
+@pytest.mark.parametrize("kind,preset,seq,idx", [("K64", "semantickitti", 5, 77), ("PARK", "parkinglot", 3, 9), ("K64", "semantickitti", 5, 1201)])
+def test_last_name_with_index_triples_outside_the_grid(scvod, oracle, kind, preset, seq, idx):
+    """returns at polar angle exactly 0 (sector index -1) alias onto another cell's voxel key, list nine cells instead of 27 and are
+    found by points they do not find: the pass follows them one by one.  Through the scan API (the device binned the cloud) and
+    through scvod_cluster (an apri_vec handed in: regularity is the clustering's own verdict, not the binning kernels' hint)."""
+    import synth
+    P = scvod.make_params(preset)
+    x = synth.make_scan(seq, idx, kind)[0].numpy()
+    rng = np.random.default_rng(idx)
+    for count in (7, 60, 200):
+        extra = np.stack([rng.uniform(3, 25, count), np.zeros(count), rng.uniform(-0.6, 1.2, count), rng.uniform(0, 1, count)], 1).astype(np.float32)
+        xi = np.concatenate([x, extra])[rng.permutation(len(x) + count)]  # (scattered through the visiting order)
+        ctx = scvod.Ctx(P, max_points_total=xi.shape[0] + 64, max_scans=1)
+        r = ctx.process_scan(xi)
+        assert (r["apri"]["sector_idx"] < 0).sum() >= count // 2
+        ctx.batch_cluster()
+        ctx.batch_cluster_types()
+        for apri in (r["apri"], r["apri"][::2].copy()):
+            if apri is not r["apri"]:
+                ctx.cluster(apri)  # scvod_cluster: voxelises the vector handed in, clusters it (and finds its max_name)
+                ctx.batch_cluster_types()
+            names = ctx.batch_fetch_clusters(0, len(apri))
+            types = ctx.batch_fetch_cluster_types(0, len(apri), car_label=2, other_label=1)
+            ln, st = ctx.batch_cluster_last_name(1)
+            want, info = oracle.cluster_last_name(P, apri)
+            assert ln[0, 2] == 0, (count, ln[0], st)
+            if ln[0, 0] == -1 and want >= 0:
+                assert types[want] == -1
+            else:
+                assert ln[0, 0] == want, (count, ln[0], want, info)
+                if want >= 0:
+                    assert names[want] == want
+        ctx.close()
