@@ -210,6 +210,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.rejected_src = k.take<int32_t>(N);
     A.counts = k.take<int32_t>(B * 8);
     A.scan_irr = k.take<int32_t>(B);
+    A.irr_list = k.take<int32_t>(B * (kIrrListCap + 1));
     A.cc_perm = k.take<int32_t>(B);
     A.vb_count = k.take<int32_t>(B * kMaxBuckets);
     A.vb_cursor = k.take<int32_t>(B * kMaxBuckets);

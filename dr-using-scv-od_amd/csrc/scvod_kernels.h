@@ -14,6 +14,7 @@ namespace scvod {
 constexpr int kMaxPatches = SCVOD_MAX_PATCHES;
 constexpr int kMaxBuckets = 1024;
 constexpr int kVgLutBins = 16384;
+constexpr int kIrrListCap = 256;  // points of a scan with an index triple outside the grid that k_emit lists (Arena::irr_list)
 // marks per INPUT point for the static map, which streams the input in order: whether Patchwork kept a point at all follows
 // from its patch id (pid) and that patch's population; k_tk_dyn marks the members of dynamic clusters; the two list marks are
 // only written when a caller asks for a map without the ground or without the range/FOV rejects
@@ -85,6 +86,8 @@ struct Arena {
     int32_t* rejected_src;    // [N]
     int32_t* counts;          // [B][8]
     int32_t* scan_irr;        // [B] != 0: the scan holds an index triple outside the grid (set by the binning kernels; only orders the clustering)
+    int32_t* irr_list;        // [B][kIrrListCap + 1] [0] = how many points of the scan have an index triple outside the grid (-1: not listed by the
+                              //   kernel that binned the batch), then their apri indices: k_emit -> scvod_lastname.hip
     int32_t* cc_perm;         // [B] order in which k_cc_scan takes the scans: the irregular ones (the long-running workgroups) first
     // voxel stage
     int32_t* vb_count;        // [B][kMaxBuckets]

@@ -471,6 +471,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
     if (do_voxels) {
         if (do_patchwork == 2) {
             hipMemsetAsync(A.scan_irr, 0, sizeof(int32_t) * (size_t)B, st);  // (order hint of the clustering: unknown here)
+            hipMemsetAsync(A.irr_list, 0xff, sizeof(int32_t) * (size_t)B * (kIrrListCap + 1), st);  // (-1: irregular points not listed)
             hipLaunchKernelGGL(k_apri_split, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A);
         }
         hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);

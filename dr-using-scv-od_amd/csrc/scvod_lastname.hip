@@ -895,11 +895,18 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
     if (MODE != 2) {
     // ---- index triples outside the grid: the points, then which clusters their lists tie into one closure class ----
     if (L.irregular) {
-        for (int i0 = 0; i0 < L.n; i0 += TH) {
-            const int i = i0 + tid;
-            if (i < L.n && !regular_point(L, i)) {
-                const int x = atomicAdd(&n_irr_s, 1);
-                if (x < kLnIrr) L.irr_pt[x] = i;
+        const int32_t* il = A.irr_list + (size_t)s * (kIrrListCap + 1);
+        const int listed = il[0];
+        if (listed >= 0) {  // k_emit listed them while it binned the scan
+            for (int x = tid; x < min(listed, kLnIrr); x += TH) L.irr_pt[x] = il[1 + x];
+            if (tid == 0) n_irr_s = listed;
+        } else {
+            for (int i0 = 0; i0 < L.n; i0 += TH) {
+                const int i = i0 + tid;
+                if (i < L.n && !regular_point(L, i)) {
+                    const int x = atomicAdd(&n_irr_s, 1);
+                    if (x < kLnIrr) L.irr_pt[x] = i;
+                }
             }
         }
         __syncthreads();
