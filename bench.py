@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-quality", action="store_true", help="skip the PR/RR comparison")
     ap.add_argument("--no-extras", action="store_true", help="skip the separately reported stages (VoxelGrid, ingest): profiling runs")
     ap.add_argument("--split-sequence", action="store_true", help="strong scaling: ONE sequence of --scans scans over the ranks (contiguous blocks, a halo of 12 x skip scans for the tracking chain's warm-up, the chain's state handed from rank to rank: pyshim/shard.py plan_split)")
+    ap.add_argument("--kitti", action="store_true", help="the job is SemanticKITTI seq 00-10 at their real lengths (BASELINE configs[3], 23 201 scans: needs the memory of several GPUs); with --split-sequence the sequences are cut where the load says")
     ap.add_argument("--split-halo", type=int, default=12, help="warm-up steps of the halo in front of a rank's block (--split-sequence)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short PARK / OS128 sub-runs that the default invocation appends under extras.configs")
     ap.add_argument("--no-map", action="store_true", help="leave the static map out of the step (profiling)")
@@ -182,14 +183,18 @@ def main():
         args.skip = 1 if args.preset == "parkinglot" else 5
     job = shard.weak_scaling_sequences(args.sequences or world, args.scans)
     split = None
-    if args.split_sequence:  # one sequence, contiguous blocks (+ halo) per rank
-        job = job[:1]
-        split = shard.plan_split(world, args.scans, skip=args.skip, warm=args.split_halo)[rank]
-        plan = dict(scans=[(job[0][0], job[0][1] + i) for i in range(split["lo"], split["hi"])], next_scan=split["next_scan"], skip=args.skip)
+    if args.kitti:  # BASELINE configs[3]: seq 00-10 at their real lengths
+        job = shard.kitti_sequences(synth.SEQ_LEN)
+    if args.split_sequence:  # the job's scans, sequence after sequence, in equal contiguous runs: sequences are CUT (+ halo) where the load says
+        if not args.kitti:
+            job = shard.weak_scaling_sequences(args.sequences or 1, args.scans)
+        split = shard.plan_job_split(world, job, skip=args.skip, warm=args.split_halo)[rank]
+        plan = dict(scans=split["scans"], next_scan=split["next_scan"], skip=args.skip)
     else:
         plan = shard.plan_job(world, job, skip=args.skip)[rank]
     n_sc = len(plan["scans"])
-    own_first, own_count = (split["own_first"], split["own_count"]) if split else (0, n_sc)
+    own_spans = [(sp["own_first"], sp["own_count"]) for sp in split["spans"]] if split else [(0, n_sc)]
+    own_count = sum(c for _, c in own_spans)
 
     # ---- the rank's scans, resident in HBM ----
     t0 = time.time()
@@ -217,7 +222,7 @@ def main():
     if args.max_name_fresh:
         ctx.set_max_name_literal(False)
     if split:
-        ctx.set_track_owned(own_first)
+        ctx.set_track_halo(split["is_halo"])
     stream = torch.cuda.current_stream().cuda_stream  # torch.distributed orders its work against this stream
     nxt = plan["next_scan"]
     T = np.zeros((n_sc, 12), np.float32)
@@ -260,10 +265,8 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             smap.clear(stream=stream)
-            if split:
-                smap.accumulate_range(ctx, poses, own_first, own_count, stream=stream)
-            else:
-                smap.accumulate(ctx, poses, stream=stream)
+            for f0, c0 in own_spans:  # (a rank adds its OWN scans: a halo belongs to the rank before)
+                smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
             if timed:
                 e1.record()
                 e1.synchronize()
@@ -303,12 +306,10 @@ def main():
         ctx.batch_cluster_types(stream=stream, sync=False)
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         smap.clear(stream=stream)
-        if split:
-            if world > 1:
-                shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
-            smap.accumulate_range(ctx, poses, own_first, own_count, stream=stream)
-        else:
-            smap.accumulate(ctx, poses, stream=stream)
+        if split and world > 1:
+            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+        for f0, c0 in own_spans:
+            smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
         _, counts0 = smap.export_parts(world, stream=stream)
         t_cap = torch.tensor([max(counts0)], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t_cap, op=dist.ReduceOp.MAX)
@@ -368,10 +369,11 @@ def main():
         dist.all_reduce(t_cells)
         map_cells = int(t_cells.item())
     if args.dump_map:
-        dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in range(own_first, own_first + own_count)], np.int64)
+        own_idx = [s for f0, c0 in own_spans for s in range(f0, f0 + c0)]
+        dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in own_idx], np.int64)
         gathered = [None] * world
         mine = (pmap if multi else smap).export().cpu().numpy().view(np.uint64)
-        own_scans = [list(map(int, q)) for q in plan["scans"][own_first:own_first + own_count]]
+        own_scans = [list(map(int, plan["scans"][s])) for s in own_idx]
         if dist is not None:
             dist.all_gather_object(gathered, (rank, own_scans, dynpts.tolist(), mine))
         else:
@@ -413,7 +415,7 @@ def main():
         except Exception as e:
             extras["ingest_error"] = str(e)[:200]
 
-    own_pts = int(offs[own_first + own_count] - offs[own_first])
+    own_pts = int(sum(offs[f0 + c0] - offs[f0] for f0, c0 in own_spans))
     dt, all_scans, all_pts = shard.aggregate(dist, dev if args.backend == "nccl" else torch.device("cpu"), dt, own_count, own_pts)
 
     if rank == 0:
@@ -506,16 +508,16 @@ def main():
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 and len(job) == 1 else
-                                       f"seq05-shaped {args.kind} sequence, {args.scans} scans, {args.preset}.yaml grid, split over {world} ranks" if split else
+                                       f"{len(job)} {args.kind} sequence(s), {int(all_scans)} scans ({'SemanticKITTI seq 00-10 lengths' if args.kitti else str(args.scans) + ' each'}), {args.preset}.yaml grid, dealt as equal contiguous runs over {world} ranks (sequences cut)" if split else
                                        f"{len(job)} sequences of {args.scans} {args.kind} scans (seeded like seq 05, 00, 02, 08, ...), {int(all_scans)} scans in total, whole sequences per rank, {args.preset}.yaml grid"),
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
                           "static_map_cells": map_cells, "static_map_table_cells": info.get("map_table_cells", (cells if smap is not None else None)), "tracking": args.track_mode, "tracking_chain": chain_stats, "clustering": cluster_stats, "max_name": max_name_stats,
                           "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                           "tracking_stride": args.skip,
-                          "sharding": (f"one sequence, contiguous blocks per rank + a halo of {args.split_halo} x {args.skip} scans; the tracking chain's state at a block boundary is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else
+                          "sharding": (f"equal contiguous runs of the job's scans per rank (sequences are cut) + a halo of {args.split_halo} x {args.skip} scans in front of a cut; the tracking chain's state at a cut is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else
                                        "whole sequences per rank (longest first to the least loaded rank)"),
-                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary")} if split else None)},
+                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary")} if split else None)},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
         if multi:

@@ -86,6 +86,8 @@ def plan_job_split(world, sequences, skip=1, warm=12):
     `world` contiguous runs of equal length (up to one scan); a run that starts inside a sequence gets the halo of warm x skip
     scans of that sequence in front (plan_split).  Returns per rank a dict:
       pieces     [(seq_id, lo, own_a, own_b, hi)]: scans [lo, hi) of the sequence are loaded, [own_a, own_b) are the rank's own
+      spans      per piece: local scan range [begin, end), own_first / own_count (local), lo, cut_before / cut_behind (the
+                 sequence continues on the rank before / behind: the tracking chain's state crosses there)
       scans      [(seq_id, idx)] in processing order;  next_scan  int32: local successor or -1;  is_halo  uint8 per local scan
       own        number of own scans
     Balance = own scans of the fullest rank against the mean: >= 0.99 by construction; the halo (<= warm x skip scans per cut)
@@ -96,7 +98,7 @@ def plan_job_split(world, sequences, skip=1, warm=12):
     out = []
     for r in range(world):
         a, b = cuts[r], cuts[r + 1]
-        pieces, scans, nxt, halo = [], [], [], []
+        pieces, spans, scans, nxt, halo = [], [], [], [], []
         g0 = 0
         for (q, first, count) in sequences:
             q, first, count = int(q), int(first), int(count)
@@ -112,54 +114,54 @@ def plan_job_split(world, sequences, skip=1, warm=12):
                     nxt.append(base + i + skip if i + skip < m else -1)
                     halo.append(1 if lo + i < oa else 0)
                 pieces.append((q, lo, oa, ob, hi))
+                spans.append(dict(begin=base, own_first=base + oa - lo, own_count=ob - oa, end=base + m, lo=lo, cut_before=oa > 0, cut_behind=ob < count))
             g0 = g1
-        out.append(dict(pieces=pieces, scans=scans, next_scan=np.asarray(nxt, np.int32).reshape(-1), is_halo=np.asarray(halo, np.uint8).reshape(-1),
+        out.append(dict(pieces=pieces, spans=spans, scans=scans, next_scan=np.asarray(nxt, np.int32).reshape(-1), is_halo=np.asarray(halo, np.uint8).reshape(-1),
                         own=b - a, skip=skip))
     return out
 
 
 def resolve_chain_boundaries(dist, ctx, plan, rank, world, device):
-    """After every rank ran scvod_batch_track on its block + halo: rank r - 1 sends the state each chain ENDED in, rank r
-    compares it with what its warm-up assumed and walks again what differs (scvod_batch_track_resume), then passes its own
-    end states on.  The ranks take their turn in order, so a correction cascades down the sequence like inside one shard;
-    the states are a few hundred KB and nothing else is exchanged.  Returns the number of chains this rank walked again."""
+    """After every rank ran scvod_batch_track on its blocks + halos: a rank whose LAST piece ends inside a sequence sends the
+    state each chain of that piece ENDED in to the next rank, whose FIRST piece continues that sequence; the receiver compares
+    with what its warm-up assumed and walks again what differs (scvod_batch_track_resume), then passes its own end states on.
+    The ranks take their turn in order, so a correction cascades down a sequence like inside one shard; the states are a few
+    hundred KB and nothing else is exchanged.  plan: one entry of plan_job_split (or plan_split).  Returns the number of chains
+    this rank walked again."""
     import torch
     if world <= 1:
         return 0
     skip = plan["skip"]
-    backend = dist.get_backend()
-    on_dev = backend == "nccl"
-
-    def residue_of(first_local, lo):  # which interleaved sub-sequence a chain is
-        return (lo + int(first_local)) % skip
-
+    spans = plan.get("spans") or [dict(begin=0, end=len(plan["next_scan"]), lo=plan["lo"], cut_before=rank > 0, cut_behind=rank + 1 < world)]
+    on_dev = dist.get_backend() == "nccl"
+    where = device if on_dev else "cpu"
     firsts = ctx.batch_track_chains()
+
+    def chains_of(span):  # {residue of the interleaved sub-sequence: chain index}
+        return {(span["lo"] + int(f) - span["begin"]) % skip: c for c, f in enumerate(firsts) if span["begin"] <= int(f) < span["end"]}
+
     rewalked = 0
-    if rank > 0:  # what the shard before really ended in, one record per sub-sequence
-        sizes = torch.zeros(skip, dtype=torch.int64, device=device if on_dev else "cpu")
+    if rank > 0 and spans and spans[0]["cut_before"]:  # what the rank before really ended in, one record per sub-sequence
+        sizes = torch.zeros(skip, dtype=torch.int64, device=where)
         dist.recv(sizes, src=rank - 1)
         recs = []
         for k in range(skip):
-            t = torch.empty(int(sizes[k].item()), dtype=torch.uint8, device=device if on_dev else "cpu")
+            t = torch.empty(int(sizes[k].item()), dtype=torch.uint8, device=where)
             if t.numel():
                 dist.recv(t, src=rank - 1)
             recs.append(t)
         before = ctx.batch_track_stats()["rewalked"]
         states = [None] * len(firsts)
-        keep = []
-        for c, f in enumerate(firsts):
-            t = recs[residue_of(f, plan["lo"])]
-            if t.numel() >= 16:
-                t = t.to(device)
-                keep.append(t)
-                states[c] = t
+        for res, c in chains_of(spans[0]).items():
+            if recs[res].numel() >= 16:
+                states[c] = recs[res].to(device)
         ctx.batch_track_resume(states)
         rewalked = ctx.batch_track_stats()["rewalked"] - before
-    if rank + 1 < world:
+    if rank + 1 < world and spans and spans[-1]["cut_behind"]:
         by_res = [torch.zeros(0, dtype=torch.uint8)] * skip
-        for c, f in enumerate(firsts):
-            by_res[residue_of(f, plan["lo"])] = ctx.chain_export_state(c, 1)
-        sizes = torch.tensor([int(t.numel()) for t in by_res], dtype=torch.int64, device=device if on_dev else "cpu")
+        for res, c in chains_of(spans[-1]).items():
+            by_res[res] = ctx.chain_export_state(c, 1)
+        sizes = torch.tensor([int(t.numel()) for t in by_res], dtype=torch.int64, device=where)
         dist.send(sizes, dst=rank + 1)
         for t in by_res:
             if t.numel():

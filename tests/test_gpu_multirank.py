@@ -63,3 +63,16 @@ def test_one_sequence_split_over_two_ranks(tmp_path):
     assert m1["dynamic_points"].sum() > 0
     assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
     assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])
+
+
+def test_two_sequences_cut_over_three_ranks(tmp_path):
+    """plan_job_split through the device path: two sequences of 40 scans dealt as three runs of 26 / 27 / 27 scans -- the first is
+    cut once, the second once; rank 1 receives the end of sequence A from rank 0, holds the start of sequence B and sends ITS end to
+    rank 2.  Per-scan results and the merged map equal the run with whole sequences on one rank."""
+    one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "40", "--sequences", "2"])
+    cut, m2 = _run(str(tmp_path), "cut", ["--gpus", "3", "--scans", "40", "--sequences", "2", "--same-device", "--split-sequence", "--split-halo", "3"])
+    assert cut["n_gpus"] == 3 and cut["scaling"] == "strong" and len(cut["config"]["split"]["pieces_rank0"]) == 1
+    assert np.array_equal(m1["scans"], m2["scans"]) and len(m2["scans"]) == 80
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
+    assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])
