@@ -231,8 +231,9 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vox_pts = k.take<int32_t>(N);
     A.vox_av = k.take<float>(N);
     A.vox_cov = k.take<float>(N);
-    A.cc_stats = k.take<int32_t>(4);
+    A.cc_stats = k.take<int32_t>(8);
     A.cc_exact_max = 4096;
+    A.cc_plain_rule = 1;
     A.cc_parent = k.take<int32_t>(N);
     A.cc_touched = k.take<uint8_t>(N);
     A.pt_voxel = k.take<int32_t>(N);
@@ -1414,6 +1415,7 @@ int scvod_batch_track_resume(scvod_ctx* c, const void* const* h_d_states, int32_
 int scvod_set_cluster_exact(scvod_ctx* c, int32_t on) {
     if (!c) return SCVOD_ERR_INVALID;
     c->A.cc_exact_max = on ? 0x3fffffff : 4096;
+    c->A.cc_plain_rule = on == 2 ? 0 : 1;
     c->clusters_valid = c->types_valid = c->tables_valid = c->track_valid = false;
     return SCVOD_OK;
 }
@@ -1424,6 +1426,14 @@ int scvod_batch_cluster_stats(scvod_ctx* c, int32_t* h_out4) {
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy(h_out4, c->A.cc_stats, 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
     h_out4[2] = c->A.cc_exact_max > 4096 ? 1 : 0;
+    return SCVOD_OK;
+}
+
+int scvod_batch_cluster_rule_stats(scvod_ctx* c, int32_t* h_out2) {
+    if (!c || !h_out2) return SCVOD_ERR_INVALID;
+    if (!c->clusters_valid) return fail(c, SCVOD_ERR_STATE, "no clustering of the last batch");
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    HIPCHK(c, hipMemcpy(h_out2, c->A.cc_stats + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
     return SCVOD_OK;
 }
 

@@ -114,8 +114,9 @@ struct Arena {
     float* vox_cov;           // [N]
     // clustering (connected components of occupied voxels)
     int32_t cc_exact_max;     // generic clustering variant: nodes of components with irregular runs that are re-clustered exactly
-                              //   (default 4096; scvod_set_cluster_exact lifts it to "any")
-    int32_t* cc_stats;        // [4] per clustering call: scans that kept "everything found is joined" for a component, nodes of
+                              //   (default 4096; scvod_set_cluster_exact(ctx, 1 or 2) lifts it to "any")
+    int32_t cc_plain_rule;    // 1: irregular runs that the cells around them settle are left as found (cc_run_is_plain); 0: every one is re-clustered
+    int32_t* cc_stats;        // [8] per clustering call: [4] irregular runs settled by the rule, [5] the others; [0..3] scans that kept "everything found is joined" for a component, nodes of
                               //   those components (an upper bound from a sample when they are not even listed), 0, scans of the generic variant
                               //   whose z-planes are too large for the windowed search (forest in HBM)
     int32_t* cc_parent;       // [N] union-find forest over apri indices (scan-local)

@@ -583,7 +583,7 @@ void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream
 }
 
 void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu) {
-    hipMemsetAsync(A.cc_stats, 0, 4 * sizeof(int32_t), st);
+    hipMemsetAsync(A.cc_stats, 0, 8 * sizeof(int32_t), st);
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
     hipFuncSetAttribute((const void*)k_cc_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcLdsBytes);

@@ -370,14 +370,23 @@ int scvod_batch_export_table(scvod_ctx* ctx, int32_t s, void* d_out, int64_t cap
 int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
 /* The visiting order of clusterAndCreateFrame (ssc.cpp:322-340) only matters around index triples OUTSIDE the grid (a
  * return at polar angle exactly 0 has sector index -1, ...).  Scans whose tables fit the LDS (every 64-beam scan) are
- * clustered with the exact visiting-order model always.  Larger scans (128 beams on a fine grid) model it exactly for the
- * components that hold such a triple as long as these have <= 4096 nodes together and otherwise keep "everything found is
- * joined" (the reference's partition then refines the device's).  on != 0 lifts the bound: exact for every scan, at
- * milliseconds per affected scan.  scvod_batch_cluster_stats: h_out4 = {scans of the last clustering that kept the
- * approximation, nodes of the components concerned (upper bound), exact flag, scans beyond the LDS whose z-planes were
- * too large for the windowed search and were joined on a forest in HBM instead (slower, same result)}.  Synchronises. */
+ * clustered with the exact visiting-order model always.  Larger scans (128 beams on a fine grid) first ask a local rule
+ * per irregular run -- do the cells around its triple and around its key's own cell settle that every find sticks? (the
+ * statement: csrc/scvod_k_cluster.inc cc_run_is_plain, pinned against the reference loop by
+ * tests/test_irregular_runs_rule.py) -- and model the visiting order exactly for the components of the runs it does not
+ * settle (about one 128-beam scan in thirty has such a run).  on = 0 (the default): while those components have <= 4096
+ * nodes together; beyond that the scan keeps "everything found is joined" for them (the reference's partition then
+ * refines the device's) and is counted.  on = 1: whatever their size -- tens of milliseconds for a component of tens of
+ * thousands of nodes, on the one workgroup that owns the scan (a batch waits for its slowest scan: DESIGN.md section 7b).
+ * on = 2: exact without the rule (every component with an irregular run is clustered again: what the rule is
+ * tested against).  scvod_batch_cluster_stats: h_out4 = {scans of the last clustering that kept the approximation, nodes
+ * of the components concerned (upper bound), 1 when the bound is lifted (on = 1, 2), scans beyond the LDS whose z-planes were
+ * too large for the windowed search and were joined on a forest in HBM instead (slower, same result)};
+ * scvod_batch_cluster_rule_stats: h_out2 = {irregular runs of those larger scans the rule settled, runs whose component
+ * was clustered again}.  Both synchronise. */
 int scvod_set_cluster_exact(scvod_ctx* ctx, int32_t on);
 int scvod_batch_cluster_stats(scvod_ctx* ctx, int32_t* h_out4);
+int scvod_batch_cluster_rule_stats(scvod_ctx* ctx, int32_t* h_out2);
 /* Frame::max_name.  clusterAndCreateFrame ends with `frame_ssc.max_name = cluster_name ++;` (ssc.cpp:354): the frame keeps
  * the LAST USED running number K, and the first cluster SSC::tracking splits off or fuses in that frame is called K again
  * (ssc.cpp:1357, :1401) -- when a cluster K is still alive the insert (:1372, :1419) is a no-op and the new cluster is lost.

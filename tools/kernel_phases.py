@@ -21,7 +21,9 @@ KERNELS = [
     ("k_vx_bucket<4096> (per scan)", ["load keys", "bitonic sort", "heads + voxel starts", "stage intensities", "per-voxel sums", "final writes"]),
     ("k_cc_scan generic variant, inside 'neighbour search + unions' (per scan)",
      ["opener triples + regular bits", "spill, plane starts, init", "windows: plan", "windows: load", "windows: search in LDS", "windows: write-out",
-      "(from 'extra runs, canonical names') extra runs", "(from 'extra runs, canonical names') affected components: marks, sample, list"]),
+      "(from 'extra runs, canonical names') extra runs", "(from 'extra runs, canonical names') rest of the affected-components block",
+      "irregular runs: rule, marks, sample, list", "exact path: run records + listed voxels", "exact path: rounds", "exact path: q", "exact path: unions",
+      "exact path: number of rounds"]),
 ]
 
 
