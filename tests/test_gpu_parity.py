@@ -866,6 +866,38 @@ def test_realistic_scans_with_their_irregular_returns_agree(scvod, oracle, kind,
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_os128_scans_with_runs_the_local_rule_does_not_settle(scvod, oracle, mode):
+    """two synthetic 128-beam scans (729, 734 of the sequence) hold an irregular return whose finds the cells around it do
+    not settle (two listed voxels that do not find each other, both still unvisited): its component -- a facade of tens of
+    thousands of points -- is clustered again with the visiting order when the bound is lifted (mode 1: the reference's
+    partition), and kept as found + counted by default (mode 0: the reference's partition refines the device's); scan 700
+    is settled by the rule alone in both modes"""
+    import torch
+    import synth
+    P = _params(scvod, "os128_fine")
+    scans = [synth.make_scan(5, i, "OS128")[0].numpy() for i in (729, 700, 734)]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=3)
+    if mode:
+        ctx.set_cluster_exact(mode)
+    ctx.batch_process(torch.from_numpy(np.concatenate(scans)).cuda(), offs)
+    ctx.batch_cluster()
+    st = ctx.batch_cluster_stats()
+    assert st["runs_clustered_again"] >= 2 and st["runs_settled_by_rule"] >= 100
+    assert st["scans_approximated"] == (0 if mode else 2)
+    for s in range(3):
+        r = ctx.batch_fetch(s)
+        got = ctx.batch_fetch_clusters(s, r["n_apri"])
+        can = _canonical(oracle.cluster(P, r["apri"])[0])
+        if mode or s == 1:
+            assert np.array_equal(got, can), f"scan {s}"
+        else:
+            pairs = np.unique(np.stack([can, got], 1), axis=0)
+            assert len(np.unique(pairs[:, 0])) == len(pairs), f"scan {s}: a reference cluster is split on the device"
+    ctx.close()
+
+
 def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
     """more apri points than the generic variant's LDS bit arrays hold (262 144): start bits / prefixes in arena scratch,
     keys and parents in HBM; a few irregular returns among them"""
