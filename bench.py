@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--no-quality", action="store_true", help="skip the PR/RR comparison")
     ap.add_argument("--no-extras", action="store_true", help="skip the separately reported stages (VoxelGrid, ingest): profiling runs")
     ap.add_argument("--split-sequence", action="store_true", help="strong scaling: ONE sequence of --scans scans over the ranks (contiguous blocks, a halo of 12 x skip scans for the tracking chain's warm-up, the chain's state handed from rank to rank: pyshim/shard.py plan_split)")
+    ap.add_argument("--replicate", action="store_true", help="N > 1: every rank runs a sequence of its own (weak scaling: rounds 1-3) instead of cutting ONE sequence over the ranks (the default at N > 1)")
     ap.add_argument("--kitti", action="store_true", help="the job is SemanticKITTI seq 00-10 at their real lengths (BASELINE configs[3], 23 201 scans: needs the memory of several GPUs); with --split-sequence the sequences are cut where the load says")
     ap.add_argument("--split-halo", type=int, default=12, help="warm-up steps of the halo in front of a rank's block (--split-sequence)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short PARK / OS128 sub-runs that the default invocation appends under extras.configs")
@@ -174,6 +175,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    # N > 1: the path shards the scans of ONE sequence (BASELINE north_star: strong scaling of configs[1]) unless told otherwise
+    if world > 1 and not args.replicate and not args.sequences and not args.kitti:
+        args.split_sequence = True
+    side = None
+    if dist is not None and world > 1 and args.split_sequence and args.backend == "nccl":
+        side = dist.new_group(backend="gloo")  # the chain's boundary records (a few hundred KB, staged through the host)
     multi = dist is not None  # the N > 1 step (also at one rank with --force-dist: RCCL initialised, device collectives executed)
     import scvod_py
     import shard
@@ -260,7 +267,7 @@ def main():
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         after()
         if split and world > 1:  # the chain's state at the block boundaries: from rank to rank, walked again where the warm-up missed it
-            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
         if smap is not None:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -308,7 +315,7 @@ def main():
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         smap.clear(stream=stream)
         if split and world > 1:
-            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
         for f0, c0 in own_spans:
             smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
         _, counts0 = smap.export_parts(world, stream=stream)

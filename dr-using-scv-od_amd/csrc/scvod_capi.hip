@@ -87,6 +87,7 @@ struct scvod_ctx {
     ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
     int32_t* d_chain_fw = nullptr;           // [cap_scans + 1]
     int32_t* d_chain_stats = nullptr;        // [8]
+    int32_t* d_chain_cmp = nullptr;          // [1] scvod_batch_track_compare
     std::vector<uint8_t> halo;               // per scan of a batch: 1 = halo (warmed up over, never decided): scvod_set_track_owned / _halo
     ChainJob last_cj;                        // the chain job of the last scvod_batch_track (export / resume)
     TrackBatch last_tb;
@@ -288,6 +289,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     c->d_chain_walkers = k.take<ChainWalker>(B);
     c->d_chain_fw = k.take<int32_t>(B + 1);
     c->d_chain_stats = k.take<int32_t>(8);
+    c->d_chain_cmp = k.take<int32_t>(4);
     c->d_ext_state = k.take<const unsigned char*>(B);
     *total = align_up(k.off, 256);
 }
@@ -1142,13 +1144,18 @@ int scvod_batch_cluster(scvod_ctx* c, void* stream, int32_t sync) {
     // in round 4, k_cc_scan 3.1 -> 7.6 ms; as separate passes with eight small workgroups per CU it costs 3 ms, partly hidden.)
     if (c->max_name_literal) {
         if (!c->ln_stream) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream, hipStreamNonBlocking));
+            // (highest priority: the few workgroups of these passes -- one per scan that needs one, each a chain of dependent
+            // look-ups -- are dispatched ahead of the tracking kernels' thousands and finish while those stream)
+            int prio_low = 0, prio_high = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+            if (getenv("SCVOD_LN_NO_PRIORITY")) prio_high = prio_low;
+            HIPCHK(c, hipStreamCreateWithPriority(&c->ln_stream, hipStreamNonBlocking, prio_high));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_fork, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_done, hipEventDisableTiming));
-            HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream2, hipStreamNonBlocking));
+            HIPCHK(c, hipStreamCreateWithPriority(&c->ln_stream2, hipStreamNonBlocking, prio_high));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_fork2, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_join2, hipEventDisableTiming));
-            HIPCHK(c, hipStreamCreateWithFlags(&c->ln_stream3, hipStreamNonBlocking));
+            HIPCHK(c, hipStreamCreateWithPriority(&c->ln_stream3, hipStreamNonBlocking, prio_high));
             HIPCHK(c, hipEventCreateWithFlags(&c->ln_join3, hipEventDisableTiming));
         }
         if (c->timing) {  // attribution runs: one stream, one pair of events per pass
@@ -1409,6 +1416,26 @@ int scvod_batch_track_resume(scvod_ctx* c, const void* const* h_d_states, int32_
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));  // (the pointer table is a pageable host array)
     (void)sync;
+    return SCVOD_OK;
+}
+
+int scvod_batch_track_compare(scvod_ctx* c, const void* const* h_d_states, int32_t n_states, int32_t* h_differ, void* stream) {
+    if (!c || !h_d_states || !h_differ) return SCVOD_ERR_INVALID;
+    if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track_compare needs a chain-mode scvod_batch_track first");
+    if (n_states != c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "%d states for %d chains", n_states, c->last_cj.n_chains);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    c->last_stream = st;
+    HIPCHK(c, hipMemcpyAsync((void*)c->d_ext_state, h_d_states, sizeof(void*) * (size_t)n_states, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->d_chain_cmp, 0, sizeof(int32_t), st));
+    ChainJob CJ = c->last_cj;
+    CJ.ext_state = c->d_ext_state;
+    CJ.resume = 2;
+    CJ.cmp_out = c->d_chain_cmp;
+    launch_track_chain_resume(c->dev, c->A, c->last_tb, CJ, c->batch_mode == 2 ? 1 : 0, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(h_differ, c->d_chain_cmp, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     return SCVOD_OK;
 }
 

@@ -37,6 +37,8 @@ struct ChainJob {
     int32_t force_generic;  // testing: every step through the HBM-resident generic path
     const unsigned char* const* ext_state;  // [n_chains] resume: the state the chain's predecessor (on another shard) really ended in, or nullptr
     int32_t resume;       // k_tk_chain_fix: compare the first walker's warm-up snapshot with ext_state first, walk it again when they differ
+                          //    (2: compare only -- count the chains that would be walked again in cmp_out, change nothing)
+    int32_t* cmp_out;     // [1] resume == 2
     int32_t literal_max_name;  // 1: a frame's first new cluster re-uses Frame::max_name as ssc.cpp:354 stores it (Arena::cc_last)
 };
 

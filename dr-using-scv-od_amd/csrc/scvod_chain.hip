@@ -1365,8 +1365,12 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
         if (!W0.ext || !ext) return;
         const Wk K0 = wk_of(C.ws, w0);
         const ExtRec R = ext_of(ext);
-        if (threadIdx.x == 0) atomicAdd(&C.stats[2], 1);
+        if (threadIdx.x == 0 && C.resume == 1) atomicAdd(&C.stats[2], 1);
         const bool ok = R.hdr[3] != 0 && K0.hdr[H_HAS_SNAP] != 0 && same_state_ext(K0, 2, R);
+        if (C.resume == 2) {  // compare only (scvod_batch_track_compare)
+            if (threadIdx.x == 0 && !ok && R.hdr[3] != 0) atomicAdd(C.cmp_out, 1);
+            return;
+        }
         if (ok) return;  // the warm-up reproduced it: everything behind stands
         if (R.hdr[3] == 0) return;  // (no state to start from: nothing to do)
         for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;

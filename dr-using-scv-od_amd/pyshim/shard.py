@@ -121,51 +121,82 @@ def plan_job_split(world, sequences, skip=1, warm=12):
     return out
 
 
-def resolve_chain_boundaries(dist, ctx, plan, rank, world, device):
-    """After every rank ran scvod_batch_track on its blocks + halos: a rank whose LAST piece ends inside a sequence sends the
-    state each chain of that piece ENDED in to the next rank, whose FIRST piece continues that sequence; the receiver compares
-    with what its warm-up assumed and walks again what differs (scvod_batch_track_resume), then passes its own end states on.
-    The ranks take their turn in order, so a correction cascades down a sequence like inside one shard; the states are a few
-    hundred KB and nothing else is exchanged.  plan: one entry of plan_job_split (or plan_split).  Returns the number of chains
-    this rank walked again."""
+def resolve_chain_boundaries(dist, ctx, plan, rank, world, device, group=None):
+    """After every rank ran scvod_batch_track on its blocks + halos: a rank whose LAST piece ends inside a sequence hands the
+    state each chain of that piece ENDED in to the next rank, whose FIRST piece continues that sequence.
+    Round 1, all ranks at once: everybody sends what it ended in and COMPARES what it received with what its warm-up assumed
+    (scvod_batch_track_compare: nothing changes); one all_gather of the verdicts.  Nobody differs (the usual case with a
+    halo of 12 steps): done -- one exchange, whatever the number of ranks.  Otherwise the ranks from the first one that
+    differs take their turn in order: resume from the received state (scvod_batch_track_resume: walked again where it
+    differs), send the new end state on -- a correction cascades down a sequence like inside one shard, and every rank
+    resumes at most once.  The records are a few hundred KB.  plan: one entry of plan_job_split (or plan_split).  group: the
+    process group the records travel on (bench.py hands a gloo group over beside RCCL: staged through the host, the path the
+    CPU tests cover).  Returns the number of chains this rank walked again."""
     import torch
     if world <= 1:
         return 0
     skip = plan["skip"]
     spans = plan.get("spans") or [dict(begin=0, end=len(plan["next_scan"]), lo=plan["lo"], cut_before=rank > 0, cut_behind=rank + 1 < world)]
-    on_dev = dist.get_backend() == "nccl"
+    on_dev = dist.get_backend(group) == "nccl"
     where = device if on_dev else "cpu"
     firsts = ctx.batch_track_chains()
+    recv_side = bool(rank > 0 and spans and spans[0]["cut_before"])
+    send_side = bool(rank + 1 < world and spans and spans[-1]["cut_behind"])
 
     def chains_of(span):  # {residue of the interleaved sub-sequence: chain index}
         return {(span["lo"] + int(f) - span["begin"]) % skip: c for c, f in enumerate(firsts) if span["begin"] <= int(f) < span["end"]}
 
-    rewalked = 0
-    if rank > 0 and spans and spans[0]["cut_before"]:  # what the rank before really ended in, one record per sub-sequence
+    def export():  # one record per sub-sequence (empty: none)
+        by_res = [torch.zeros(0, dtype=torch.uint8, device=where)] * skip
+        for res, c in chains_of(spans[-1]).items():
+            t = ctx.chain_export_state(c, 1)
+            by_res[res] = t if on_dev else t.cpu()
+        return by_res
+
+    def start_send(by_res):
+        sizes = torch.tensor([int(t.numel()) for t in by_res], dtype=torch.int64, device=where)
+        keep = [sizes] + by_res
+        return keep, [dist.isend(sizes, dst=rank + 1, group=group)] + [dist.isend(t, dst=rank + 1, group=group) for t in by_res if t.numel()]
+
+    def receive():
         sizes = torch.zeros(skip, dtype=torch.int64, device=where)
-        dist.recv(sizes, src=rank - 1)
+        dist.recv(sizes, src=rank - 1, group=group)
         recs = []
         for k in range(skip):
             t = torch.empty(int(sizes[k].item()), dtype=torch.uint8, device=where)
             if t.numel():
-                dist.recv(t, src=rank - 1)
+                dist.recv(t, src=rank - 1, group=group)
             recs.append(t)
-        before = ctx.batch_track_stats()["rewalked"]
         states = [None] * len(firsts)
         for res, c in chains_of(spans[0]).items():
             if recs[res].numel() >= 16:
                 states[c] = recs[res].to(device)
+        return states
+
+    # round 1: everybody at once
+    keep, works = start_send(export()) if send_side else (None, [])
+    states = receive() if recv_side else None
+    for w in works:
+        w.wait()
+    differs = ctx.batch_track_compare(states) if recv_side else 0
+    mine = torch.tensor([1 if differs else 0], dtype=torch.int64, device=where)
+    verdicts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(verdicts, mine, group=group)
+    bad = [r for r in range(world) if int(verdicts[r].item())]
+    if not bad or rank < bad[0]:
+        return 0
+    # from the first rank that differs: one after the other
+    rewalked = 0
+    if recv_side:
+        if rank > bad[0]:
+            states = receive()  # (what the rank before ends in NOW)
+        before = ctx.batch_track_stats()["rewalked"]
         ctx.batch_track_resume(states)
         rewalked = ctx.batch_track_stats()["rewalked"] - before
-    if rank + 1 < world and spans and spans[-1]["cut_behind"]:
-        by_res = [torch.zeros(0, dtype=torch.uint8)] * skip
-        for res, c in chains_of(spans[-1]).items():
-            by_res[res] = ctx.chain_export_state(c, 1)
-        sizes = torch.tensor([int(t.numel()) for t in by_res], dtype=torch.int64, device=where)
-        dist.send(sizes, dst=rank + 1)
-        for t in by_res:
-            if t.numel():
-                dist.send(t if on_dev else t.cpu(), dst=rank + 1)
+    if send_side:
+        keep, works = start_send(export())
+        for w in works:
+            w.wait()
     return rewalked
 
 

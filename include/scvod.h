@@ -315,7 +315,11 @@ int scvod_set_chain_capacity(scvod_ctx* ctx, int64_t pool_points);
  *                                 compared bit for bit with that snapshot; a chain whose warm-up did not reproduce it is walked
  *                                 again from the received state (and verified / walked on segment by segment, like inside one
  *                                 shard), then the per-point bytes are rebuilt.  scvod_batch_track_stats counts the checks and walks.
- * The result is the single-shard chain's, whatever the halo length. */
+ *   scvod_batch_track_compare     the comparison alone: *h_differ = chains whose warm-up did NOT reproduce the received record
+ *                                 (they would be walked again); nothing is changed.  Lets the shards of a job exchange their
+ *                                 end states all at once and fall back to one-after-the-other only behind the first shard
+ *                                 that reports a difference (pyshim/shard.py resolve_chain_boundaries).  Synchronises.
+ * The result is the single-shard chain's, whatever the halo length.  A shard resumes at most once per scvod_batch_track. */
 int scvod_set_track_owned(scvod_ctx* ctx, int32_t first_owned_scan);
 /* the same per scan (a shard that holds blocks of several sequences): h_is_halo[s] != 0 marks scan s as halo; a chain's halo
  * scans must be its first ones */
@@ -324,6 +328,7 @@ int scvod_batch_track_chains(scvod_ctx* ctx, int32_t* h_first_scan, int32_t cap)
 int64_t scvod_chain_state_bytes(scvod_ctx* ctx);
 int scvod_chain_export_state(scvod_ctx* ctx, int32_t chain, int32_t which, void* d_dst, int64_t cap_bytes, void* stream);
 int scvod_batch_track_resume(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, void* stream, int32_t sync);
+int scvod_batch_track_compare(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, int32_t* h_differ, void* stream);
 /* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
  * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.
  * Returns SCVOD_ERR_CAPACITY when a chain state did not fit the walkers' workspace (the result is then invalid). */

@@ -31,7 +31,7 @@ def _run(tmp, name, extra, backend="gloo"):
 
 def test_two_ranks_reproduce_the_single_rank_job(tmp_path):
     one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "24", "--sequences", "2"])
-    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "24", "--same-device"])
+    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "24", "--same-device", "--replicate"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2
     assert one["config"]["tracking_chain"]["chain"] and two["config"]["tracking_chain"]["chain"]
     assert np.array_equal(m1["scans"], m2["scans"]) and len(m1["scans"]) == 48
@@ -52,12 +52,15 @@ def test_rccl_leg_at_one_rank(tmp_path):
     assert plain["config"]["static_map_cells"] == rccl["config"]["static_map_cells"]
 
 
-def test_one_sequence_split_over_two_ranks(tmp_path):
-    """bench.py --split-sequence: one PARK sequence (one chain, stride 1) in two blocks on two gloo ranks of one device; a halo
-    of two steps cannot rebuild the carried clouds, so the second rank has to walk its chain again from the state the first
-    one sends -- and the per-scan results and the merged map are those of the single-rank run, bit for bit."""
+@pytest.mark.parametrize("halo", [2, 12])
+def test_one_sequence_split_over_two_ranks(tmp_path, halo):
+    """bench.py at N = 2 (one sequence is cut over the ranks by default): one PARK sequence (one chain, stride 1) in two blocks
+    on two gloo ranks of one device.  A halo of two steps cannot rebuild the carried clouds, so the second rank has to walk its
+    chain again from the state the first one sends (the one-after-the-other phase of resolve_chain_boundaries); with twelve the
+    warm-up reproduces it and the comparison round is all there is.  Either way the per-scan results and the merged map are
+    those of the single-rank run, bit for bit."""
     one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "60"])
-    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "60", "--same-device", "--split-sequence", "--split-halo", "2"])
+    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "60", "--same-device", "--split-halo", str(halo)])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["split"]["own"] == 30
     assert np.array_equal(m1["scans"], m2["scans"]) and len(m2["scans"]) == 60
     assert m1["dynamic_points"].sum() > 0
