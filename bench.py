@@ -267,7 +267,10 @@ def main():
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         after()
         if split and world > 1:  # the chain's state at the block boundaries: from rank to rank, walked again where the warm-up missed it
+            torch.cuda.synchronize()  # (the exchange starts when this rank's chain is done: its host time is the exchange's alone)
+            t_b = time.perf_counter()
             info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
+            info["boundary_ms"] = (time.perf_counter() - t_b) * 1e3
         if smap is not None:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -525,7 +528,7 @@ def main():
                           "tracking_stride": args.skip,
                           "sharding": (f"equal contiguous runs of the job's scans per rank (sequences are cut) + a halo of {args.split_halo} x {args.skip} scans in front of a cut; the tracking chain's state at a cut is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else
                                        "whole sequences per rank (longest first to the least loaded rank)"),
-                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary")} if split else None)},
+                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary"), "boundary_exchange_ms_rank0_last_step": info.get("boundary_ms")} if split else None)},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
         if multi:
