@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--skip", type=int, default=0, help="tracking stride: scan i is differenced against scan i + skip (0: the preset's config skip_, 5 in semantickitti.yaml, 1 in parkinglot.yaml)")
     ap.add_argument("--map-cells", type=int, default=0, help="capacity of the static map in cells (0: from the points)")
     ap.add_argument("--map-leaf", type=float, default=0.2)
-    ap.add_argument("--cpu-scans", type=int, default=64, help="bounded sample for the CPU baseline and the PR/RR check")
+    ap.add_argument("--cpu-scans", type=int, default=320, help="bounded sample for the CPU baseline and the PR/RR check")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the multi-threaded CPU context number")
     ap.add_argument("--no-quality", action="store_true", help="skip the PR/RR comparison")
