@@ -214,6 +214,50 @@ __device__ __forceinline__ void copy_state(const Wk& A, int src, const Wk& B, in
 }
 
 // bit-for-bit comparison of two states (all threads); returns true when they are equal
+// The carried points of two states whose entries are equal: the same points PER ENTRY, in any order.  An entry's carried cloud is
+// the concatenation of what its predecessors appended, block after block in the order of the links that fed it -- which depends
+// on where a walk started (a fresh state lists the clusters in segmentation order, a state with a history has the created ones
+// behind them), while nothing that reads the cloud depends on its order: every point is transformed on its own and marks the
+// voxel it falls into (a bit set), and the cloud is copied on as a whole.  Compared as two 64-bit sums of mixed coordinate bits
+// per entry (a multiset signature; the bit-for-bit comparison of rounds 3-4a made every shard boundary look different although
+// the walk behind it was the same, and cost in-GPU segments a second walk now and then).
+__device__ __forceinline__ unsigned long long pool_mix(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+__device__ __forceinline__ int pools_differ(const int4* ent, int ne, int nc, const float4* pa, const float4* pb) {
+    int diff = 0;
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x >> 6; e < ne; e += kChThreads / 64) {
+        const int4 r = ent[2 * e];
+        const int off = r.z, cnt = r.w;
+        if (cnt <= 0 || off < 0 || off + cnt > nc) continue;
+        unsigned long long a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+        for (int i = lane; i < cnt; i += 64) {
+            const float4 x = pa[off + i], y = pb[off + i];
+            const unsigned long long kx = (unsigned long long)__float_as_uint(x.x) | ((unsigned long long)__float_as_uint(x.y) << 32);
+            const unsigned long long ky = (unsigned long long)__float_as_uint(y.x) | ((unsigned long long)__float_as_uint(y.y) << 32);
+            const unsigned long long zx = __float_as_uint(x.z), zy = __float_as_uint(y.z);
+            a1 += pool_mix(kx ^ (zx * 0x9e3779b97f4a7c15ull));
+            a2 += pool_mix(kx * 0xc2b2ae3d27d4eb4full + zx + 1ull);
+            b1 += pool_mix(ky ^ (zy * 0x9e3779b97f4a7c15ull));
+            b2 += pool_mix(ky * 0xc2b2ae3d27d4eb4full + zy + 1ull);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            a1 += __shfl_xor(a1, d);
+            a2 += __shfl_xor(a2, d);
+            b1 += __shfl_xor(b1, d);
+            b2 += __shfl_xor(b2, d);
+        }
+        diff |= (a1 != b1) | (a2 != b2);
+    }
+    return diff;
+}
 __device__ __forceinline__ bool same_state(const Wk& A, int sa, const Wk& B, int sb) {
     const int ne = A.hdr[H_NENT + sa], nc = A.hdr[H_NCARRIED + sa], np = A.hdr[H_NPARTS + sa];
     int diff = (ne != B.hdr[H_NENT + sb]) || (nc != B.hdr[H_NCARRIED + sb]) || (np != B.hdr[H_NPARTS + sb]);
@@ -223,11 +267,7 @@ __device__ __forceinline__ bool same_state(const Wk& A, int sa, const Wk& B, int
             diff |= (int)(x.x != y.x) | (int)(x.y != y.y) | (int)(x.z != y.z) | (int)(x.w != y.w);
         }
         for (int i = threadIdx.x; i < np; i += kChThreads) diff |= A.parts[sa][i] != B.parts[sb][i];
-        for (int i = threadIdx.x; i < nc; i += kChThreads) {
-            const float4 x = A.pool[sa][i], y = B.pool[sb][i];
-            diff |= (int)(__float_as_uint(x.x) != __float_as_uint(y.x)) | (int)(__float_as_uint(x.y) != __float_as_uint(y.y)) |
-                    (int)(__float_as_uint(x.z) != __float_as_uint(y.z));
-        }
+        diff |= pools_differ(A.ent[sa], ne, nc, A.pool[sa], B.pool[sb]);
     }
     return __syncthreads_or(diff) == 0;
 }
@@ -257,11 +297,7 @@ __device__ __forceinline__ bool same_state_ext(const Wk& A, int sa, const ExtRec
             diff |= (int)(x.x != y.x) | (int)(x.y != y.y) | (int)(x.z != y.z) | (int)(x.w != y.w);
         }
         for (int i = threadIdx.x; i < np; i += kChThreads) diff |= A.parts[sa][i] != B.parts[i];
-        for (int i = threadIdx.x; i < nc; i += kChThreads) {
-            const float4 x = A.pool[sa][i], y = B.pool[i];
-            diff |= (int)(__float_as_uint(x.x) != __float_as_uint(y.x)) | (int)(__float_as_uint(x.y) != __float_as_uint(y.y)) |
-                    (int)(__float_as_uint(x.z) != __float_as_uint(y.z));
-        }
+        diff |= pools_differ(A.ent[sa], ne, nc, A.pool[sa], B.pool);
     }
     return __syncthreads_or(diff) == 0;
 }

@@ -312,7 +312,8 @@ int scvod_set_chain_capacity(scvod_ctx* ctx, int64_t pool_points);
  *   scvod_chain_export_state      which = 1: the state chain k ENDED in (a device buffer: send it to the shard that owns the next
  *                                 block); which = 0: the state the chain assumed at its first own step (its warm-up's snapshot)
  *   scvod_batch_track_resume      h_d_states[k] = device pointer of the record the previous shard sent for chain k (NULL: none):
- *                                 compared bit for bit with that snapshot; a chain whose warm-up did not reproduce it is walked
+ *                                 compared with that snapshot (entries and parts bit for bit, the carried points per entry as a
+ *                                 multiset: their order depends on where a walk started and nothing reads it); a chain whose warm-up did not reproduce it is walked
  *                                 again from the received state (and verified / walked on segment by segment, like inside one
  *                                 shard), then the per-point bytes are rebuilt.  scvod_batch_track_stats counts the checks and walks.
  *   scvod_batch_track_compare     the comparison alone: *h_differ = chains whose warm-up did NOT reproduce the received record

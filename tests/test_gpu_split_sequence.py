@@ -62,6 +62,10 @@ def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
     firsts_b = B.batch_track_chains()
     before = [B.batch_fetch_track(s - lo)["pt_dyn"] for s in range(cut, count)]
     st0 = B.batch_track_stats()
+    differs = B.batch_track_compare([end[(lo + int(f)) % skip] for f in firsts_b])  # the comparison alone: nothing changes
+    assert (differs > 0) == (halo_steps == 1) and B.batch_track_stats() == st0
+    for s in range(cut, count):
+        assert np.array_equal(B.batch_fetch_track(s - lo)["pt_dyn"], before[s - cut])
     B.batch_track_resume([end[(lo + int(f)) % skip] for f in firsts_b])
     st1 = B.batch_track_stats()
     assert st1["error_bits"] == 0 and st1["verified"] == st0["verified"] + skip  # every sub-sequence's boundary was compared
@@ -75,3 +79,47 @@ def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
     else:
         assert differ_before == 0  # (a full warm-up reproduces the state on this sequence: nothing to walk again ...)
     B.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_three_shards_with_random_cuts_and_halos(scvod, seed):
+    """a PARK sequence (one chain, stride 1) over three shards with random cut points and halo lengths: the protocol of
+    pyshim/shard.py resolve_chain_boundaries by hand -- every shard compares the state the shard before ended in FIRST
+    (tentative: before that shard resumed); from the first shard that reports a difference on, the shards resume one after
+    the other with the state their predecessor ends in NOW.  The per-point bytes are the unsplit run's."""
+    import synth
+    import torch
+    rng = np.random.default_rng(seed)
+    P = scvod.make_params("parkinglot")
+    skip, count = 1, 150
+    scans = [synth.make_scan(3, 20 + k, "PARK", device="cuda") for k in range(count)]
+    d = torch.cat([sc[0] for sc in scans]).contiguous()
+    offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int64)
+    poses = np.asarray([sc[2] for sc in scans], np.float32)
+    whole = _tracked(scvod, P, d, offs, poses, 0, count, skip)
+    want = [whole.batch_fetch_track(s)["pt_dyn"] for s in range(count)]
+    assert sum(int(w.sum()) for w in want) > 0
+    whole.close()
+    c1 = int(rng.integers(35, 60))
+    c2 = int(rng.integers(c1 + 30, 120))
+    cuts = [0, c1, c2, count]
+    halos = [0, int(rng.integers(1, 13)), int(rng.integers(1, 13))]
+    shards = []
+    for k in range(3):
+        lo = max(cuts[k] - halos[k] * skip, 0)
+        hi = min(cuts[k + 1] + skip, count)
+        shards.append((lo, _tracked(scvod, P, d, offs, poses, lo, hi, skip, owned_first=cuts[k] - lo)))
+    ends = [sh.chain_export_state(0, 1) for _, sh in shards]  # tentative end states, all at once
+    differs = [0] + [shards[k][1].batch_track_compare([ends[k - 1]]) for k in (1, 2)]
+    bad = [k for k in range(3) if differs[k]]
+    if bad:
+        for k in range(bad[0], 3):
+            state = ends[k - 1] if k == bad[0] else shards[k - 1][1].chain_export_state(0, 1)
+            shards[k][1].batch_track_resume([state])
+            assert shards[k][1].batch_track_stats()["error_bits"] == 0
+    for k in range(3):
+        lo, sh = shards[k]
+        for s in range(cuts[k], cuts[k + 1]):
+            got = sh.batch_fetch_track(s - lo)["pt_dyn"]
+            assert np.array_equal(got, want[s]), (seed, cuts, halos, differs, k, s, int((got != want[s]).sum()))
+        sh.close()
