@@ -229,10 +229,63 @@ __device__ __forceinline__ unsigned long long pool_mix(unsigned long long k) {
     k ^= k >> 33;
     return k;
 }
+constexpr int kPdEnt = 512;   // entries whose offsets pools_differ keeps in LDS
 __device__ __forceinline__ int pools_differ(const int4* ent, int ne, int nc, const float4* pa, const float4* pb) {
     int diff = 0;
-    const int lane = threadIdx.x & 63;
-    for (int e = threadIdx.x >> 6; e < ne; e += kChThreads / 64) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (nc <= 0) return 0;
+    if (ne <= kPdEnt) {
+        // flat over the points: the entry a point belongs to (offsets ascend with the entry index) salts its hash, so ONE pair of sums
+        // per state stands for all the per-entry multisets
+        __shared__ int32_t pd_off[kPdEnt + 1];
+        __shared__ unsigned long long pd_sum[kChThreads / 64][4];
+        __syncthreads();  // (the arrays may still be read by a previous call)
+        for (int e = threadIdx.x; e < ne; e += kChThreads) pd_off[e] = ent[2 * e].z;
+        if (threadIdx.x == 0) pd_off[ne] = nc;
+        __syncthreads();
+        unsigned long long a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+        for (int i = threadIdx.x; i < nc; i += kChThreads) {
+            const float4 x = pa[i], y = pb[i];
+            int lo = 0, hi = ne;  // the last entry whose offset is <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (pd_off[mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const unsigned long long salt = pool_mix((unsigned long long)lo + 0x51ull);
+            const unsigned long long kx = (unsigned long long)__float_as_uint(x.x) | ((unsigned long long)__float_as_uint(x.y) << 32);
+            const unsigned long long ky = (unsigned long long)__float_as_uint(y.x) | ((unsigned long long)__float_as_uint(y.y) << 32);
+            const unsigned long long zx = __float_as_uint(x.z), zy = __float_as_uint(y.z);
+            a1 += pool_mix(kx ^ (zx * 0x9e3779b97f4a7c15ull) ^ salt);
+            a2 += pool_mix((kx + salt) * 0xc2b2ae3d27d4eb4full + zx + 1ull);
+            b1 += pool_mix(ky ^ (zy * 0x9e3779b97f4a7c15ull) ^ salt);
+            b2 += pool_mix((ky + salt) * 0xc2b2ae3d27d4eb4full + zy + 1ull);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            a1 += __shfl_xor(a1, d);
+            a2 += __shfl_xor(a2, d);
+            b1 += __shfl_xor(b1, d);
+            b2 += __shfl_xor(b2, d);
+        }
+        if (lane == 0) {
+            pd_sum[wave][0] = a1;
+            pd_sum[wave][1] = a2;
+            pd_sum[wave][2] = b1;
+            pd_sum[wave][3] = b2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t[4] = {0, 0, 0, 0};
+            for (int w = 0; w < kChThreads / 64; ++w)
+                for (int k = 0; k < 4; ++k) t[k] += pd_sum[w][k];
+            diff = (t[0] != t[2]) | (t[1] != t[3]);
+        }
+        return diff;
+    }
+    for (int e = wave; e < ne; e += kChThreads / 64) {
         const int4 r = ent[2 * e];
         const int off = r.z, cnt = r.w;
         if (cnt <= 0 || off < 0 || off + cnt > nc) continue;
