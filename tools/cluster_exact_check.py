@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """How often does the bounded visiting-order model of the generic clustering variant (scans beyond the LDS tables, OS128 class)
-change a partition?  Clusters the same scans with and without scvod_set_cluster_exact and counts differing points.
+change a partition, and does the local rule (cc_run_is_plain) ever?  Clusters the same scans in the three modes of
+scvod_set_cluster_exact -- 0: rule + components up to 4096 nodes (default), 1: rule + components of any size, 2: no rule, every
+component with an irregular run (the visiting-order model itself, checked against the oracle by the tests) -- and counts the
+points whose cluster differs from mode 2's.
 usage: python tools/cluster_exact_check.py [--kind OS128] [--preset os128_fine] [--scans 64] [--first 0] [--stride 5]"""
 import argparse
 import os
@@ -35,19 +38,21 @@ def main():
     ctx.batch_process(pts, offs)
     cnt = ctx.batch_counts()
     out = {}
-    for exact in (False, True):
-        ctx.set_cluster_exact(exact)
+    for mode in (0, 1, 2):
+        ctx.set_cluster_exact(mode)
         ctx.batch_cluster()
         st = ctx.batch_cluster_stats()
-        out[exact] = ([ctx.batch_fetch_clusters(s, int(cnt[s, 4])) for s in range(a.scans)], st)
-    differ = scans_differ = total = 0
-    for s in range(a.scans):
-        d = int((out[False][0][s] != out[True][0][s]).sum())
-        differ += d
-        scans_differ += d > 0
-        total += len(out[True][0][s])
-    print(f"{a.kind} {a.preset}: {a.scans} scans, {total} binned points; bounded model: {out[False][1]}; exact: {out[True][1]}")
-    print(f"points whose cluster name differs between the two: {differ} in {scans_differ} scans")
+        out[mode] = ([ctx.batch_fetch_clusters(s, int(cnt[s, 4])) for s in range(a.scans)], st)
+    total = sum(len(x) for x in out[2][0])
+    print(f"{a.kind} {a.preset}: {a.scans} scans, {total} binned points")
+    for mode in (0, 1):
+        differ = scans_differ = 0
+        for s in range(a.scans):
+            d = int((out[mode][0][s] != out[2][0][s]).sum())
+            differ += d
+            scans_differ += d > 0
+        print(f"mode {mode}: {out[mode][1]}\n   points whose cluster name differs from mode 2's: {differ} in {scans_differ} scans")
+    print(f"mode 2: {out[2][1]}")
 
 
 if __name__ == "__main__":
