@@ -379,6 +379,10 @@ def main():
         t_cells = torch.tensor([pmap.count()], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(t_cells)
         map_cells = int(t_cells.item())
+    if split and multi:  # chains walked again at a block boundary, all ranks, all steps of this run
+        t_rw = torch.tensor([info.get("chains_rewalked_at_boundary", 0)], dtype=torch.int64, device=dev if args.backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(t_rw)
+        info["chains_rewalked_all_ranks"] = int(t_rw.item())
     if args.dump_map:
         own_idx = [s for f0, c0 in own_spans for s in range(f0, f0 + c0)]
         dynpts = np.array([ctx.batch_fetch_track(s)["n_dynamic_points"] for s in own_idx], np.int64)
@@ -528,7 +532,7 @@ def main():
                           "tracking_stride": args.skip,
                           "sharding": (f"equal contiguous runs of the job's scans per rank (sequences are cut) + a halo of {args.split_halo} x {args.skip} scans in front of a cut; the tracking chain's state at a cut is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else
                                        "whole sequences per rank (longest first to the least loaded rank)"),
-                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary"), "boundary_exchange_ms_rank0_last_step": info.get("boundary_ms")} if split else None)},
+                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary"), "chains_rewalked_at_boundary_all_ranks": info.get("chains_rewalked_all_ranks"), "boundary_exchange_ms_rank0_last_step": info.get("boundary_ms")} if split else None)},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
         if multi:

@@ -79,3 +79,16 @@ def test_two_sequences_cut_over_three_ranks(tmp_path):
     assert m1["dynamic_points"].sum() > 0
     assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
     assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])
+
+
+def test_k64_sequence_over_two_ranks_with_the_default_halo(tmp_path):
+    """the KITTI stride (five interleaved chains) cut in two with the default halo of 12 steps: the warm-up reproduces every
+    chain's boundary state (nothing is walked again: the ranks' comparison round is the whole exchange) and the job equals
+    the one-rank run"""
+    one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "170", "--kind", "K64", "--preset", "semantickitti"])
+    two, m2 = _run(str(tmp_path), "two", ["--gpus", "2", "--scans", "170", "--kind", "K64", "--preset", "semantickitti", "--same-device"])
+    assert two["scaling"] == "strong" and two["config"]["split"]["chains_rewalked_at_boundary_all_ranks"] == 0
+    assert np.array_equal(m1["scans"], m2["scans"]) and len(m2["scans"]) == 170
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
+    assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])
