@@ -528,6 +528,8 @@ def main():
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
                           "static_map_cells": map_cells, "static_map_table_cells": info.get("map_table_cells", (cells if smap is not None else None)), "tracking": args.track_mode, "tracking_chain": chain_stats, "clustering": cluster_stats, "max_name": max_name_stats,
+                          "memory_GB_rank0": {"input_points": round(float(pts.numel() * 4) / 1e9, 2), "arena": round(ctx.arena_bytes() / 1e9, 2), "chain_workspace": round(ctx.chain_workspace_bytes() / 1e9, 2),
+                                              "process_peak_on_device": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9, 2)},
                           "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                           "tracking_stride": args.skip,
                           "sharding": (f"equal contiguous runs of the job's scans per rank (sequences are cut) + a halo of {args.split_halo} x {args.skip} scans in front of a cut; the tracking chain's state at a cut is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else

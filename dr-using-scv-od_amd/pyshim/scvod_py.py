@@ -508,6 +508,10 @@ class Ctx:
     def arena_bytes(self):
         return int(self.lib.scvod_arena_bytes(self.h))
 
+    def chain_workspace_bytes(self):
+        """the tracking chain's walker workspace of the last job (not part of arena_bytes)"""
+        return int(self.lib.scvod_chain_workspace_bytes(self.h))
+
     def nn_search_device(self, d_map_xyz, d_query_xyz, radius, stream=None):
         """torch CUDA tensors [n, 3] float32 in, (idx int32, sqdist float32, within uint8) CUDA tensors out."""
         import torch
