@@ -416,6 +416,23 @@ class Ctx:
         used = 16 + 32 * int(hdr[0]) + ((4 * int(hdr[2]) + 15) // 16) * 16 + 16 * int(hdr[1])
         return buf[:max(used, 16)].clone()
 
+    def chain_export_states(self, chains, which, stream=None):
+        """chain_export_state for several chains: the export kernels back to back, ONE synchronisation, one copy of the headers"""
+        import torch
+        chains = [int(c) for c in chains]
+        if not chains:
+            return []
+        nb = int(self.lib.scvod_chain_state_bytes(self.h))
+        big = torch.empty((len(chains), nb), dtype=torch.uint8, device=f"cuda:{self.device}")
+        for k, c in enumerate(chains):
+            self._chk(self.lib.scvod_chain_export_state(self.h, c, int(which), C.c_void_p(big[k].data_ptr()), nb, C.c_void_p(stream or 0)))
+        hdr = big[:, :16].contiguous().view(torch.int32).cpu().numpy().reshape(len(chains), 4)  # (synchronises)
+        out = []
+        for k in range(len(chains)):
+            used = 16 + 32 * int(hdr[k, 0]) + ((4 * int(hdr[k, 2]) + 15) // 16) * 16 + 16 * int(hdr[k, 1])
+            out.append(big[k, :max(used, 16)])
+        return out
+
     def batch_track_resume(self, states, stream=None):
         """states[k]: the record the shard before this one exported (which=1) for chain k, or None"""
         self._resume_keep = states

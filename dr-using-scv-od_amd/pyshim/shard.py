@@ -148,9 +148,9 @@ def resolve_chain_boundaries(dist, ctx, plan, rank, world, device, group=None):
 
     def export():  # one record per sub-sequence (empty: none)
         by_res = [torch.zeros(0, dtype=torch.uint8, device=where)] * skip
-        for res, c in chains_of(spans[-1]).items():
-            t = ctx.chain_export_state(c, 1)
-            by_res[res] = t if on_dev else t.cpu()
+        of = sorted(chains_of(spans[-1]).items())
+        for (res, c), t in zip(of, ctx.chain_export_states([c for _, c in of], 1)):
+            by_res[res] = t.contiguous() if on_dev else t.cpu()
         return by_res
 
     def start_send(by_res):

@@ -44,7 +44,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         firsts = ctx.batch_track_chains()
-        ends = [ctx.chain_export_state(c, 1) for c in range(len(firsts))]
+        ends = ctx.chain_export_states(range(len(firsts)), 1)
         t1 = time.perf_counter()
         host = [e.cpu() for e in ends]
         t2 = time.perf_counter()
