@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 
-def measure(scvod_py, P, d_pts, offs, poses, device, scans=2048, chunk=512, skip=5):
+def measure(scvod_py, P, d_pts, offs, poses, device, scans=2048, chunk=256, skip=5):
     import torch
     n_sc = min(int(scans), len(offs) - 1)
     o = np.ascontiguousarray(offs[: n_sc + 1], np.int32)
