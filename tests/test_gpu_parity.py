@@ -540,6 +540,71 @@ def test_tracking_chain_equals_the_reference_chain(scvod, oracle, kind, preset, 
     ctx.close()
 
 
+def _box_points(rng, cx, cy, yaw, l, w, h, n, z0=-1.7):
+    u = rng.random((n, 3))
+    face = rng.integers(0, 3, n)
+    p = np.empty((n, 3))
+    p[:, 0] = (u[:, 0] - 0.5) * l; p[:, 1] = (u[:, 1] - 0.5) * w; p[:, 2] = u[:, 2] * h
+    s = rng.random(n) < 0.5
+    p[face == 0, 0] = np.where(s[face == 0], l / 2, -l / 2)
+    p[face == 1, 1] = np.where(s[face == 1], w / 2, -w / 2)
+    p[face == 2, 2] = h
+    c, sn = np.cos(yaw), np.sin(yaw)
+    return np.stack([cx + c * p[:, 0] - sn * p[:, 1], cy + sn * p[:, 0] + c * p[:, 1], z0 + p[:, 2]], 1)
+
+def _crowded_sequence(seed, frames):
+    rng = np.random.default_rng(seed)
+    K = int(rng.integers(25, 60))
+    pos = rng.uniform(-28, 28, (K, 2)); pos[np.hypot(pos[:, 0], pos[:, 1]) < 5] += 8
+    vel = rng.normal(0, 0.6, (K, 2)) * (rng.random((K, 1)) < 0.6)      # 40 % parked
+    yaw = rng.uniform(0, np.pi, K); size = np.stack([rng.uniform(3.5, 4.8, K), rng.uniform(1.6, 2.0, K), rng.uniform(1.3, 1.8, K)], 1)
+    dens = rng.integers(150, 500, K)
+    scans, poses = [], []
+    for f in range(frames):
+        g = int(rng.integers(15000, 25000)); r = rng.uniform(3, 45, g) ** 1.0; th = rng.uniform(0, 2 * np.pi, g)
+        pts = [np.stack([r * np.cos(th), r * np.sin(th), -1.73 + rng.normal(0, 0.02, g)], 1)]
+        for k in range(K):
+            if rng.random() < 0.08: continue                                  # drops out of a frame now and then
+            pts.append(_box_points(rng, pos[k, 0], pos[k, 1], yaw[k], *size[k], int(dens[k] * rng.uniform(0.6, 1.2))))
+        x = np.concatenate(pts); x = np.concatenate([x, rng.uniform(0, 255, (len(x), 1))], 1).astype(np.float32)
+        scans.append(x[rng.permutation(len(x))]); poses.append([0, 0, 0, 0, 0, 0])
+        pos += vel
+        att = rng.random(K) < 0.15                                            # some drift towards a neighbour: they touch, fuse, part again
+        for k in np.nonzero(att)[0]:
+            j = int(np.argmin(np.hypot(*(pos - pos[k]).T) + (np.arange(K) == k) * 1e9)); pos[k] += 0.25 * (pos[j] - pos[k])
+    return scans, np.asarray(poses, np.float32)
+
+
+@pytest.mark.parametrize("seed,preset", [(7001, "semantickitti"), (7004, "parkinglot")])
+def test_tracking_chain_on_crowded_random_scenes(scvod, oracle, seed, preset):
+    """25-60 car-sized boxes on a ground disc, 60 % of them moving, some drifting into a neighbour (they touch, fuse, part
+    again), each missing from a frame now and then, points in random order: splits, fusions, re-used max_name, clouds that keep
+    growing -- in the crowded scenes most segments fail their verification and are walked again.  The per-point bytes are
+    the literal oracle chain's, with the job's own segments and with short ones."""
+    import torch
+    frames = 50
+    scans, poses = _crowded_sequence(seed, frames)
+    P = _params(scvod, preset)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=frames)
+    ctx.batch_process(torch.from_numpy(np.concatenate(scans)).cuda(), offs)
+    ctx.batch_cluster()
+    ctx.batch_cluster_types()
+    res = [ctx.batch_fetch(s) for s in range(frames)]
+    names = [ctx.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(frames)]
+    types = [ctx.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(frames)]
+    T = np.zeros((frames, 12), np.float32)
+    for s in range(frames - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    for seg, warm in ((0, -1), (5, 3)):
+        ctx.set_track_mode(chain=True, segment_steps=seg, warmup_steps=warm)
+        ctx.batch_track(T)
+        assert ctx.batch_track_stats()["error_bits"] == 0
+        dyn, nd = _assert_chain_equal(ctx, oracle, P, res, names, types, poses)
+        assert nd > 20
+    ctx.close()
+
+
 def test_tracking_chain_of_interleaved_subsequences(scvod, oracle):
     """bench.py's layout: consecutive scans in the batch, scan i tracked against scan i + skip -- `skip` interleaved chains in
     one call.  Every sub-sequence must come out as if it had been tracked on its own."""
