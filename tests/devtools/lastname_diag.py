@@ -1,7 +1,7 @@
 """per-scan outcome of csrc/scvod_lastname.hip next to the oracle's literal loop (run on the GPU box)"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (under tests/: the oracle is test infrastructure)
 sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py, scvod_py, synth, torch
 kind, preset, first, stride, count = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])

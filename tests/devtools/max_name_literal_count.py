@@ -1,14 +1,14 @@
 """How many per-point labels does the reference's literal `max_name` (ssc.cpp:354 stores the LAST USED running number, so the
 first split-off / fused cluster of every frame re-uses it: ssc.cpp:1357, 1401, no-op insert at 1372 / 1419) move, against a
 chain that hands out fresh numbers?  Device segmentation, oracle chains.  Run on the GPU box:
-    python tools/max_name_literal_count.py [K64|PARK|OS128 ...]"""
+    python tests/devtools/max_name_literal_count.py [K64|PARK|OS128 ...]"""
 import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (under tests/: the oracle is test infrastructure)
 sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py
