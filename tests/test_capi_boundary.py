@@ -73,7 +73,7 @@ def test_no_cpu_fallback(scvod):
 
 def test_product_does_not_reference_the_oracle():
     bad = []
-    for base in ("dr-using-scv-od_amd", "include"):
+    for base in ("dr-using-scv-od_amd", "include", "tools"):  # (development tools that need the checker live under tests/devtools)
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
                 if f.endswith((".so", ".pyc", ".o")):
