@@ -3,10 +3,13 @@
 
 Workload at one GPU (BASELINE.json configs[1]): a SemanticKITTI-seq-05-shaped sequence -- 2761 scans of a 64-beam sensor,
 ~118 k returns per scan, config/semantickitti.yaml parameters -- synthetic (no dataset exists in this environment),
-resident in HBM before the timed region starts.  With N GPUs (configs[3]): N such sequences (seeded like seq 05, 00, 02,
-08, ...), one per rank -- weak scaling.  The unit of sharding is the SEQUENCE: the reference tracks frame i against frame
-i + 1 in order and every call mutates the successor (SSC::segDF, ssc.cpp:1449-1451), a chain the device replays exactly
-and that therefore stays on one rank (pyshim/shard.py).
+resident in HBM before the timed region starts.  With N GPUs the SAME job is cut over the ranks (strong scaling, the
+default): the scans of the sequence in N contiguous blocks, each with a halo of 12 x skip_ scans in front for the warm-up
+of the tracking chain (pyshim/shard.py plan_split / plan_job_split).  The reference tracks frame i against frame i + 1 in
+order and every call mutates the successor (SSC::segDF, ssc.cpp:1449-1451): the chain's state at a cut is exported by the
+rank before, compared with what the halo's warm-up produced and walked again only where it differs.  `--kitti
+--split-sequence` is configs[3] (seq 00-10 at their real lengths, `--kitti-scale a/b` shrinks every sequence for a dry
+run); `--replicate` / `--sequences K` deal whole sequences to the ranks instead (weak scaling, no tracking data crosses).
 
 One "step" = one pass of the whole path over the rank's scans, raw points in, per-point dynamic/static labels and the
 static map out, everything on the device through the C-ABI (libscvod.so):
@@ -14,10 +17,14 @@ static map out, everything on the device through the C-ABI (libscvod.so):
     -> curved-voxel clustering -> bounding boxes + type rules                             scvod_batch_cluster(_types)
     -> scan-vs-next-scan differencing: probe, remap_name, state rule, the reference's     scvod_batch_track
        SEQUENTIAL re-labelling chain (scan i against scan i + skip_), per-point byte
+    -> (N > 1, a sequence cut over ranks) the chain states at the cuts: one exchange,     shard.resolve_chain_boundaries
+       compared on the device; a rank walks its chains again only if the verdict says so
     -> world-frame static map of the rank's scans                                         scvod_batch_map_accumulate
     -> (N > 1) the map reduce-scattered over RCCL: records grouped by owner rank in       scvod_map_export_parts_padded,
        equal padded slots, ONE all_to_all_single, every rank merges the cells it owns     scvod_map_merge
-No host synchronisation inside a step, at any N.  value = scans of all ranks / max-over-ranks time.
+At N = 1 there is no host synchronisation inside a step.  At N > 1 the boundary exchange reads ONE verdict word per step on
+the host (does any rank have to walk a chain again?); everything else stays on the stream.
+value = scans of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline      HBM roofline: algorithmic bytes of the path over the measured step time; the dominant kernel
@@ -135,6 +142,7 @@ def main():
     ap.add_argument("--split-sequence", action="store_true", help="strong scaling: ONE sequence of --scans scans over the ranks (contiguous blocks, a halo of 12 x skip scans for the tracking chain's warm-up, the chain's state handed from rank to rank: pyshim/shard.py plan_split)")
     ap.add_argument("--replicate", action="store_true", help="N > 1: every rank runs a sequence of its own (weak scaling: rounds 1-3) instead of cutting ONE sequence over the ranks (the default at N > 1)")
     ap.add_argument("--kitti", action="store_true", help="the job is SemanticKITTI seq 00-10 at their real lengths (BASELINE configs[3], 23 201 scans: needs the memory of several GPUs); with --split-sequence the sequences are cut where the load says")
+    ap.add_argument("--kitti-scale", default="1", help="with --kitti: every sequence length times this fraction (e.g. 1/32: a dry run of configs[3]'s 11-sequence plan that fits one GPU)")
     ap.add_argument("--split-halo", type=int, default=12, help="warm-up steps of the halo in front of a rank's block (--split-sequence)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short PARK / OS128 sub-runs that the default invocation appends under extras.configs")
     ap.add_argument("--no-map", action="store_true", help="leave the static map out of the step (profiling)")
@@ -178,9 +186,6 @@ def main():
     # N > 1: the path shards the scans of ONE sequence (BASELINE north_star: strong scaling of configs[1]) unless told otherwise
     if world > 1 and not args.replicate and not args.sequences and not args.kitti:
         args.split_sequence = True
-    side = None
-    if dist is not None and world > 1 and args.split_sequence and args.backend == "nccl":
-        side = dist.new_group(backend="gloo")  # the chain's boundary records (a few hundred KB, staged through the host)
     multi = dist is not None  # the N > 1 step (also at one rank with --force-dist: RCCL initialised, device collectives executed)
     import scvod_py
     import shard
@@ -192,7 +197,8 @@ def main():
     job = shard.weak_scaling_sequences(args.sequences or world, args.scans)
     split = None
     if args.kitti:  # BASELINE configs[3]: seq 00-10 at their real lengths
-        job = shard.kitti_sequences(synth.SEQ_LEN)
+        num, _, den = args.kitti_scale.partition("/")
+        job = shard.kitti_sequences(synth.SEQ_LEN, scale=float(num) / float(den or 1))
     if args.split_sequence:  # the job's scans, sequence after sequence, in equal contiguous runs: sequences are CUT (+ halo) where the load says
         if not args.kitti:
             job = shard.weak_scaling_sequences(args.sequences or 1, args.scans)
@@ -254,10 +260,59 @@ def main():
             a[0] += ms
             a[1] += 1
 
+    devb = None  # the chain states at the cuts on the device (RCCL); None: host-staged protocol (gloo dry runs) or nothing to exchange
+
+    def map_part(timed=False):
+        if smap is None:
+            return
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        smap.clear(stream=stream)
+        for f0, c0 in own_spans:  # (a rank adds its OWN scans: a halo belongs to the rank before)
+            smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
+        if timed:
+            e1.record()
+            e1.synchronize()
+            a = kt.setdefault("map_accumulate", [0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+        if multi:  # reduce-scatter of the map: equal padded slots, one all-to-all, no size on the host
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+            if timed:
+                ev[0].record()
+            smap.export_parts_padded(world, part_send, stream=stream)
+            pmap.clear(stream=stream)
+            if timed:
+                ev[1].record()
+            got = shard.reduce_scatter_map(dist, part_send, part_recv)
+            if timed:
+                ev[2].record()
+            pmap.merge(got, stream=stream)
+            if timed:
+                ev[3].record()
+                ev[3].synchronize()
+                for name, i in (("map_export_parts", 0), ("map_all_to_all", 1), ("map_merge", 2)):
+                    a = kt.setdefault(name, [0.0, 0])
+                    a[0] += ev[i].elapsed_time(ev[i + 1])
+                    a[1] += 1
+
+    def check_boundary():
+        """the verdict of the LAST step's boundary exchange (device path): read when that step has been enqueued; != 0 (rare: a warm-up
+        missed the state at a cut, or a state outgrew its record) -> the host-driven protocol walks those chains again and the
+        step's map is accumulated once more from the corrected labels"""
+        if devb is None or not devb.pending:
+            return
+        if devb.verdict_wait() != 0:
+            info["boundary_slow_path_steps"] = info.get("boundary_slow_path_steps", 0) + 1
+            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            map_part(False)
+
     def step(timed=False):
         def after():
             if timed:
                 collect()
+        check_boundary()
         ctx.batch_process(pts, offs, stream=stream, sync=False)
         after()
         ctx.batch_cluster(stream=stream, sync=False)
@@ -266,59 +321,51 @@ def main():
         after()
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
         after()
-        if split and world > 1:  # the chain's state at the block boundaries: from rank to rank, walked again where the warm-up missed it
-            torch.cuda.synchronize()  # (the exchange starts when this rank's chain is done: its host time is the exchange's alone)
-            t_b = time.perf_counter()
-            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
-            info["boundary_ms"] = (time.perf_counter() - t_b) * 1e3
-        if smap is not None:
+        if devb is not None:  # the chain's state at the cuts: exported, exchanged and compared on the device, nothing read here
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            smap.clear(stream=stream)
-            for f0, c0 in own_spans:  # (a rank adds its OWN scans: a halo belongs to the rank before)
-                smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
+            devb.exchange(stream)
             if timed:
                 e1.record()
                 e1.synchronize()
-                a = kt.setdefault("map_accumulate", [0.0, 0])
+                a = kt.setdefault("tk_boundary_exchange", [0.0, 0])
                 a[0] += e0.elapsed_time(e1)
                 a[1] += 1
-            if multi:  # reduce-scatter of the map: equal padded slots, one all-to-all, no size on the host
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
-                if timed:
-                    ev[0].record()
-                smap.export_parts_padded(world, part_send, stream=stream)
-                pmap.clear(stream=stream)
-                if timed:
-                    ev[1].record()
-                got = shard.reduce_scatter_map(dist, part_send, part_recv)
-                if timed:
-                    ev[2].record()
-                pmap.merge(got, stream=stream)
-                if timed:
-                    ev[3].record()
-                    ev[3].synchronize()
-                    for name, i in (("map_export_parts", 0), ("map_all_to_all", 1), ("map_merge", 2)):
-                        a = kt.setdefault(name, [0.0, 0])
-                        a[0] += ev[i].elapsed_time(ev[i + 1])
-                        a[1] += 1
+        elif split and world > 1:  # gloo dry run: records staged through the host, from rank to rank, walked again where the warm-up missed it
+            torch.cuda.synchronize()  # (the exchange starts when this rank's chain is done: its host time is the exchange's alone)
+            t_b = time.perf_counter()
+            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            info["boundary_ms"] = (time.perf_counter() - t_b) * 1e3
+        map_part(timed)
+        if devb is not None:
+            devb.verdict_async()
 
     def barrier():
+        check_boundary()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if multi and smap is not None:
-        # slot size of the all-to-all: from one untimed pass (the only host read of a size, outside every timed step)
+    need_devb = bool(split and multi and args.backend == "nccl" and (world > 1 or args.force_dist))
+    if multi and (smap is not None or need_devb):
+        # one untimed pass: the slot size of the all-to-all and the record size of the boundary exchange (the only host reads of a size)
         ctx.batch_process(pts, offs, stream=stream, sync=False)
         ctx.batch_cluster(stream=stream, sync=False)
         ctx.batch_cluster_types(stream=stream, sync=False)
         ctx.batch_track(T, next_scan=nxt, stream=stream, sync=False)
+        if need_devb:
+            rec_bytes = shard.boundary_record_bytes(dist, ctx, split, rank, world, dev)
+            devb = shard.DeviceBoundary(dist, ctx, split, rank, world, dev, rec_bytes, self_exchange=(world == 1))
+            info["boundary"] = {"path": "device: padded records, one RCCL point-to-point exchange, compare kernel, all_reduce(MAX) of the verdict; the host reads the verdict after the step was enqueued",
+                                "record_bytes": rec_bytes, "records_per_exchange": args.skip}
+        elif split and world > 1:
+            info["boundary"] = {"path": "host-staged (gloo dry run)"}
+    if multi and smap is not None:
         smap.clear(stream=stream)
         if split and world > 1:
-            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
+            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
         for f0, c0 in own_spans:
             smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
         _, counts0 = smap.export_parts(world, stream=stream)
@@ -523,7 +570,7 @@ def main():
                "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (f"seq05-shaped {args.kind} sequence, {n_sc} scans, {args.preset}.yaml grid, one batch" if world == 1 and len(job) == 1 else
-                                       f"{len(job)} {args.kind} sequence(s), {int(all_scans)} scans ({'SemanticKITTI seq 00-10 lengths' if args.kitti else str(args.scans) + ' each'}), {args.preset}.yaml grid, dealt as equal contiguous runs over {world} ranks (sequences cut)" if split else
+                                       f"{len(job)} {args.kind} sequence(s), {int(all_scans)} scans ({'SemanticKITTI seq 00-10 lengths' + ('' if args.kitti_scale == '1' else ' x ' + args.kitti_scale) if args.kitti else str(args.scans) + ' each'}), {args.preset}.yaml grid, dealt as equal contiguous runs over {world} ranks (sequences cut)" if split else
                                        f"{len(job)} sequences of {args.scans} {args.kind} scans (seeded like seq 05, 00, 02, 08, ...), {int(all_scans)} scans in total, whole sequences per rank, {args.preset}.yaml grid"),
                           "scans_per_rank": n_sc, "points_per_scan": total_pts / n_sc, "nonground_binned_per_scan": tot_apri / n_sc,
                           "voxels_per_scan": tot_vox / n_sc, "car_points_per_scan": tot_car / n_sc, "dynamic_fraction_of_binned": dyn_frac,
@@ -534,7 +581,7 @@ def main():
                           "tracking_stride": args.skip,
                           "sharding": (f"equal contiguous runs of the job's scans per rank (sequences are cut) + a halo of {args.split_halo} x {args.skip} scans in front of a cut; the tracking chain's state at a cut is sent by the rank before, compared and walked again from where the halo's warm-up missed it" if split else
                                        "whole sequences per rank (longest first to the least loaded rank)"),
-                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary"), "chains_rewalked_at_boundary_all_ranks": info.get("chains_rewalked_all_ranks"), "boundary_exchange_ms_rank0_last_step": info.get("boundary_ms")} if split else None)},
+                          "split": ({"scans_loaded_by_rank0": n_sc, "own": own_count, "pieces_rank0": [list(map(int, pc)) for pc in split["pieces"]], "chains_rewalked_at_boundary_rank0": info.get("chains_rewalked_at_boundary"), "chains_rewalked_at_boundary_all_ranks": info.get("chains_rewalked_all_ranks"), "boundary_exchange_ms_rank0_last_step": info.get("boundary_ms"), "boundary": info.get("boundary"), "boundary_slow_path_steps_rank0": info.get("boundary_slow_path_steps", 0)} if split else None)},
                "mpts_per_s": all_pts * args.steps / dt / 1e6, "gen_seconds": gen_s,
                "roofline": roof, "cpu_baseline": cpu, "quality": quality, "kernels": kernels, "extras": extras}
         if multi:

@@ -87,11 +87,26 @@ struct scvod_ctx {
     ChainWalker* d_chain_walkers = nullptr;  // [cap_scans]
     int32_t* d_chain_fw = nullptr;           // [cap_scans + 1]
     int32_t* d_chain_stats = nullptr;        // [8]
+    int32_t* d_step_ticks = nullptr;         // [cap_scans] per frame of the chain plan: what k_tk_chain spent in the step that starts there (ChainJob::step_ticks)
+    int32_t* h_step_ticks = nullptr;         // pinned copy of the last batch's, behind step_fb_ev
+    hipEvent_t step_fb_ev = nullptr;
+    bool step_fb_pending = false;
+    std::vector<int32_t> step_fb_scans;      // the plan (frames of every chain) the ticks in flight belong to
+    std::vector<int32_t> step_ticks, step_ticks_scans;  // the last ticks that arrived and their plan
+    std::vector<int32_t> plan_scans_tmp;
+    std::vector<std::vector<int>> cuts_cache;  // the time-balanced segment starts of the plan below
+    std::vector<int32_t> cuts_scans;
+    std::vector<uint8_t> cuts_halo;
+    int cuts_warm = -1;
+    int chain_balance = 1;                   // 1: cut the segments of a stream's next batch by these times (scvod_set_track_mode: segment_steps 0)
     int32_t* d_chain_cmp = nullptr;          // [1] scvod_batch_track_compare
     std::vector<uint8_t> halo;               // per scan of a batch: 1 = halo (warmed up over, never decided): scvod_set_track_owned / _halo
     ChainJob last_cj;                        // the chain job of the last scvod_batch_track (export / resume)
     TrackBatch last_tb;
     const unsigned char** d_ext_state = nullptr;  // [cap_scans] device array of the states a resume compares with
+    void** h_ext_state_pin = nullptr;        // pinned staging of that table (scvod_batch_track_compare_device)
+    bool ext_state_pin_valid = false;
+    int ext_state_pin_n = 0;
     std::vector<int32_t> up_chain_scans, up_chain_fw, up_chain_walkers;
     void* chain_ws = nullptr;                // walkers' workspace (own allocation, grows on demand)
     size_t chain_ws_bytes = 0;
@@ -289,6 +304,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     c->d_chain_walkers = k.take<ChainWalker>(B);
     c->d_chain_fw = k.take<int32_t>(B + 1);
     c->d_chain_stats = k.take<int32_t>(8);
+    c->d_step_ticks = k.take<int32_t>(B + 1);
     c->d_chain_cmp = k.take<int32_t>(4);
     c->d_ext_state = k.take<const unsigned char*>(B);
     *total = align_up(k.off, 256);
@@ -766,6 +782,77 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
     }
     const int warm = c->chain_warm >= 0 ? c->chain_warm : c->chain_warm_auto;
     c->chain_warm_used = warm;
+    // the times the walkers of this stream's last batch measured per step (same plan of frames): a kernel lasts as long as its slowest
+    // walker, and what a step costs follows the stretch of the sequence (objects tracked for tens of frames carry large clouds), not
+    // anything the planner could read off the scans -- so the segments of the NEXT batch are cut to equal measured time (warm-up included)
+    if (c->step_fb_pending && hipEventQuery(c->step_fb_ev) == hipSuccess) {
+        c->step_fb_pending = false;
+        c->step_ticks.assign(c->h_step_ticks, c->h_step_ticks + c->step_fb_scans.size());
+        c->step_ticks_scans = c->step_fb_scans;
+    }
+    std::vector<std::vector<int>> cuts;  // per chain: segment starts (own steps), when cut by time
+    // (planned ONCE per plan of frames, halo and warm-up -- from the first times that arrive for it -- and kept: the host pays for the
+    //  search once, the walker table is uploaded once, and a stream's batches keep one segmentation)
+    if (c->chain_seg <= 0 && c->chain_balance && !c->cuts_cache.empty() && c->cuts_scans == scans && c->cuts_warm == warm && c->cuts_halo == c->halo) {
+        cuts = c->cuts_cache;
+    } else if (c->chain_seg <= 0 && c->chain_balance && !c->step_ticks.empty() && c->step_ticks_scans == scans) {
+        std::vector<double> cost(scans.size(), 0.0);
+        double sum = 0;
+        long long cnt = 0;
+        for (size_t i = 0; i < scans.size(); ++i)
+            if (c->step_ticks[i] > 0) {
+                sum += c->step_ticks[i];
+                ++cnt;
+            }
+        const double mean = cnt ? sum / (double)cnt : 1.0;
+        for (size_t i = 0; i < scans.size(); ++i) cost[i] = c->step_ticks[i] > 0 ? (double)c->step_ticks[i] : mean;
+        std::vector<int> a0s(chain_len.size());
+        double total = 0, biggest = 0;
+        for (size_t ci = 0; ci < chain_len.size(); ++ci) {
+            const int first = chain_first[ci], steps = chain_len[ci] - 1;
+            int a0 = 0;
+            while (a0 < steps && (size_t)scans[first + a0] < c->halo.size() && c->halo[scans[first + a0]]) ++a0;
+            a0s[ci] = a0;
+            for (int k = 0; k < steps; ++k) total += cost[first + k];
+        }
+        auto plan = [&](double tau, std::vector<std::vector<int>>* out) -> long long {
+            long long nseg = 0;
+            if (out) out->assign(chain_len.size(), std::vector<int>());
+            for (size_t ci = 0; ci < chain_len.size(); ++ci) {
+                const int first = chain_first[ci], steps = chain_len[ci] - 1, a0 = a0s[ci];
+                int a = a0;
+                while (a < steps) {
+                    const int t0 = (a == a0 && a0 > 0) ? 0 : (a - warm > 0 ? a - warm : 0);
+                    double t = 0;
+                    for (int k = t0; k < a; ++k) t += cost[first + k];
+                    int b = a;
+                    do {
+                        t += cost[first + b];
+                        ++b;
+                    } while (b < steps && t + cost[first + b] <= tau);
+                    if (out) (*out)[ci].push_back(a);
+                    ++nseg;
+                    a = b;
+                }
+            }
+            return nseg;
+        };
+        double lo_t = 0, hi_t = total + 1.0;  // smallest tau whose plan fits the device one walker per CU
+        if (plan(hi_t, nullptr) <= c->n_cu) {
+            for (int it = 0; it < 40; ++it) {
+                const double mid = 0.5 * (lo_t + hi_t);
+                if (plan(mid, nullptr) <= c->n_cu)
+                    hi_t = mid;
+                else
+                    lo_t = mid;
+            }
+            plan(hi_t, &cuts);
+            c->cuts_cache = cuts;
+            c->cuts_scans = scans;
+            c->cuts_warm = warm;
+            c->cuts_halo = c->halo;
+        }
+    }
     int n_chains = 0;
     for (size_t ci = 0; ci < chain_len.size(); ++ci) {
         const int first = chain_first[ci], n = chain_len[ci];
@@ -774,6 +861,21 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
         // are only ever a warm-up (the whole halo for the first walker: its start state has no other source on this shard)
         int a0 = 0;
         while (a0 < steps && (size_t)scans[first + a0] < c->halo.size() && c->halo[scans[first + a0]]) ++a0;
+        if (!cuts.empty()) {
+            const std::vector<int>& cs = cuts[ci];
+            for (size_t k = 0; k < cs.size(); ++k) {
+                const int a = cs[k], b = k + 1 < cs.size() ? cs[k + 1] : steps;
+                const int t0 = (a == a0 && a0 > 0) ? 0 : (a - warm > 0 ? a - warm : 0);
+                const int32_t w[8] = {first, n, a, b, t0, n_chains, (a == a0 && a0 > 0) ? 1 : 0, 0};
+                walkers.insert(walkers.end(), w, w + 8);
+            }
+            fw.push_back((int32_t)(walkers.size() / 8));
+            ++n_chains;
+            continue;
+        }
+        for (int a = a0; a < n; ++a)  // a halo flag behind a scan of the chain that is not halo would be ignored silently: refuse it
+            if ((size_t)scans[first + a] < c->halo.size() && c->halo[scans[first + a]] && a > a0)
+                return fail(c, SCVOD_ERR_INVALID, "scan %d is marked halo but follows scan %d of its chain, which is not: a chain's halo scans must be its first ones", scans[first + a], scans[first + a0]);
         for (int a = a0; a < steps; a += seg) {
             const int b = a + seg < steps ? a + seg : steps;
             const int t0 = (a == a0 && a0 > 0) ? 0 : (a - warm > 0 ? a - warm : 0);
@@ -923,6 +1025,7 @@ int scvod_create(const scvod_params* params, const scvod_pw_params* pw, int devi
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+        if (const char* e = getenv("SCVOD_CHAIN_BALANCE")) c->chain_balance = atoi(e);  // (development: 0 = equal-length segments, as rounds 3-4)
     }
     if (hipStreamCreate(&c->stream) != hipSuccess) {
         hipFree(c->arena_base);
@@ -944,6 +1047,9 @@ void scvod_destroy(scvod_ctx* c) {
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->ln_stream) hipStreamDestroy(c->ln_stream);
     if (c->h_chain_fb) hipHostFree(c->h_chain_fb);
+    if (c->h_step_ticks) hipHostFree(c->h_step_ticks);
+    if (c->h_ext_state_pin) hipHostFree(c->h_ext_state_pin);
+    if (c->step_fb_ev) hipEventDestroy(c->step_fb_ev);
     if (c->chain_fb_ev) hipEventDestroy(c->chain_fb_ev);
     if (c->ln_stream2) hipStreamDestroy(c->ln_stream2);
     if (c->ln_stream3) hipStreamDestroy(c->ln_stream3);
@@ -1242,6 +1348,8 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
     if (c->batch_mode == 3) return fail(c, SCVOD_ERR_STATE, "the last batch was a VoxelGrid run");
     const int B = c->A.n_scans;
     if (n_ext > c->cap_scans) return fail(c, SCVOD_ERR_CAPACITY, "too many external tables");
+    if ((int)c->halo.size() > B)  // (a mask left over from a batch with another layout would silently turn leading scans into warm-up only)
+        return fail(c, SCVOD_ERR_INVALID, "the halo mask covers %d scans, the batch holds %d: call scvod_set_track_owned / scvod_set_track_halo for this batch", (int)c->halo.size(), B);
     std::vector<int32_t> next(B);
     for (int s = 0; s < B; ++s) {
         const int32_t v = h_next_scan ? h_next_scan[s] : (s + 1 < B ? s + 1 : -1);
@@ -1319,6 +1427,9 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             CJ.literal_max_name = (c->max_name_literal && c->last_name_valid) ? 1 : 0;
             CJ.ext_state = nullptr;
             CJ.resume = 0;
+            CJ.step_ticks = c->d_step_ticks;
+            HIPCHK(c, hipMemsetAsync(c->d_step_ticks, 0, sizeof(int32_t) * scans.size(), st));
+            c->plan_scans_tmp = scans;
             c->last_cj = CJ;
             c->last_tb = J;
             c->chain_ran = true;
@@ -1337,6 +1448,16 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
             HIPCHK(c, hipEventRecord(c->chain_fb_ev, st));
             c->chain_fb_pending = true;
             c->chain_fb_segments = CJ.n_walkers;
+        }
+        if (!c->h_step_ticks) {
+            HIPCHK(c, hipHostMalloc((void**)&c->h_step_ticks, sizeof(int32_t) * (size_t)(c->cap_scans + 1)));
+            HIPCHK(c, hipEventCreateWithFlags(&c->step_fb_ev, hipEventDisableTiming));
+        }
+        if (!c->step_fb_pending && c->chain_balance && !(c->cuts_scans == c->plan_scans_tmp && !c->cuts_cache.empty())) {  // the per-step times, for the cuts of the stream's next batch
+            HIPCHK(c, hipMemcpyAsync(c->h_step_ticks, c->d_step_ticks, sizeof(int32_t) * c->plan_scans_tmp.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(c->step_fb_ev, st));
+            c->step_fb_pending = true;
+            c->step_fb_scans = c->plan_scans_tmp;
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -1379,7 +1500,7 @@ int scvod_chain_export_state(scvod_ctx* c, int32_t chain, int32_t which, void* d
     if (chain < 0 || chain >= c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "chain %d out of range (%d chains)", chain, c->last_cj.n_chains);
     if (cap_bytes < 16) return fail(c, SCVOD_ERR_CAPACITY, "state buffer too small");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = stream ? (hipStream_t)stream : (c->last_stream ? c->last_stream : c->stream);  // (behind the walkers of the last scvod_batch_track)
     launch_chain_export_state(c->last_cj, chain, which, (unsigned char*)d_dst, cap_bytes, st);
     HIPCHK(c, hipGetLastError());
     return SCVOD_OK;
@@ -1405,8 +1526,9 @@ int scvod_batch_track_resume(scvod_ctx* c, const void* const* h_d_states, int32_
     if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track_resume needs a chain-mode scvod_batch_track first");
     if (n_states != c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "%d states for %d chains", n_states, c->last_cj.n_chains);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = stream ? (hipStream_t)stream : (c->last_stream ? c->last_stream : c->stream);
     c->last_stream = st;
+    c->ext_state_pin_valid = false;
     HIPCHK(c, hipMemcpyAsync((void*)c->d_ext_state, h_d_states, sizeof(void*) * (size_t)n_states, hipMemcpyHostToDevice, st));
     ChainJob CJ = c->last_cj;
     CJ.ext_state = c->d_ext_state;
@@ -1424,8 +1546,9 @@ int scvod_batch_track_compare(scvod_ctx* c, const void* const* h_d_states, int32
     if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track_compare needs a chain-mode scvod_batch_track first");
     if (n_states != c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "%d states for %d chains", n_states, c->last_cj.n_chains);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = stream ? (hipStream_t)stream : (c->last_stream ? c->last_stream : c->stream);
     c->last_stream = st;
+    c->ext_state_pin_valid = false;
     HIPCHK(c, hipMemcpyAsync((void*)c->d_ext_state, h_d_states, sizeof(void*) * (size_t)n_states, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(c->d_chain_cmp, 0, sizeof(int32_t), st));
     ChainJob CJ = c->last_cj;
@@ -1436,6 +1559,32 @@ int scvod_batch_track_compare(scvod_ctx* c, const void* const* h_d_states, int32
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(h_differ, c->d_chain_cmp, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    return SCVOD_OK;
+}
+
+int scvod_batch_track_compare_device(scvod_ctx* c, const void* const* h_d_states, int32_t n_states, int32_t* d_differ, void* stream) {
+    if (!c || !h_d_states || !d_differ) return SCVOD_ERR_INVALID;
+    if (!c->track_valid || !c->chain_ran) return fail(c, SCVOD_ERR_STATE, "scvod_batch_track_compare_device needs a chain-mode scvod_batch_track first");
+    if (n_states != c->last_cj.n_chains) return fail(c, SCVOD_ERR_INVALID, "%d states for %d chains", n_states, c->last_cj.n_chains);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : (c->last_stream ? c->last_stream : c->stream);
+    c->last_stream = st;
+    // the pointer table goes through a pinned copy of the ctx (nothing waits on the host, the caller's array may go away); it is
+    // uploaded again only when it changed (a shard's receive buffers stay where they are from step to step)
+    if (!c->h_ext_state_pin) HIPCHK(c, hipHostMalloc((void**)&c->h_ext_state_pin, sizeof(void*) * (size_t)c->cap_scans));
+    if (!c->ext_state_pin_valid || c->ext_state_pin_n != n_states || memcmp(c->h_ext_state_pin, h_d_states, sizeof(void*) * (size_t)n_states) != 0) {
+        if (c->ext_state_pin_valid) HIPCHK(c, hipStreamSynchronize(st));  // (a table in flight is still being read: rare, the table changed)
+        memcpy(c->h_ext_state_pin, h_d_states, sizeof(void*) * (size_t)n_states);
+        HIPCHK(c, hipMemcpyAsync((void*)c->d_ext_state, c->h_ext_state_pin, sizeof(void*) * (size_t)n_states, hipMemcpyHostToDevice, st));
+        c->ext_state_pin_valid = true;
+        c->ext_state_pin_n = n_states;
+    }
+    ChainJob CJ = c->last_cj;
+    CJ.ext_state = c->d_ext_state;
+    CJ.resume = 2;
+    CJ.cmp_out = d_differ;
+    launch_track_chain_resume(c->dev, c->A, c->last_tb, CJ, c->batch_mode == 2 ? 1 : 0, st);
+    HIPCHK(c, hipGetLastError());
     return SCVOD_OK;
 }
 

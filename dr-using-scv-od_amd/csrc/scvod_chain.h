@@ -40,6 +40,8 @@ struct ChainJob {
                           //    (2: compare only -- count the chains that would be walked again in cmp_out, change nothing)
     int32_t* cmp_out;     // [1] resume == 2
     int32_t literal_max_name;  // 1: a frame's first new cluster re-uses Frame::max_name as ssc.cpp:354 stores it (Arena::cc_last)
+    int32_t* step_ticks;  // [frames of all chains, parallel to chain_scans] 10 ns ticks k_tk_chain spent in step t of a chain as an OWN step (0: not
+                          //    walked as one): the planner of the stream's next batch cuts the segments by these times; may be nullptr
 };
 
 #ifdef __HIPCC__

@@ -1365,8 +1365,10 @@ __device__ __forceinline__ void chain_step(const DevParams& P, const Arena& A, c
 
 // walks steps [t_begin, t_end) of a chain on workspace K starting from the state in slot `cur`; returns the slot of the final state
 __device__ __forceinline__ int walk(const DevParams& P, const Arena& A, const TrackBatch& J, const ChainJob& C, const Wk& K, Shared& sh,
-                    uint32_t* bits, const ChainWalker& W, int cur, int t_begin, int t_end, int out_from, int snap_at, int from_apri) {
+                    uint32_t* bits, const ChainWalker& W, int cur, int t_begin, int t_end, int out_from, int snap_at, int from_apri,
+                    int32_t* ticks = nullptr) {
     const int32_t* frames = C.chain_scans + W.first;
+    long long t_prev = ticks ? wall_clock64() : 0;
     for (int t = t_begin; t < t_end; ++t) {
         if (t == snap_at) {
             copy_state(K, cur, K, 2);
@@ -1374,6 +1376,11 @@ __device__ __forceinline__ int walk(const DevParams& P, const Arena& A, const Tr
         }
         chain_step(P, A, J, C, K, sh, bits, cur, frames[t], frames[t + 1], t >= out_from, from_apri);
         cur ^= 1;
+        if (ticks) {  // what this step cost (thread 0's clock between the ends of two steps): the next batch's segments are cut by it
+            const long long now = wall_clock64();
+            if (threadIdx.x == 0 && t >= out_from) ticks[t] = (int32_t)min(now - t_prev, 0x7fffffffll);
+            t_prev = now;
+        }
     }
     return cur;
 }
@@ -1393,7 +1400,7 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain(DevParams P, Arena A, T
 #ifdef SCVOD_PROFILE
     const long long wt0 = wall_clock64();
 #endif
-    const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.t0, W.b, W.a, W.t0 < W.a ? W.a : -1, from_apri);
+    const int end = walk(P, A, J, C, K, sh, ch_bits, W, 0, W.t0, W.b, W.a, W.t0 < W.a ? W.a : -1, from_apri, C.step_ticks ? C.step_ticks + W.first : nullptr);
     if (threadIdx.x == 0) K.hdr[H_END_SLOT] = end;
 #ifdef SCVOD_PROFILE
     if (threadIdx.x == 0) K.hdr[15] = (int)(wall_clock64() - wt0);
@@ -1451,17 +1458,20 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
     if (C.resume) {
         const ChainWalker W0 = C.walkers[w0];
         const unsigned char* ext = C.ext_state ? C.ext_state[blockIdx.x] : nullptr;
-        if (!W0.ext || !ext) return;
+        if (!ext) return;
         const Wk K0 = wk_of(C.ws, w0);
         const ExtRec R = ext_of(ext);
         if (threadIdx.x == 0 && C.resume == 1) atomicAdd(&C.stats[2], 1);
-        const bool ok = R.hdr[3] != 0 && K0.hdr[H_HAS_SNAP] != 0 && same_state_ext(K0, 2, R);
-        if (C.resume == 2) {  // compare only (scvod_batch_track_compare)
+        // a chain that continues another shard WITHOUT a halo (no warm-up step in front of its block: W0.ext == 0) started from the fresh
+        // segmentation of its first frame and has no snapshot to compare: the received state is what it has to start from, so it
+        // counts as "differs" and is walked again from that state (round-4 advice: it used to be ignored silently)
+        const bool ok = R.hdr[3] == 1 && W0.ext != 0 && K0.hdr[H_HAS_SNAP] != 0 && same_state_ext(K0, 2, R);
+        if (C.resume == 2) {  // compare only (scvod_batch_track_compare); a record that did not fit its exchange buffer (hdr[3] == 2) counts as a difference
             if (threadIdx.x == 0 && !ok && R.hdr[3] != 0) atomicAdd(C.cmp_out, 1);
             return;
         }
         if (ok) return;  // the warm-up reproduced it: everything behind stands
-        if (R.hdr[3] == 0) return;  // (no state to start from: nothing to do)
+        if (R.hdr[3] != 1) return;  // (no state to start from: nothing to do)
         for (int i = threadIdx.x; i < C.n_eval_waves * C.words; i += kChThreads) ch_bits[i] = 0u;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(&C.stats[1], 1);
@@ -1543,12 +1553,13 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_export(ChainJob C, int 
     }
     const int ne = valid ? K.hdr[H_NENT + slot] : 0, nc = valid ? K.hdr[H_NCARRIED + slot] : 0, np = valid ? K.hdr[H_NPARTS + slot] : 0;
     const size_t need = 16 + (size_t)32 * ne + (((size_t)4 * np + 15) & ~(size_t)15) + (size_t)16 * nc;
-    if ((long long)need > cap_bytes) valid = false;
+    const bool too_large = valid && (long long)need > cap_bytes;  // (a fixed-size exchange buffer: the receiver treats it as "differs" and asks for the full record)
+    if (too_large) valid = false;
     if (threadIdx.x == 0) {
         hdr[0] = valid ? ne : 0;
         hdr[1] = valid ? nc : 0;
         hdr[2] = valid ? np : 0;
-        hdr[3] = valid ? 1 : 0;
+        hdr[3] = valid ? 1 : (too_large ? 2 : 0);
     }
     if (!valid) return;
     int4* ent = (int4*)(dst + 16);

@@ -454,8 +454,13 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A, coop_class);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");
-        hipLaunchKernelGGL((k_pw_arrange<64, kClassWave, 63>), dim3(kPersistCUs * 8), dim3(256), 0, st, P, A);
-        hipLaunchKernelGGL((k_pw_arrange<16, 0, kClassWave - 1>), dim3(kPersistCUs * 4), dim3(256), 0, st, P, A);
+#ifndef SCVOD_NO_FUSED_ARRANGE
+        // (patches of the 16-lane fit are arranged by the lanes that fitted them; what is left: the lane-per-patch fit's)
+        if (coop_class > kClassWave) hipLaunchKernelGGL((k_pw_arrange<64>), dim3(kPersistCUs * 8), dim3(256), 0, st, P, A, kClassWave, coop_class - 1);
+#else
+        hipLaunchKernelGGL((k_pw_arrange<64>), dim3(kPersistCUs * 8), dim3(256), 0, st, P, A, kClassWave, 63);
+#endif
+        hipLaunchKernelGGL((k_pw_arrange<16>), dim3(kPersistCUs * 4), dim3(256), 0, st, P, A, 0, kClassWave - 1);
         TH_END("pw_arrange");
         TH_BEGIN("emit_offsets");
         hipLaunchKernelGGL(k_emit_offsets, dim3(B), dim3(1024), 0, st, P, A);

@@ -1367,14 +1367,12 @@ void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStre
                      hipEvent_t ev_join3, TimerHook th, void* tu) {
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {  // (function attributes are per device: set on every launch, like launch_track_chain does)
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
-        attr_set = true;
     }
     int32_t* lists = A.cc_redo;  // 3 x ([B] scans, [B] = how many)
     for (int k = 0; k < 3; ++k) hipMemsetAsync(lists + (size_t)k * (B + 1) + B, 0, sizeof(int32_t), st);

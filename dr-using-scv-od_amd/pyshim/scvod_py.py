@@ -145,6 +145,7 @@ def load_lib():
         "scvod_chain_export_state": (C.c_int, [vp, i32, i32, vp, i64, vp]),
         "scvod_batch_track_resume": (C.c_int, [vp, vp, i32, vp, i32]),
         "scvod_batch_track_compare": (C.c_int, [vp, vp, i32, vp, vp]),
+        "scvod_batch_track_compare_device": (C.c_int, [vp, vp, i32, vp, vp]),
         "scvod_batch_map_accumulate_range": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "scvod_batch_track_stats": (C.c_int, [vp, vp]),
         "scvod_batch_track_tables": (C.c_int, [vp, vp]),
@@ -181,7 +182,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_batch_cluster_rule_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_get_params", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_track_compare", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_batch_cluster_rule_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_get_params", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_track_compare", "scvod_batch_track_compare_device", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
@@ -446,6 +447,17 @@ class Ctx:
         out = C.c_int32(0)
         self._chk(self.lib.scvod_batch_track_compare(self.h, ptrs, len(states), C.byref(out), C.c_void_p(stream or 0)))
         return int(out.value)
+
+    def chain_export_state_into(self, chain, which, buf, stream=None):
+        """the record of chain_export_state written into `buf` (a torch uint8 device tensor of fixed size) without a word read on the
+        host: a state that needs more room leaves header word 3 = 2 (compare_device then counts the chain as differing)"""
+        self._chk(self.lib.scvod_chain_export_state(self.h, int(chain), int(which), C.c_void_p(buf.data_ptr()), int(buf.numel()), C.c_void_p(stream or 0)))
+
+    def batch_track_compare_device(self, states, d_differ, stream=None):
+        """batch_track_compare with the verdict ADDED to d_differ (a torch int32 device tensor the caller cleared): asynchronous"""
+        self._resume_keep = states
+        ptrs = (C.c_void_p * max(len(states), 1))(*[C.c_void_p(t.data_ptr() if t is not None else 0) for t in states])
+        self._chk(self.lib.scvod_batch_track_compare_device(self.h, ptrs, len(states), C.c_void_p(d_differ.data_ptr()), C.c_void_p(stream or 0)))
 
     def batch_fetch_track(self, s):
         r = TrackResult()

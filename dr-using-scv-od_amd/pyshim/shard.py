@@ -1,14 +1,18 @@
-"""Sharding of a multi-sequence job across GPUs (one process per GPU) -- shared by bench.py and the gloo tests.
+"""Sharding of a job of one or more sequences across GPUs (one process per GPU) -- shared by bench.py and the gloo tests.
 
 What shards: Patchwork / binning / voxel descriptors / clustering are independent per scan (SSC::reset clears all per-scan
-state, src/ssc.cpp:79-86).  What does not: SSC::segDF tracks frame i against frame i + 1 IN ORDER and every call mutates
-the successor before the next call walks it (src/ssc.cpp:1449-1451, 1354-1419) -- a chain per sequence, which the device
-replays exactly (csrc/scvod_chain.hip).  A chain cannot cross ranks without serialising them, so the unit of work is the
-SEQUENCE: whole sequences are dealt to the ranks (longest first, to the least loaded rank); inside a rank its sequences
-(and the `skip` interleaved sub-sequences of each, config skip_) are independent chains of one batch.  No tracking data
-crosses ranks.  The one exchange step of the path is the static map: every rank accumulates its scans into its own map
-and the maps are reduce-scattered (records grouped by owner rank, one all-to-all of equal-sized padded slots over
-RCCL/xGMI); the cell rule is order-independent, so the merged map is bit-identical to the single-rank map."""
+state, src/ssc.cpp:79-86).  What does not by itself: SSC::segDF tracks frame i against frame i + 1 IN ORDER and every call
+mutates the successor before the next call walks it (src/ssc.cpp:1449-1451, 1354-1419) -- a chain per sequence, which the
+device replays exactly (csrc/scvod_chain.hip).  Two plans:
+  plan_split / plan_job_split (the default of bench.py at N > 1, BASELINE north_star and configs[3]): the job's scans,
+      sequence after sequence, in N contiguous runs; a run that starts inside a sequence also loads a halo of warm x skip
+      scans in front of it, warms its chains up over the halo and VERIFIES the state at the cut against the state the rank
+      before really ended in (resolve_chain_boundaries): one exchange, walked again only where it differs.
+  plan_job (bench.py --replicate / --sequences): whole sequences are dealt to the ranks (longest first, to the least
+      loaded rank); no tracking data crosses ranks.
+In both, the static map is the path's real exchange step: every rank accumulates its own scans into its own map and the
+maps are reduce-scattered (records grouped by owner rank, one all-to-all of equal-sized padded slots over RCCL/xGMI); the
+cell rule is order-independent, so the merged map is bit-identical to the single-rank map."""
 import numpy as np
 
 SEQ_ORDER = (5, 0, 2, 8, 9, 10, 1, 6, 7, 3, 4)  # seq 05 first: one rank = BASELINE.json configs[1]
@@ -20,9 +24,10 @@ def weak_scaling_sequences(n_sequences, scans_per_sequence, seq_order=SEQ_ORDER)
     return [(int(seq_order[k % len(seq_order)]) + 100 * (k // len(seq_order)), 0, int(scans_per_sequence)) for k in range(int(n_sequences))]
 
 
-def kitti_sequences(seq_len, seq_order=SEQ_ORDER):
-    """BASELINE.json configs[3]: SemanticKITTI seq 00-10 at their real lengths."""
-    return [(int(q), 0, int(seq_len[q])) for q in seq_order]
+def kitti_sequences(seq_len, seq_order=SEQ_ORDER, scale=1.0):
+    """BASELINE.json configs[3]: SemanticKITTI seq 00-10 at their real lengths (scale < 1: every length times scale, at least
+    two scans -- the same 11-sequence plan at a size one GPU holds)."""
+    return [(int(q), 0, max(2, int(round(int(seq_len[q]) * float(scale))))) for q in seq_order]
 
 
 def plan_job(world, sequences, skip=1):
@@ -198,6 +203,88 @@ def resolve_chain_boundaries(dist, ctx, plan, rank, world, device, group=None):
         for w in works:
             w.wait()
     return rewalked
+
+
+class DeviceBoundary:
+    """The chain states at the cuts, exchanged ON THE DEVICE (RCCL, backend nccl): every rank exports the state each chain of its
+    last piece ended in into a fixed-size padded record (one row per interleaved sub-sequence), ONE point-to-point exchange with
+    the neighbours moves the rows (batch_isend_irecv: stream-ordered, the host does not wait), the compare kernel adds the
+    chains whose warm-up did not reproduce the received state to a device word, one all_reduce(MAX) makes that word the job's
+    verdict.  Nothing is read on the host inside a step: `verdict_async` copies the word to pinned memory behind an event, and
+    the caller looks at it when the step has been enqueued (bench.py: before the next step).  A verdict != 0 (a chain has to be
+    walked again, or a state outgrew its row) sends the job through resolve_chain_boundaries, the host-driven protocol.
+    cap_bytes: row size, from one untimed pass (the largest record of the job x 2)."""
+
+    def __init__(self, dist, ctx, plan, rank, world, device, cap_bytes, group=None, self_exchange=False):
+        import torch
+        self.dist, self.ctx, self.rank, self.world, self.group = dist, ctx, rank, world, group
+        self.skip = int(plan["skip"])
+        spans = plan.get("spans") or [dict(begin=0, end=len(plan["next_scan"]), lo=plan["lo"], cut_before=rank > 0, cut_behind=rank + 1 < world)]
+        self.recv_side = bool(rank > 0 and spans and spans[0]["cut_before"])
+        self.send_side = bool(rank + 1 < world and spans and spans[-1]["cut_behind"])
+        self.self_exchange = bool(self_exchange and world == 1)  # (one rank: the records travel rank 0 -> rank 0 over RCCL: the same calls, nothing to compare)
+        firsts = ctx.batch_track_chains()
+
+        def chains_of(span):
+            return {(span["lo"] + int(f) - span["begin"]) % self.skip: c for c, f in enumerate(firsts) if span["begin"] <= int(f) < span["end"]}
+        self.n_chains = len(firsts)
+        self.send_chains = sorted(chains_of(spans[-1]).items()) if (self.send_side or self.self_exchange) else []
+        self.recv_chains = chains_of(spans[0]) if self.recv_side else {}
+        self.send = torch.zeros((self.skip, int(cap_bytes)), dtype=torch.uint8, device=device)
+        self.recv = torch.zeros_like(self.send)
+        self.verdict = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending = False
+        self.states = [None] * self.n_chains
+        for res, c in self.recv_chains.items():
+            self.states[c] = self.recv[res]
+
+    def exchange(self, stream):
+        """enqueue export -> exchange -> compare -> all_reduce on the current stream; returns nothing (see verdict_async)"""
+        import torch
+        dist = self.dist
+        for res, c in self.send_chains:
+            self.ctx.chain_export_state_into(c, 1, self.send[res], stream=stream)
+        ops = []
+        if self.send_side or self.self_exchange:
+            ops.append(dist.P2POp(dist.isend, self.send, self.rank + 1 if self.send_side else self.rank, self.group))
+        if self.recv_side or self.self_exchange:
+            ops.append(dist.P2POp(dist.irecv, self.recv, self.rank - 1 if self.recv_side else self.rank, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()  # (nccl: orders the current stream behind the transfer, the host goes on)
+        self.verdict.zero_()
+        if self.recv_side:
+            self.ctx.batch_track_compare_device(self.states, self.verdict, stream=stream)
+        dist.all_reduce(self.verdict, op=dist.ReduceOp.MAX, group=self.group)
+
+    def verdict_async(self):
+        self.host.copy_(self.verdict, non_blocking=True)
+        self.event.record()
+        self.pending = True
+
+    def verdict_wait(self):
+        """the job's verdict of the last exchange (waits for it): 0 = every warm-up reproduced the state at its cut"""
+        if not self.pending:
+            return 0
+        self.event.synchronize()
+        self.pending = False
+        return int(self.host.item())
+
+
+def boundary_record_bytes(dist, ctx, plan, rank, world, device, group=None):
+    """row size for DeviceBoundary: the largest boundary record of the job (one untimed look at the sizes) x 2, at least 64 KB, at most
+    what a state can hold"""
+    import torch
+    spans = plan.get("spans") or [dict(begin=0, end=len(plan["next_scan"]), lo=plan["lo"])]
+    firsts = ctx.batch_track_chains()
+    mine = [c for c, f in enumerate(firsts) if spans[-1]["begin"] <= int(f) < spans[-1]["end"]]
+    used = max([int(t.numel()) for t in ctx.chain_export_states(mine, 1)] + [16]) if mine else 16
+    t = torch.tensor([used], dtype=torch.int64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    full = int(ctx.lib.scvod_chain_state_bytes(ctx.h))
+    return int(min(max(2 * int(t.item()), 64 * 1024), max(full, 16)))
 
 
 def reduce_scatter_map(dist, send, recv=None):

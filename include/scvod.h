@@ -310,7 +310,9 @@ int scvod_set_chain_capacity(scvod_ctx* ctx, int64_t pool_points);
  *   scvod_batch_track_chains      h_first_scan[k] = first scan of chain k (which interleaved sub-sequence it is), returns the count
  *   scvod_chain_state_bytes       size of a boundary-state record of this job
  *   scvod_chain_export_state      which = 1: the state chain k ENDED in (a device buffer: send it to the shard that owns the next
- *                                 block); which = 0: the state the chain assumed at its first own step (its warm-up's snapshot)
+ *                                 block); which = 0: the state the chain assumed at its first own step (its warm-up's snapshot).
+ *                                 Record = int32 {entries, carried points, parts, valid}, entries, parts, carried points; valid = 1,
+ *                                 0 (the chain has no such state) or 2 (the state needs more than cap_bytes: nothing but the header is written)
  *   scvod_batch_track_resume      h_d_states[k] = device pointer of the record the previous shard sent for chain k (NULL: none):
  *                                 compared with that snapshot (entries and parts bit for bit, the carried points per entry as a
  *                                 multiset: their order depends on where a walk started and nothing reads it); a chain whose warm-up did not reproduce it is walked
@@ -330,6 +332,11 @@ int64_t scvod_chain_state_bytes(scvod_ctx* ctx);
 int scvod_chain_export_state(scvod_ctx* ctx, int32_t chain, int32_t which, void* d_dst, int64_t cap_bytes, void* stream);
 int scvod_batch_track_resume(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, void* stream, int32_t sync);
 int scvod_batch_track_compare(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, int32_t* h_differ, void* stream);
+/* The comparison without a word read on the host: the chains whose warm-up did NOT reproduce the received record are ADDED to
+ * *d_differ, a device word the caller cleared (and may all-reduce over RCCL afterwards); a record that did not fit the buffer
+ * it was exported into (scvod_chain_export_state with a fixed-size exchange buffer: header word 3 = 2) counts as a difference.
+ * Asynchronous on `stream`; nothing is changed.  h_d_states is copied before the call returns. */
+int scvod_batch_track_compare_device(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, int32_t* d_differ, void* stream);
 /* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
  * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.
  * Returns SCVOD_ERR_CAPACITY when a chain state did not fit the walkers' workspace (the result is then invalid). */

@@ -44,9 +44,14 @@ def test_two_ranks_reproduce_the_single_rank_job(tmp_path):
 
 def test_rccl_leg_at_one_rank(tmp_path):
     plain, m0 = _run(str(tmp_path), "plain", ["--gpus", "1", "--scans", "20"])
-    rccl, m1 = _run(str(tmp_path), "rccl", ["--gpus", "1", "--scans", "20", "--force-dist"], backend="nccl")
+    rccl, m1 = _run(str(tmp_path), "rccl", ["--gpus", "1", "--scans", "20", "--force-dist", "--split-sequence"], backend="nccl")
     assert rccl["config"]["backend"] == "nccl" and rccl["config"]["rccl_ranks"] == 1
     assert rccl["config"]["map_slot_records"] > 0                       # the padded all_to_all_single ran
+    # the boundary exchange of a cut sequence on the device: export kernels into padded records, one RCCL point-to-point exchange
+    # (rank 0 -> rank 0 here), the compare kernel, the all_reduce of the verdict -- and nothing for the slow path to do
+    b = rccl["config"]["split"]
+    assert b["boundary"]["path"].startswith("device") and b["boundary"]["record_bytes"] >= 65536 and b["boundary_slow_path_steps_rank0"] == 0
+    assert "tk_boundary_exchange" in rccl["kernels"]
     assert np.array_equal(m0["dynamic_points"], m1["dynamic_points"])
     assert np.array_equal(m0["keys"], m1["keys"]) and np.array_equal(m0["vals"], m1["vals"])
     assert plain["config"]["static_map_cells"] == rccl["config"]["static_map_cells"]
@@ -92,3 +97,50 @@ def test_k64_sequence_over_two_ranks_with_the_default_halo(tmp_path):
     assert m1["dynamic_points"].sum() > 0
     assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
     assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])
+
+
+def _run_k64(tmp, name, extra, timeout=1500):
+    out = os.path.join(tmp, name + ".npz")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu", "--no-extras", "--backend", "gloo",
+           "--kind", "K64", "--preset", "semantickitti", "--dump-map", out] + extra
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), np.load(out)
+
+
+def test_one_k64_sequence_over_eight_ranks(tmp_path):
+    """The driver's `bench.py --gpus 8` job (ONE sequence cut over eight ranks, default halo of 12 steps, the KITTI stride of five
+    interleaved chains) driven through the device path before the first 8-GPU run: eight gloo ranks on one device, 30 own scans
+    each + a halo of 60 + one successor per chain.  Per-scan dynamic points and the merged map equal the one-rank run bit for
+    bit; the line reports how many chains were walked again at a cut (none with the full halo)."""
+    one, m1 = _run_k64(str(tmp_path), "one", ["--gpus", "1", "--scans", "240"])
+    eight, m8 = _run_k64(str(tmp_path), "eight", ["--gpus", "8", "--scans", "240", "--same-device"])
+    sp = eight["config"]["split"]
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and sp["own"] == 30 and eight["config"]["rccl_ranks"] == 8
+    assert sp["chains_rewalked_at_boundary_all_ranks"] == 0
+    assert np.array_equal(m1["scans"], m8["scans"]) and len(m8["scans"]) == 240
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m8["dynamic_points"])
+    assert np.array_equal(m1["keys"], m8["keys"]) and np.array_equal(m1["vals"], m8["vals"])
+    assert len(m1["keys"]) == one["config"]["static_map_cells"] == eight["config"]["static_map_cells"]
+
+
+def test_kitti_job_scaled_down_over_eight_ranks(tmp_path):
+    """BASELINE configs[3] -- SemanticKITTI seq 00-10, the sequences cut where the load says (shard.plan_job_split) -- with every
+    sequence at 1/32 of its real length (86, 142, 146, 127, 50, 38, 34, 34, 34, 25 and 8 scans in job order: 724 in all), eight gloo ranks on one
+    device: cuts fall inside sequences, ranks hold the end of one sequence and the start of the next, the shortest sequence is
+    shorter than the tracking stride's warm-up.  Results equal the run with whole sequences on one rank."""
+    one, m1 = _run_k64(str(tmp_path), "one", ["--gpus", "1", "--kitti", "--kitti-scale", "1/32"])
+    eight, m8 = _run_k64(str(tmp_path), "eight", ["--gpus", "8", "--kitti", "--kitti-scale", "1/32", "--split-sequence", "--same-device"])
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    n = len(m1["scans"])
+    assert n == len(m8["scans"]) and n > 700 and np.array_equal(m1["scans"], m8["scans"])
+    assert len(np.unique(m1["scans"][:, 0])) == 11
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m8["dynamic_points"])
+    assert np.array_equal(m1["keys"], m8["keys"]) and np.array_equal(m1["vals"], m8["vals"])
+    assert eight["config"]["split"]["chains_rewalked_at_boundary_all_ranks"] is not None

@@ -34,7 +34,7 @@ def _tracked(scvod, P, d, offs, poses, lo, hi, skip, owned_first=0):
     return ctx
 
 
-@pytest.mark.parametrize("halo_steps", [1, 12])
+@pytest.mark.parametrize("halo_steps", [0, 1, 12])
 def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
     import synth
     import torch
@@ -63,7 +63,9 @@ def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
     before = [B.batch_fetch_track(s - lo)["pt_dyn"] for s in range(cut, count)]
     st0 = B.batch_track_stats()
     differs = B.batch_track_compare([end[(lo + int(f)) % skip] for f in firsts_b])  # the comparison alone: nothing changes
-    assert (differs > 0) == (halo_steps == 1) and B.batch_track_stats() == st0
+    assert (differs > 0) == (halo_steps <= 1) and B.batch_track_stats() == st0
+    if halo_steps == 0:  # no warm-up at all: every chain that continues shard A has to start from the state A sends
+        assert differs == skip
     for s in range(cut, count):
         assert np.array_equal(B.batch_fetch_track(s - lo)["pt_dyn"], before[s - cut])
     B.batch_track_resume([end[(lo + int(f)) % skip] for f in firsts_b])
@@ -74,7 +76,7 @@ def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
         t = B.batch_fetch_track(s - lo)
         assert np.array_equal(t["pt_dyn"], want[s]["pt_dyn"]), (s, int((t["pt_dyn"] != want[s]["pt_dyn"]).sum()))
         assert t["n_dynamic_clusters"] == want[s]["n_dynamic_clusters"] and t["n_dynamic_points"] == want[s]["n_dynamic_points"]
-    if halo_steps == 1:  # one warm-up step cannot rebuild clouds that were appended over ten frames: the boundary state differs, chains are walked again
+    if halo_steps <= 1:  # no / one warm-up step cannot rebuild clouds that were appended over ten frames: the boundary state differs, chains are walked again
         assert st1["rewalked"] > st0["rewalked"]
     else:
         assert differ_before == 0  # (a full warm-up reproduces the state on this sequence: nothing to walk again ...)
