@@ -258,7 +258,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cl_count = k.take<int32_t>(N);
     A.pt_type = k.take<uint8_t>(N);
     A.cc_last = k.take<int32_t>(B * 4);
-    A.cc_redo = k.take<int32_t>(3 * (B + 1));
+    A.cc_redo = k.take<int32_t>(4 * (B + 1));
     A.ln_state = k.take<int32_t>(B * 2048);
     A.ln_stats = k.take<int32_t>(4);
     A.ln_prof = k.take<int32_t>(B * 8);

@@ -129,7 +129,7 @@ struct Arena {
     // the cluster that still carries Frame::max_name as ssc.cpp:354 stores it (scvod_lastname.hip)
     int32_t* cc_last;         // [B][4] {canonical name or -1, lowest voxel slot whose first point belongs to it or -1,
                               //         status: 0 exact, 1 a replay did not fit the LDS, 2 too many index triples outside the grid, events replayed}
-    int32_t* cc_redo;         // 3 x [B + 1] scans listed by the triage for the pass with the small / mid / large tables, [B] = how many
+    int32_t* cc_redo;         // 4 x [B + 1] scans listed by the triage for the pass with the small / mid / large tables, [B] = how many
     int32_t* ln_state;        // [B][kLnStateWords] what the triage leaves a scan's follow-up pass: the set of classes, the irregular points, the class table
     int32_t* ln_prof;         // [B][8] phase clocks (10 ns ticks) and counts of the last pass over a scan: tools/lastname_lat.py
     int32_t* ln_prof2;        // [B][8] the largest class walked: nodes, Jacobi rounds, clocks of build / rounds / openers / partition / walk, events

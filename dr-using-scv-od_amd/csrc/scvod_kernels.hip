@@ -465,6 +465,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_BEGIN("emit_offsets");
         hipLaunchKernelGGL(k_emit_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("emit_offsets");
+        if (do_voxels) hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);  // (k_emit counts the voxel stage's buckets)
         TH_BEGIN("emit");
         hipLaunchKernelGGL(k_emit, dim3(kPersistCUs * 8), dim3(kEmitThreads), 0, st, P, A);
         TH_END("emit");
@@ -479,12 +480,14 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
             hipMemsetAsync(A.irr_list, 0xff, sizeof(int32_t) * (size_t)B * (kIrrListCap + 1), st);  // (-1: irregular points not listed)
             hipLaunchKernelGGL(k_apri_split, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A);
         }
-        hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
         hipMemsetAsync(A.vb_cursor, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
         dim3 gv((A.max_scan_pts + kVxThreads * kVxItems - 1) / (kVxThreads * kVxItems), B);
-        TH_BEGIN("vx_count");
-        hipLaunchKernelGGL(k_vx_count, gv, dim3(kVxThreads), 0, st, P, A);
-        TH_END("vx_count");
+        if (do_patchwork != 1) {  // (after Patchwork k_emit has counted the buckets already)
+            hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
+            TH_BEGIN("vx_count");
+            hipLaunchKernelGGL(k_vx_count, gv, dim3(kVxThreads), 0, st, P, A);
+            TH_END("vx_count");
+        }
         TH_BEGIN("vx_offsets");
         hipLaunchKernelGGL(k_vx_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("vx_offsets");

@@ -30,7 +30,10 @@
 //     looks at the p-th listed voxel; the walk only steps through the DISTINCT classes a visit meets, the neighbour's name
 //     winning each time) -- K's class either keeps the name or is renamed away;
 //   * the tables of a set live in LDS: 320 nodes for nearly every scan (eight workgroups per CU), 1792 or 8192 for the scans
-//     listed on the device for the larger passes; a set beyond 8192 nodes is not followed: the scan reports "unknown" (counted,
+//     listed on the device for the larger passes; a set of up to 32 767 nodes (the facades of a 128-beam scan: 15-30 k voxels)
+//     is followed by a fourth pass whose read-mostly tables (times, first points, flags) live in arena scratch and whose
+//     atomics table (the next round's times, later the partition's parents) takes the LDS: 4 ms for a 28 k-node set against
+//     0.8 ms for 5 k nodes in LDS.  Beyond that (node numbers are 16-bit in the lists) the scan reports "unknown" (counted,
 //     scvod_batch_cluster_last_name) and the chain hands out a fresh number as if K had been merged away.
 // Checked against a literal restatement of the loop in tests/test_gpu_lastname.py.
 #include "scvod_dev.h"
@@ -45,7 +48,9 @@ constexpr int kLnPairs = 1024;    // links between clusters that such points cre
 constexpr int kLnNames = 256;     // distinct cluster names in those links
 constexpr int kLnSamples = 1024;  // sampled voxel keys (LDS)
 constexpr int kLnMarked = 16;     // components to replay besides the latest-born one
-constexpr int kLnCapTinyNodes = 320, kLnCapSmallNodes = 1792, kLnCapBigNodes = 8192;  // nodes the tables of the three passes hold
+constexpr int kLnCapTinyNodes = 320, kLnCapSmallNodes = 1792, kLnCapBigNodes = 8192;  // nodes the LDS tables of the three passes hold
+constexpr int kLnCapHugeNodes = 32767;  // a fourth pass with its tables in arena scratch (round 5): the facade components of a 128-beam scan (~20 k voxels);
+                                        // node numbers are 16-bit in the lists (Rp::rows)
 constexpr int kLnChunk = 512;     // events staged per round
 constexpr int kInf = 0x7fffffff;
 
@@ -213,6 +218,8 @@ struct Rp {  // tables of one class (LDS unless said otherwise)
     int16_t* rows;   // [nodes][32] listed nodes in findVoxelNeighbors order (ssc.cpp:400-410: range outermost, azimuth innermost), -1 none
     int32_t* ev3;    // [nodes][3] times of a node's visits
     int32_t* ifirst; // [nodes] voxel node -> its first irregular point of this class (index into the scan's irr list), -1
+    int cap;         // nodes the tables hold (CAP, or what the scratch of this scan holds when the tables live there)
+    bool in_hbm;     // T / fa / Tn / par / fl live in arena scratch, not in LDS
 };
 
 struct RpOut {
@@ -374,7 +381,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
             if (lane == lead) b0 = atomicAdd(&bc[0], __popcll(mask));
             b0 = __shfl(b0, lead);
             const int at = b0 + __popcll(mask & ((1ull << lane) - 1ull));
-            if (in && at < CAP) {
+            if (in && at < T.cap) {
                 L.cvl[at] = v;
                 L.loc[v] = at;
             }
@@ -389,18 +396,18 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
             T.inode[j] = -1;
             T.inext[j] = -1;
             T.ivis[j] = 0;
-            if (in_set(L.irr_cls[j])) T.inode[j] = (int16_t)min(nn++, CAP - 1);
+            if (in_set(L.irr_cls[j])) T.inode[j] = (int16_t)min(nn++, T.cap - 1);
         }
         bc[0] = nn;
     }
     __syncthreads();
     const int nn = bc[0];
     auto leave = [&]() {
-        for (int l = tid; l < min(m, CAP); l += TH) L.loc[L.cvl[l]] = -1;
+        for (int l = tid; l < min(m, T.cap); l += TH) L.loc[L.cvl[l]] = -1;
         __syncthreads();
     };
     out.nodes = nn;
-    if (nn > CAP || m > CAP || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || 3 * nn > L.n_raw) {  // does not fit
+    if (nn > T.cap || m > T.cap || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || 3 * nn > L.n_raw) {  // does not fit
         leave();
         out.too_big = 1;
         return out;
@@ -427,7 +434,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
     // ---- lists: 27 cells around a voxel's own cell / around an irregular point's triple, found row by row (the three
     // sectors of a (range, azimuth) pair are consecutive keys: one search, then the records behind it) ----
     {
-        const bool keys_fit = nn >= 96 && (size_t)L.nv * 4 <= (size_t)CAP * 16;  // (T / fa / Tn / par are not in use yet)
+        const bool keys_fit = !T.in_hbm && nn >= 96 && (size_t)L.nv * 4 <= (size_t)CAP * 16;  // (T / fa / Tn / par are not in use yet)
         int32_t* lk = T.T;
         if (keys_fit)
             for (int v = tid; v < L.nv; v += TH) lk[v] = L.vkey[v];
@@ -806,7 +813,7 @@ struct Blk {
 // class table are left in A.ln_state and the scan is listed for the pass whose tables hold the set (lists[0 / 1 / 2]: up to
 // kLnCapTiny / kLnCapSmall / kLnCapBig nodes).  MODE 2: follows the set a triage left.
 constexpr int kLnStateWords = 8 + (kLnMarked + 1) + kLnIrr * 5 + kLnNames * 2;
-template <int CAP, int TH, int MODE>
+template <int CAP, int TH, int MODE, bool GT = false>
 __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char* ln_smem, int32_t* redo, int32_t* redo_big, int big_from) {
     __shared__ int wsum[2 * kLnMaxWaves + 2];
     __shared__ int bc[8];
@@ -858,11 +865,28 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
     L.crep = (int32_t*)take(kLnNames * 4);
     unsigned char* ovl = q;  // from here on: the replay tables, overlaid by the link pairs / the candidates' blocks
     Rp<CAP> T;
-    T.T = (int32_t*)take((size_t)CAP * 4);
-    T.fa = (int32_t*)take((size_t)CAP * 4);
-    T.Tn = (int32_t*)take((size_t)CAP * 4);
-    T.par = (int32_t*)take((size_t)CAP * 4);
-    T.fl = (uint8_t*)take(CAP);
+    if (GT) {
+        // the read-mostly class tables (times, first points, flags: 9 bytes per node) in arena scratch -- `seg`, 4 bytes per input
+        // point, dead since k_emit -- and the one the rounds hammer with atomics in LDS: the next round's times, whose room the
+        // partition's parent array takes over when the rounds are done (the two are never live together)
+        const int fit = (int)min((long long)CAP, (4ll * L.n_raw - 64) / 9);
+        T.cap = fit > 0 ? (fit & ~3) : 0;
+        T.in_hbm = true;
+        int32_t* g = (int32_t*)(A.seg + base);
+        T.T = g;
+        T.fa = g + T.cap;
+        T.fl = (uint8_t*)(g + 2 * (size_t)T.cap);
+        T.Tn = (int32_t*)take((size_t)CAP * 4);
+        T.par = T.Tn;
+    } else {
+        T.cap = CAP;
+        T.in_hbm = false;
+        T.T = (int32_t*)take((size_t)CAP * 4);
+        T.fa = (int32_t*)take((size_t)CAP * 4);
+        T.Tn = (int32_t*)take((size_t)CAP * 4);
+        T.par = (int32_t*)take((size_t)CAP * 4);
+        T.fl = (uint8_t*)take(CAP);
+    }
     T.inext = (int16_t*)take(kLnIrr * 2);
     T.inode = (int16_t*)take(kLnIrr * 2);
     T.ivis = (uint8_t*)take(kLnIrr);
@@ -873,7 +897,8 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
     T.ifirst = (int32_t*)A.sorted_xyz + 3 * (size_t)base + L.n_raw;
     int2* pairs = (int2*)ovl;        // [kLnPairs]
     Blk* blk = (Blk*)ovl + wave;     // [(TH / 64)]
-    static_assert(sizeof(Blk) * (TH / 64) <= (size_t)CAP * 17 + kLnIrr * 5 + kLnChunk * 8 && kLnPairs * 8 <= (size_t)CAP * 17 + kLnIrr * 5 + kLnChunk * 8,
+    constexpr size_t kOvl = (size_t)(GT ? kLnCapBigNodes : CAP) * 17 + kLnIrr * 5 + kLnChunk * 8;
+    static_assert(sizeof(Blk) * (TH / 64) <= kOvl && kLnPairs * 8 <= kOvl,
                   "overlays fit the class tables (and the walk's staging behind them: neither is live at the time)");
 
     L.n_irr = 0;
@@ -1278,11 +1303,11 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
         }
         if (tid == 0) {
             state[0] = n_mk, state[1] = L.n_irr, state[2] = L.n_xs, state[3] = L.n_names;
-            if (cnt > kLnCapBigNodes) {
+            if (cnt > kLnCapHugeNodes) {
                 outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = 0;
                 atomicAdd(&A.ln_stats[0], 1);
             } else {
-                int32_t* list = redo + (size_t)(cnt <= kLnCapTinyNodes ? 0 : (cnt <= kLnCapSmallNodes ? 1 : 2)) * (A.n_scans + 1);
+                int32_t* list = redo + (size_t)(cnt <= kLnCapTinyNodes ? 0 : (cnt <= kLnCapSmallNodes ? 1 : (cnt <= kLnCapBigNodes ? 2 : 3))) * (A.n_scans + 1);
                 list[atomicAdd(list + A.n_scans, 1)] = s;
             }
         }
@@ -1343,7 +1368,7 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
 }
 
 
-template <int CAP, int TH, int MODE>
+template <int CAP, int TH, int MODE, bool GT = false>
 __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const int32_t* todo, const int32_t* n_todo, int32_t* redo, int32_t* redo_big, int big_from,
                                                     int32_t* n_redo) {
     extern __shared__ __align__(16) unsigned char ln_kernel_smem[];
@@ -1352,7 +1377,7 @@ __global__ __launch_bounds__(TH) void k_cc_lastname(DevParams P, Arena A, const 
         if (s >= *n_todo) return;
         s = todo[s];
     }
-    ln_scan<CAP, TH, MODE>(P, A, s, ln_kernel_smem, redo, redo_big, big_from);
+    ln_scan<CAP, TH, MODE, GT>(P, A, s, ln_kernel_smem, redo, redo_big, big_from);
 }
 
 }  // namespace
@@ -1373,9 +1398,10 @@ void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStre
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapTiny, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapTiny>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapSmall, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapSmall>());
         hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapBig, 1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
+        hipFuncSetAttribute((const void*)k_cc_lastname<kLnCapHugeNodes, 1024, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ln_lds_bytes<kLnCapBig>());
     }
-    int32_t* lists = A.cc_redo;  // 3 x ([B] scans, [B] = how many)
-    for (int k = 0; k < 3; ++k) hipMemsetAsync(lists + (size_t)k * (B + 1) + B, 0, sizeof(int32_t), st);
+    int32_t* lists = A.cc_redo;  // 4 x ([B] scans, [B] = how many)
+    for (int k = 0; k < 4; ++k) hipMemsetAsync(lists + (size_t)k * (B + 1) + B, 0, sizeof(int32_t), st);
     hipMemsetAsync(A.ln_stats, 0, 4 * sizeof(int32_t), st);
     const bool large = A.max_scan_pts > 200000;  // (128-beam class, 262 144 returns per scan: its tables are passed over by 1024 threads)
     if (th) th(tu, "cc_lastname", 1);
@@ -1392,9 +1418,15 @@ void launch_lastname(const DevParams& P, const Arena& A, hipStream_t st, hipStre
         hipStreamWaitEvent(st2, ev_fork, 0);
         hipStreamWaitEvent(st3, ev_fork, 0);
     }
-    int32_t* l0 = lists, *l1 = lists + (B + 1), *l2 = lists + 2 * (size_t)(B + 1);
+    int32_t* l0 = lists, *l1 = lists + (B + 1), *l2 = lists + 2 * (size_t)(B + 1), *l3 = lists + 3 * (size_t)(B + 1);
+    {  // sets of more than 8192 nodes (the facades of a 128-beam scan): tables in arena scratch, the longest pass first (an empty list: the workgroups leave at once)
+        if (th) th(tu, "cc_lastname_huge", 1);
+        hipLaunchKernelGGL((k_cc_lastname<kLnCapHugeNodes, 1024, 2, true>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), side ? st3 : st, P, A, (const int32_t*)l3,
+                           (const int32_t*)(l3 + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
+        if (th) th(tu, "cc_lastname_huge", 0);
+    }
     if (th) th(tu, "cc_lastname_big", 1);
-    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024, 2>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), side ? st3 : st, P, A, (const int32_t*)l2,
+    hipLaunchKernelGGL((k_cc_lastname<kLnCapBig, 1024, 2>), dim3(B), dim3(1024), ln_lds_bytes<kLnCapBig>(), side ? (large ? st2 : st3) : st, P, A, (const int32_t*)l2,
                        (const int32_t*)(l2 + B), (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr);
     if (th) th(tu, "cc_lastname_big", 0);
     if (th) th(tu, "cc_lastname_mid", 1);
