@@ -373,7 +373,10 @@ __device__ __forceinline__ void block_bitonic_merge_stages(T* a, int np2) {
 #endif
 constexpr int kLGE = SCVOD_SORT_LGE;           // keys per thread = 2^kLGE in the LDS sorts
 constexpr int kTS = (kLGE == 4) ? 1 : 2;      // thread multiplier: 8 keys per thread -> twice the threads
-constexpr int kLGEv = 3, kTSv = 2;             // voxel-bucket sorts measured faster with 8 keys per thread
+#ifndef SCVOD_VOX_LGE
+#define SCVOD_VOX_LGE 3
+#endif
+constexpr int kLGEv = SCVOD_VOX_LGE, kTSv = (kLGEv == 4) ? 1 : 2;  // voxel-bucket sorts measured faster with 8 keys per thread
 constexpr int kPersistCUs = 256;  // MI355X: 256 CUs; list-driven kernels launch a few workgroups per CU
 constexpr int kSortCapS = 1024, kSortThreadsS = 64;
 constexpr int kSortCapL = 8192, kSortThreadsL = 512;

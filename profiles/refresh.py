@@ -62,7 +62,7 @@ def label(k):
     if k.startswith("k_cc_lastname"):  # the three passes of scvod_lastname.hip by table size (<1792, 1024>: the first pass of 128-beam batches)
         m = re.search(r"<(\d+), *(\d+)", k)
         cap, th = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
-        return "cc_lastname_big" if cap > 4096 else ("cc_lastname_mid" if cap > 1024 and th == 256 else "cc_lastname")
+        return "cc_lastname_huge" if cap > 16384 else ("cc_lastname_big" if cap > 4096 else ("cc_lastname_mid" if cap > 1024 and th == 256 else "cc_lastname"))
     for pre, l in (("k_pw_sort", "pw_sort"), ("k_vx_bucket", "vx_bucket")):
         if k.startswith(pre):
             return l + "_" + str(int(re.search(r"<(\d+)", k).group(1)))
