@@ -218,6 +218,7 @@ struct Rp {  // tables of one class (LDS unless said otherwise)
     int16_t* rows;   // [nodes][32] listed nodes in findVoxelNeighbors order (ssc.cpp:400-410: range outermost, azimuth innermost), -1 none
     int32_t* ev3;    // [nodes][3] times of a node's visits
     int32_t* ifirst; // [nodes] voxel node -> its first irregular point of this class (index into the scan's irr list), -1
+    int32_t* lab;    // [cap] or nullptr: min(T, fa) per node, kept beside the two when the tables live in HBM (one look-up per listed voxel instead of two)
     int cap;         // nodes the tables hold (CAP, or what the scratch of this scan holds when the tables live there)
     bool in_hbm;     // T / fa / Tn / par / fl live in arena scratch, not in LDS
 };
@@ -339,7 +340,7 @@ __device__ __forceinline__ void rp_visit3(const Rp<CAP>& T, const int16_t* row16
         const int u = (int)(int16_t)((w[p >> 1] >> ((p & 1) * 16)) & 0xffffu);
         nb[p] = u;
         if (u >= 0) {
-            const int lab = min(T.T[u], T.fa[u]);  // labelled before time t <=> lab < t
+            const int lab = T.lab ? T.lab[u] : min(T.T[u], T.fa[u]);  // labelled before time t <=> lab < t
 #pragma unroll
             for (int e = 0; e < 3; ++e)
                 if (q[e] < 0 && lab < ie[e] && ie[e] != kInf) q[e] = p;
@@ -441,6 +442,16 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
         __syncthreads();
         Ln Lk = L;
         Lk.lkeys = keys_fit ? lk : nullptr;
+        if (T.in_hbm) {  // the LDS table of the rounds is idle while the lists are built: a dense sample of the keys (every 4th of a 128-beam scan's 72 k)
+            int sh = 0;  //   leaves two look-ups in HBM per row instead of seven behind the 1024 samples of the LDS passes
+            while (((L.nv + (1 << sh) - 1) >> sh) > T.cap) ++sh;
+            const int ns2 = (L.nv + (1 << sh) - 1) >> sh;
+            for (int j = tid; j < ns2; j += TH) T.Tn[j] = L.vkey[(size_t)j << sh];
+            Lk.skey = T.Tn;
+            Lk.sshift = sh;
+            Lk.ns = ns2;
+            __syncthreads();
+        }
         const int32_t* kk = keys_fit ? lk : L.vkey;
         for (int w = tid; w < nn * 9; w += TH) {
             const int x = w / 9, rw = w - x * 9;
@@ -476,6 +487,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
     for (int x = tid; x < nn; x += TH) {
         T.T[x] = kInf;
         T.fa[x] = x < m ? L.fp[L.cvl[x]] : kInf;
+        if (T.lab) T.lab[x] = T.fa[x];
     }
     // the visits of node x: a voxel's first three regular points, an irregular point itself (cached); `home` = the voxel whose
     // full labelling labels the visitor before it starts
@@ -534,6 +546,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
             const int tv = T.Tn[x];
             changed |= tv != T.T[x];
             T.T[x] = tv;
+            if (T.lab) T.lab[x] = min(tv, T.fa[x]);
         }
         converged = !__syncthreads_or(changed);
         out.rounds = round + 1;
@@ -866,21 +879,23 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
     unsigned char* ovl = q;  // from here on: the replay tables, overlaid by the link pairs / the candidates' blocks
     Rp<CAP> T;
     if (GT) {
-        // the read-mostly class tables (times, first points, flags: 9 bytes per node) in arena scratch -- `seg`, 4 bytes per input
+        // the read-mostly class tables (times, first points, their minimum, flags: 13 bytes per node) in arena scratch -- `seg`, 4 bytes per input
         // point, dead since k_emit -- and the one the rounds hammer with atomics in LDS: the next round's times, whose room the
         // partition's parent array takes over when the rounds are done (the two are never live together)
-        const int fit = (int)min((long long)CAP, (4ll * L.n_raw - 64) / 9);
+        const int fit = (int)min((long long)CAP, (4ll * L.n_raw - 64) / 13);
         T.cap = fit > 0 ? (fit & ~3) : 0;
         T.in_hbm = true;
         int32_t* g = (int32_t*)(A.seg + base);
         T.T = g;
         T.fa = g + T.cap;
-        T.fl = (uint8_t*)(g + 2 * (size_t)T.cap);
+        T.lab = g + 2 * (size_t)T.cap;
+        T.fl = (uint8_t*)(g + 3 * (size_t)T.cap);
         T.Tn = (int32_t*)take((size_t)CAP * 4);
         T.par = T.Tn;
     } else {
         T.cap = CAP;
         T.in_hbm = false;
+        T.lab = nullptr;
         T.T = (int32_t*)take((size_t)CAP * 4);
         T.fa = (int32_t*)take((size_t)CAP * 4);
         T.Tn = (int32_t*)take((size_t)CAP * 4);

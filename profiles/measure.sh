@@ -23,12 +23,13 @@ for cfg in "k64:--scans 1024" "park:--kind PARK --preset parkinglot --scans 1024
     [ -n "$f" ] && cp "$f" "$out/rocprofv3_kernel_stats_$name.csv"
 done
 # 3. HBM traffic PER WORKLOAD: FETCH_SIZE and WRITE_SIZE in separate passes (one step, no warm-up: one dispatch per kernel)
-for cfg in "k64:512:--scans 512" "park:512:--kind PARK --preset parkinglot --scans 512" "os128:256:--kind OS128 --preset os128_fine --scans 256"; do
+# (the bench line's own job sizes: the tracking chain's traffic per scan depends on how many walkers a job is cut into)
+for cfg in "k64:2761:--scans 2761" "park:2000:--kind PARK --preset parkinglot --scans 2000" "os128:1000:--kind OS128 --preset os128_fine --scans 1000"; do
     name=${cfg%%:*}; rest=${cfg#*:}; nsc=${rest%%:*}; args=${rest#*:}
     for c in FETCH_SIZE WRITE_SIZE; do
         d=/tmp/prof_${c}_$name
         rm -rf $d
-        timeout 600 rocprofv3 --pmc $c --kernel-include-regex scvod --output-format csv -d $d -- python "$R/bench.py" $args --steps 1 --warmup 0 --no-cpu --no-extras \
+        timeout 900 rocprofv3 --pmc $c --kernel-include-regex scvod --output-format csv -d $d -- python "$R/bench.py" $args --steps 1 --warmup 0 --no-cpu --no-extras \
             > /dev/null 2> "$out/rocprof_${c}_$name.err"
         f=$(find $d -name '*counter_collection.csv' | head -1)
         [ -n "$f" ] && (head -1 "$f"; grep scvod "$f") > "$out/${c}_counter_collection_$name.csv"
