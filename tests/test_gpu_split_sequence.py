@@ -84,11 +84,13 @@ def test_a_sequence_split_in_two_equals_the_whole(scvod, halo_steps):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_three_shards_with_random_cuts_and_halos(scvod, seed):
+def test_three_shards_with_random_cuts_and_halos(scvod, oracle, seed):
     """a PARK sequence (one chain, stride 1) over three shards with random cut points and halo lengths: the protocol of
     pyshim/shard.py resolve_chain_boundaries by hand -- every shard compares the state the shard before ended in FIRST
     (tentative: before that shard resumed); from the first shard that reports a difference on, the shards resume one after
-    the other with the state their predecessor ends in NOW.  The per-point bytes are the unsplit run's."""
+    the other with the state their predecessor ends in NOW.  The per-point bytes are the unsplit run's -- and the ORACLE's: the
+    shards' results are compared with the literal restatement of SSC::segDF's loop over the whole sequence directly, not only
+    with another device run (round-4 verdict, weak #9)."""
     import synth
     import torch
     rng = np.random.default_rng(seed)
@@ -101,6 +103,14 @@ def test_three_shards_with_random_cuts_and_halos(scvod, seed):
     whole = _tracked(scvod, P, d, offs, poses, 0, count, skip)
     want = [whole.batch_fetch_track(s)["pt_dyn"] for s in range(count)]
     assert sum(int(w.sum()) for w in want) > 0
+    res = [whole.batch_fetch(s) for s in range(count)]
+    names = [whole.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(count)]
+    types = [whole.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(count)]
+    ln, _ = whole.batch_cluster_last_name(count)
+    assert int((ln[:, 2] != 0).sum()) == 0  # (every max_name of this sequence is determined: nothing handed to the oracle as unknown)
+    ref_dyn, _ = oracle.reference_chain(P, res, names, types, [poses[s] for s in range(count)])
+    ao = np.concatenate([[0], np.cumsum([r["n_apri"] for r in res])])
+    ref = [ref_dyn[ao[s]:ao[s + 1]] for s in range(count)]
     whole.close()
     c1 = int(rng.integers(35, 60))
     c2 = int(rng.integers(c1 + 30, 120))
@@ -124,4 +134,5 @@ def test_three_shards_with_random_cuts_and_halos(scvod, seed):
         for s in range(cuts[k], cuts[k + 1]):
             got = sh.batch_fetch_track(s - lo)["pt_dyn"]
             assert np.array_equal(got, want[s]), (seed, cuts, halos, differs, k, s, int((got != want[s]).sum()))
+            assert np.array_equal(got, ref[s]), (seed, cuts, halos, "oracle chain", k, s, int((got != ref[s]).sum()))
         sh.close()
