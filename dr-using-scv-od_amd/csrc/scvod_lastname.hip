@@ -203,7 +203,9 @@ __device__ __forceinline__ int cls_of(const Ln& L, int name) {
 }
 
 template <int CAP>
-struct Rp {  // tables of one class (LDS unless said otherwise)
+struct Rp {  // tables of one class (LDS unless said otherwise; the CAP == kLnCapHugeNodes instantiation keeps T / fa / lab / fl in arena scratch --
+             // a compile-time distinction: a run-time flag in these inner loops cost the LDS passes 1.5-1.8 x)
+    static constexpr bool kHbm = (CAP == kLnCapHugeNodes);
     int32_t* T;      // [CAP] voxel node: time of the visit that labelled it FULLY, kInf never
     int32_t* fa;     // [CAP] voxel node: its first point (of any kind), kInf for the nodes of irregular points
     int32_t* Tn;     // [CAP] next round's times
@@ -340,7 +342,11 @@ __device__ __forceinline__ void rp_visit3(const Rp<CAP>& T, const int16_t* row16
         const int u = (int)(int16_t)((w[p >> 1] >> ((p & 1) * 16)) & 0xffffu);
         nb[p] = u;
         if (u >= 0) {
-            const int lab = T.lab ? T.lab[u] : min(T.T[u], T.fa[u]);  // labelled before time t <=> lab < t
+            int lab;  // labelled before time t <=> lab < t
+            if constexpr (Rp<CAP>::kHbm)
+                lab = T.lab[u];
+            else
+                lab = min(T.T[u], T.fa[u]);
 #pragma unroll
             for (int e = 0; e < 3; ++e)
                 if (q[e] < 0 && lab < ie[e] && ie[e] != kInf) q[e] = p;
@@ -382,7 +388,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
             if (lane == lead) b0 = atomicAdd(&bc[0], __popcll(mask));
             b0 = __shfl(b0, lead);
             const int at = b0 + __popcll(mask & ((1ull << lane) - 1ull));
-            if (in && at < T.cap) {
+            if (in && at < (Rp<CAP>::kHbm ? T.cap : CAP)) {
                 L.cvl[at] = v;
                 L.loc[v] = at;
             }
@@ -397,18 +403,18 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
             T.inode[j] = -1;
             T.inext[j] = -1;
             T.ivis[j] = 0;
-            if (in_set(L.irr_cls[j])) T.inode[j] = (int16_t)min(nn++, T.cap - 1);
+            if (in_set(L.irr_cls[j])) T.inode[j] = (int16_t)min(nn++, (Rp<CAP>::kHbm ? T.cap : CAP) - 1);
         }
         bc[0] = nn;
     }
     __syncthreads();
     const int nn = bc[0];
     auto leave = [&]() {
-        for (int l = tid; l < min(m, T.cap); l += TH) L.loc[L.cvl[l]] = -1;
+        for (int l = tid; l < min(m, Rp<CAP>::kHbm ? T.cap : CAP); l += TH) L.loc[L.cvl[l]] = -1;
         __syncthreads();
     };
     out.nodes = nn;
-    if (nn > T.cap || m > T.cap || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || 3 * nn > L.n_raw) {  // does not fit
+    if (nn > (Rp<CAP>::kHbm ? T.cap : CAP) || m > (Rp<CAP>::kHbm ? T.cap : CAP) || nn > 32767 || (long long)nn * 64 > (long long)L.rows_bytes || 3 * nn > L.n_raw) {  // does not fit
         leave();
         out.too_big = 1;
         return out;
@@ -435,14 +441,14 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
     // ---- lists: 27 cells around a voxel's own cell / around an irregular point's triple, found row by row (the three
     // sectors of a (range, azimuth) pair are consecutive keys: one search, then the records behind it) ----
     {
-        const bool keys_fit = !T.in_hbm && nn >= 96 && (size_t)L.nv * 4 <= (size_t)CAP * 16;  // (T / fa / Tn / par are not in use yet)
+        const bool keys_fit = !Rp<CAP>::kHbm && nn >= 96 && (size_t)L.nv * 4 <= (size_t)CAP * 16;  // (T / fa / Tn / par are not in use yet)
         int32_t* lk = T.T;
         if (keys_fit)
             for (int v = tid; v < L.nv; v += TH) lk[v] = L.vkey[v];
         __syncthreads();
         Ln Lk = L;
         Lk.lkeys = keys_fit ? lk : nullptr;
-        if (T.in_hbm) {  // the LDS table of the rounds is idle while the lists are built: a dense sample of the keys (every 4th of a 128-beam scan's 72 k)
+        if constexpr (Rp<CAP>::kHbm) {  // the LDS table of the rounds is idle while the lists are built: a dense sample of the keys (every 4th of a 128-beam scan's 72 k)
             int sh = 0;  //   leaves two look-ups in HBM per row instead of seven behind the 1024 samples of the LDS passes
             while (((L.nv + (1 << sh) - 1) >> sh) > T.cap) ++sh;
             const int ns2 = (L.nv + (1 << sh) - 1) >> sh;
@@ -487,7 +493,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
     for (int x = tid; x < nn; x += TH) {
         T.T[x] = kInf;
         T.fa[x] = x < m ? L.fp[L.cvl[x]] : kInf;
-        if (T.lab) T.lab[x] = T.fa[x];
+        if constexpr (Rp<CAP>::kHbm) T.lab[x] = T.fa[x];
     }
     // the visits of node x: a voxel's first three regular points, an irregular point itself (cached); `home` = the voxel whose
     // full labelling labels the visitor before it starts
@@ -546,7 +552,7 @@ __device__ RpOut replay_class(const Ln& L, const Rp<CAP>& T, const int* set, int
             const int tv = T.Tn[x];
             changed |= tv != T.T[x];
             T.T[x] = tv;
-            if (T.lab) T.lab[x] = min(tv, T.fa[x]);
+            if constexpr (Rp<CAP>::kHbm) T.lab[x] = min(tv, T.fa[x]);
         }
         converged = !__syncthreads_or(changed);
         out.rounds = round + 1;
@@ -878,7 +884,8 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
     L.crep = (int32_t*)take(kLnNames * 4);
     unsigned char* ovl = q;  // from here on: the replay tables, overlaid by the link pairs / the candidates' blocks
     Rp<CAP> T;
-    if (GT) {
+    static_assert(GT == Rp<CAP>::kHbm, "the pass with its tables in arena scratch is the kLnCapHugeNodes one");
+    if constexpr (GT) {
         // the read-mostly class tables (times, first points, their minimum, flags: 13 bytes per node) in arena scratch -- `seg`, 4 bytes per input
         // point, dead since k_emit -- and the one the rounds hammer with atomics in LDS: the next round's times, whose room the
         // partition's parent array takes over when the rounds are done (the two are never live together)
