@@ -56,7 +56,9 @@ struct scvod_ctx {
     int32_t* t_pair = nullptr;
     int32_t* t_pairpt = nullptr;
     uint16_t* d_vb_lut = nullptr;   // A.vb_lut is set only for the duration of a VoxelGrid run
-    uint32_t* d_labels = nullptr;   // staging of the host API's label array (scvod_voxelgrid)
+    uint32_t* d_labels = nullptr;   // staging of the host API's label array (scvod_voxelgrid): side buffer
+    scvod_apri* d_apri = nullptr;   // PointAPRI records: side buffer (Arena::apri)
+    size_t side_bytes = 0;          // what ensure_side allocated so far (counted in scvod_arena_bytes)
     int32_t* t_count = nullptr;
     float* t_T = nullptr;
     int32_t* d_next_scan = nullptr;   // [cap_scans] successor table of scvod_batch_track
@@ -195,7 +197,6 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     const size_t N = (size_t)c->cap_pts, B = (size_t)c->cap_scans;
     Carver k{base};
     Arena& A = c->A;
-    c->d_in = k.take<float4>(N);
     c->d_scan_off = k.take<int32_t>(B + 1);
     A.pid = k.take<int16_t>(N);
     A.keys = k.take<uint64_t>(N);
@@ -203,7 +204,6 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.sorted_xyz = k.take<Xyz>(N + 8);
     A.sorted_idx = k.take<uint32_t>(N);
     A.zkey = k.take<uint32_t>(N);
-    c->t_pts = k.take<float4>(N);
     A.fit_thd = k.take<float>(B * kMaxPatches);
     A.order = k.take<int4>(B * kMaxPatches);
     A.order_hist = k.take<int32_t>(64);
@@ -218,7 +218,7 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.cls = k.take<uint8_t>(N);
     A.ground_idx = k.take<int32_t>(N);
     A.nonground_idx = k.take<int32_t>(N);
-    A.apri = k.take<scvod_apri>(N);
+    A.apri = c->d_apri;  // (side buffer: ensure_side; nullptr until something asks for PointAPRI records)
     A.apri_src = k.take<int32_t>(N);
     A.apri_key = k.take<int32_t>(N);
     A.apri_int = k.take<float>(N);
@@ -271,7 +271,6 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vb_lut_shift = nullptr;
     A.vg_labels = nullptr;
     A.vg_max_intensity = 1.f;
-    c->d_labels = k.take<uint32_t>(N);
     c->t_hit = k.take<int32_t>(N);
     c->t_work = k.take<uint64_t>(N);
     c->t_uniq = k.take<int32_t>(N);
@@ -416,6 +415,27 @@ static void join_lastname(scvod_ctx* c, hipStream_t st) {
     c->ln_pending = false;
 }
 
+// Buffers that only the per-scan host API, the one-shot probe, the VoxelGrid run and a fetch of PointAPRI records touch: 80 of
+// what used to be 318 bytes per point of the arena, allocated on first use (round 5: a sequence shard that stays in the batch
+// API never pays for them -- 26 GB of the seq-05 job's 104).
+enum SideBuf { kSideIn = 1, kSideTpts = 2, kSideLabels = 4, kSideApri = 8 };
+int ensure_side(scvod_ctx* c, int which) {
+    const size_t N = (size_t)c->cap_pts;
+    auto need = [&](void** p, size_t bytes) -> int {
+        if (*p) return SCVOD_OK;
+        HIPCHK(c, hipMalloc(p, bytes));
+        c->side_bytes += bytes;
+        return SCVOD_OK;
+    };
+    int rc = SCVOD_OK;
+    if ((which & kSideIn) && (rc = need((void**)&c->d_in, sizeof(float4) * N))) return rc;
+    if ((which & kSideTpts) && (rc = need((void**)&c->t_pts, sizeof(float4) * N))) return rc;
+    if ((which & kSideLabels) && (rc = need((void**)&c->d_labels, sizeof(uint32_t) * N))) return rc;
+    if ((which & kSideApri) && (rc = need((void**)&c->d_apri, sizeof(scvod_apri) * N))) return rc;
+    c->A.apri = c->d_apri;
+    return rc;
+}
+
 int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_scans, hipStream_t st,
               int do_patchwork, int apply_filter, int do_voxels, int sync, bool off_pinned = false) {
     if (!c) return SCVOD_ERR_INVALID;
@@ -437,6 +457,10 @@ int run_batch(scvod_ctx* c, const void* d_xyzi, const int32_t* h_off, int32_t n_
     c->last_stream = st;
     join_lastname(c, st);
     c->h_scan_off.assign(h_off, h_off + n_scans + 1);
+    if (do_patchwork != 1) {  // (binning without Patchwork writes the PointAPRI records, a caller's apri_vec lives in them)
+        const int rc_side = ensure_side(c, kSideApri);
+        if (rc_side) return rc_side;
+    }
     // (a caller-pinned offset table is read by the copy engine directly: nothing to wait for on the host)
     HIPCHK(c, hipMemcpyAsync(c->d_scan_off, off_pinned ? h_off : c->h_scan_off.data(), sizeof(int32_t) * (n_scans + 1), hipMemcpyHostToDevice, st));
     c->A.pts = (const float4*)d_xyzi;
@@ -502,6 +526,10 @@ int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
     out->n_rejected = k[5];
     out->n_voxels = k[6];
     out->n_patches = k[7];
+    if (c->apri_compact && k[4] > 0) {
+        const int rc_side = ensure_side(c, kSideApri);
+        if (rc_side) return rc_side;
+    }
     const Arena& A = c->A;
     hipStream_t st = c->last_stream;
     if (c->have_patchwork) launch_cls(A, s, base, k[0], st);
@@ -518,7 +546,7 @@ int fetch_scan(scvod_ctx* c, int32_t s, scvod_scan_result* out) {
                       {A.ground_idx + base, 4 * (size_t)k[1], 0},
                       {A.nonground_idx + base, 4 * (size_t)k[2], 0},
                       {A.planes + (size_t)s * kMaxPatches, sizeof(scvod_patch_plane) * (size_t)k[7], 0},
-                      {A.apri + base, sizeof(scvod_apri) * (size_t)k[4], 0},
+                      {A.apri ? A.apri + base : nullptr, A.apri ? sizeof(scvod_apri) * (size_t)k[4] : 0, 0},
                       {A.apri_src + base, 4 * (size_t)k[4], 0},
                       {A.rejected_src + base, 4 * (size_t)k[5], 0},
                       {A.vox_key + base, 4 * (size_t)k[6], 0},
@@ -563,6 +591,7 @@ int host_scan(scvod_ctx* c, const float* h_xyzi, int32_t n, int do_pw, int filt,
     if (!c || !out || n < 0 || (n > 0 && !h_xyzi)) return fail(c, SCVOD_ERR_INVALID, "bad arguments");
     if (n > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%d points > capacity %lld", n, (long long)c->cap_pts);
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc_side = ensure_side(c, kSideIn)) return rc_side;
     if (n) HIPCHK(c, hipMemcpyAsync(c->d_in, h_xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     int32_t off[2] = {0, n};
     int rc = run_batch(c, c->d_in, off, 1, c->stream, do_pw, filt, do_vox, 1);
@@ -631,6 +660,7 @@ int run_voxelgrid(scvod_ctx* c, const void* d_xyzi, const uint32_t* d_labels, co
         for (int s = 0; s < n_scans; ++s) h_out_off[s + 1] = 0;
         return SCVOD_OK;
     }
+    if (int rc_side = ensure_side(c, kSideApri)) return rc_side;  // (the centroids of a VoxelGrid run live in the PointAPRI array)
     VgJob J;
     J.labels = d_labels;
     J.max_intensity = max_intensity;
@@ -1070,6 +1100,10 @@ void scvod_destroy(scvod_ctx* c) {
         if (u.ev) hipEventDestroy(u.ev);
     }
     if (c->arena_base) hipFree(c->arena_base);
+    if (c->d_in) hipFree(c->d_in);
+    if (c->t_pts) hipFree(c->t_pts);
+    if (c->d_labels) hipFree(c->d_labels);
+    if (c->d_apri) hipFree(c->d_apri);
     if (c->chain_ws) hipFree(c->chain_ws);
     if (c->stage) hipHostFree(c->stage);
     for (void* b : c->nn_buf)
@@ -1078,7 +1112,7 @@ void scvod_destroy(scvod_ctx* c) {
 }
 
 const char* scvod_last_error(const scvod_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
-int64_t scvod_arena_bytes(const scvod_ctx* c) { return c ? (int64_t)c->arena_bytes : 0; }
+int64_t scvod_arena_bytes(const scvod_ctx* c) { return c ? (int64_t)(c->arena_bytes + c->side_bytes) : 0; }
 
 int scvod_process_scan(scvod_ctx* c, const float* h_xyzi, int32_t n, scvod_scan_result* out) {
     return host_scan(c, h_xyzi, n, 1, 1, 1, out);
@@ -1100,6 +1134,7 @@ int scvod_voxelize(scvod_ctx* c, const scvod_apri* h_apri, int32_t n, scvod_scan
     if (n > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%d points > capacity %lld", n, (long long)c->cap_pts);
     HIPCHK(c, hipSetDevice(c->device));
     const int32_t counts[8] = {n, 0, 0, 0, n, 0, 0, 0};
+    if (int rc_side = ensure_side(c, kSideApri)) return rc_side;
     if (n) HIPCHK(c, hipMemcpyAsync(c->A.apri, h_apri, sizeof(scvod_apri) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->A.counts, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1167,6 +1202,7 @@ int scvod_track_probe(scvod_ctx* c, const float* h_xyzi, const int32_t* h_offset
     // the batch's tracking result (a following scvod_batch_track uploads and decides again)
     c->up_T.clear();
     c->track_valid = false;
+    if (int rc_side = ensure_side(c, kSideTpts)) return rc_side;
     float4* d_pts = c->t_pts;
     if (n_pts) HIPCHK(c, hipMemcpyAsync(d_pts, h_xyzi, sizeof(float) * 4 * (size_t)n_pts, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->t_begin, h_offsets, sizeof(int32_t) * (n_clusters + 1), hipMemcpyHostToDevice, st));
@@ -1927,6 +1963,7 @@ int scvod_voxelgrid(scvod_ctx* c, const float* h_xyzi, const uint32_t* h_labels,
     if (n == 0) return SCVOD_OK;
     if (n > c->cap_pts) return fail(c, SCVOD_ERR_CAPACITY, "%d points > capacity %lld", n, (long long)c->cap_pts);
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc_side = ensure_side(c, kSideIn | (h_labels ? kSideLabels : 0))) return rc_side;
     HIPCHK(c, hipMemcpyAsync(c->d_in, h_xyzi, sizeof(float) * 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     if (h_labels) HIPCHK(c, hipMemcpyAsync(c->d_labels, h_labels, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     float4* d_out = (float4*)c->A.cl_bbox;  // device-side output staging: 24 bytes per point, idle outside cluster typing

@@ -4,10 +4,10 @@
 //   PatchWork::estimate_ground prologue + pc2czm   patchwork.h:277-325,416-459 -> k_pw_classify, k_pw_offsets, k_pw_scatter,
 //                                                                                  k_pw_order_*, k_pw_sort_wave, k_pw_sort<...>
 //   extract_piecewiseground / seeds / plane fit    patchwork.h:217-268,463-504 -> k_pw_fit_coop<16|64>, k_pw_fit
-//   gating + emission order                        patchwork.h:326-391         -> fit_finish, k_pw_arrange, k_emit_offsets, k_emit
+//   gating + emission order                        patchwork.h:326-391         -> fit_status / fit_finish, arrange_group (in k_pw_fit_coop), k_pw_arrange, k_emit_offsets, k_emit
 //   SSC::makeApriVec                               ssc.cpp:155-195             -> k_emit (fused, compact apri_vec), k_apri_expand,
 //                                                                                  k_bin_direct
-//   SSC::makeHashCloud                             ssc.cpp:253-289             -> k_vx_count, k_vx_offsets, k_vx_scatter, k_vx_order_*,
+//   SSC::makeHashCloud                             ssc.cpp:253-289             -> (bucket histogram: k_emit; k_vx_count without Patchwork), k_vx_offsets, k_vx_scatter, k_vx_order_*,
 //                                                                                  k_vx_bucket<...>, k_vx_final*
 //   SSC::tracking bulk part                        ssc.cpp:1274-1321           -> k_track_probe_pair, k_track_probe, k_track_unique_bits
 //   SSC::clusterAndCreateFrame (next row f-1)      ssc.cpp:299-393             -> k_cc_scan (one workgroup per scan, union-find in LDS)
@@ -457,12 +457,8 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_pw_fit, dim3((n_all + 63) / 64), dim3(64), 0, st, P, A, coop_class);
         TH_END("pw_fit");
         TH_BEGIN("pw_arrange");
-#ifndef SCVOD_NO_FUSED_ARRANGE
         // (patches of the 16-lane fit are arranged by the lanes that fitted them; what is left: the lane-per-patch fit's)
         if (coop_class > kClassWave) hipLaunchKernelGGL((k_pw_arrange<64>), dim3(kPersistCUs * 8), dim3(256), 0, st, P, A, kClassWave, coop_class - 1);
-#else
-        hipLaunchKernelGGL((k_pw_arrange<64>), dim3(kPersistCUs * 8), dim3(256), 0, st, P, A, kClassWave, 63);
-#endif
         hipLaunchKernelGGL((k_pw_arrange<16>), dim3(kPersistCUs * 4), dim3(256), 0, st, P, A, 0, kClassWave - 1);
         TH_END("pw_arrange");
         TH_BEGIN("emit_offsets");
