@@ -17,7 +17,7 @@ static map out, everything on the device through the C-ABI (libscvod.so):
     -> curved-voxel clustering -> bounding boxes + type rules                             scvod_batch_cluster(_types)
     -> scan-vs-next-scan differencing: probe, remap_name, state rule, the reference's     scvod_batch_track
        SEQUENTIAL re-labelling chain (scan i against scan i + skip_), per-point byte
-    -> (N > 1, a sequence cut over ranks) the chain states at the cuts: one exchange,     shard.resolve_chain_boundaries
+    -> (N > 1, a sequence cut over ranks) the chain states at the cuts: one exchange,     shard.DeviceBoundary
        compared on the device; a rank walks its chains again only if the verdict says so
     -> world-frame static map of the rank's scans                                         scvod_batch_map_accumulate
     -> (N > 1) the map reduce-scattered over RCCL: records grouped by owner rank in       scvod_map_export_parts_padded,
@@ -186,6 +186,12 @@ def main():
     # N > 1: the path shards the scans of ONE sequence (BASELINE north_star: strong scaling of configs[1]) unless told otherwise
     if world > 1 and not args.replicate and not args.sequences and not args.kitti:
         args.split_sequence = True
+    side = None
+    if dist is not None and world > 1 and args.split_sequence and args.backend == "nccl":
+        # the host-driven boundary protocol (the untimed sizing pass; a step whose device verdict says a chain has to be walked
+        # again): its records travel staged through the host on a gloo group -- plain blocking sends and receives between
+        # neighbours, the path the same-device tests cover; the per-step exchange itself is on RCCL (shard.DeviceBoundary)
+        side = dist.new_group(backend="gloo")
     multi = dist is not None  # the N > 1 step (also at one rank with --force-dist: RCCL initialised, device collectives executed)
     import scvod_py
     import shard
@@ -305,7 +311,7 @@ def main():
             return
         if devb.verdict_wait() != 0:
             info["boundary_slow_path_steps"] = info.get("boundary_slow_path_steps", 0) + 1
-            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
             map_part(False)
 
     def step(timed=False):
@@ -335,7 +341,7 @@ def main():
         elif split and world > 1:  # gloo dry run: records staged through the host, from rank to rank, walked again where the warm-up missed it
             torch.cuda.synchronize()  # (the exchange starts when this rank's chain is done: its host time is the exchange's alone)
             t_b = time.perf_counter()
-            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            info["chains_rewalked_at_boundary"] = info.get("chains_rewalked_at_boundary", 0) + shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
             info["boundary_ms"] = (time.perf_counter() - t_b) * 1e3
         map_part(timed)
         if devb is not None:
@@ -365,7 +371,7 @@ def main():
     if multi and smap is not None:
         smap.clear(stream=stream)
         if split and world > 1:
-            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev)
+            shard.resolve_chain_boundaries(dist, ctx, split, rank, world, dev, group=side)
         for f0, c0 in own_spans:
             smap.accumulate_range(ctx, poses, f0, c0, stream=stream)
         _, counts0 = smap.export_parts(world, stream=stream)
