@@ -1720,6 +1720,11 @@ int scvod_batch_track_stats(scvod_ctx* c, int32_t* h_out8) {
     h_out8[5] = c->chain_seg_used;
     h_out8[6] = c->chain_warm_used;
     h_out8[7] = 0;
+    if (c->chain_ran && c->max_name_literal && c->last_name_valid) {  // scans whose max_name the clustering could not determine: the chain handed out a fresh number there
+        int32_t ls[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpy(ls, c->A.ln_stats, sizeof(ls), hipMemcpyDeviceToHost));
+        h_out8[7] = ls[0] + ls[1];
+    }
 #ifdef SCVOD_PROFILE
     fprintf(stderr, "[chain phases, 10 ns ticks summed over walkers x steps] fetch %d  carried %d  eval %d  walk+state %d  copy %d\n", st[3], st[4], st[5], st[6], st[7]);
     if (c->chain_ran) {

@@ -2,6 +2,7 @@
 // the HIP kernels; this file converts between the reference's containers (pcl::PointCloud,
 // std::vector<PointAPRI>, unordered_map<int, Voxel>) and the POD arrays of the boundary, and keeps the
 // sequential label bookkeeping of SSC::tracking (src/ssc.cpp:1323-1421) on the host.
+#include <cstdio>
 #include "ssc.h"
 
 #include <dirent.h>
@@ -189,6 +190,8 @@ void SSC::segmentGpu() {
     int32_t last[4] = {-1, -1, 0, 0};
     rc = scvod_batch_cluster_last_name(ctx_, last, 1, nullptr);
     if (rc < 0) chk(ctx_, rc, "scvod_batch_cluster_last_name");
+    if (last[2] != 0)  // (status 1 / 2: include/scvod.h) the reference would re-use the number of a cluster this scan could not name
+        std::fprintf(stderr, "[scvod] max_name of this scan is undetermined (status %d): new clusters get fresh numbers\n", (int)last[2]);
     frame_ssc.name_floor = n + 6;  // (above every canonical name + 5, erased clusters included)
     frame_ssc.max_name = last[0] >= 0 ? last[0] + 5 : frame_ssc.name_floor;
     frame_ssc.hash_cloud = hash_cloud;  // ssc.cpp:651

@@ -515,7 +515,7 @@ class Ctx:
         out = np.zeros(8, np.int32)
         self._chk(self.lib.scvod_batch_track_stats(self.h, out.ctypes.data_as(C.c_void_p)))
         return dict(chain=bool(out[0]), segments=int(out[1]), verified=int(out[2]), rewalked=int(out[3]), error_bits=int(out[4]),
-                    segment_steps=int(out[5]), warmup_steps=int(out[6]))
+                    segment_steps=int(out[5]), warmup_steps=int(out[6]), max_name_undetermined=int(out[7]))
 
     def batch_track_tables(self, stream=None):
         self._chk(self.lib.scvod_batch_track_tables(self.h, C.c_void_p(stream or 0)))

@@ -338,7 +338,9 @@ int scvod_batch_track_compare(scvod_ctx* ctx, const void* const* h_d_states, int
  * Asynchronous on `stream`; nothing is changed.  h_d_states is copied before the call returns. */
 int scvod_batch_track_compare_device(scvod_ctx* ctx, const void* const* h_d_states, int32_t n_states, int32_t* d_differ, void* stream);
 /* h_out8 = {mode the last scvod_batch_track ran, segments (workgroups), segments verified against their predecessor's
- * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, 0}.  Synchronises.
+ * end state, segments walked again after that check failed, error bits, segment_steps, warmup_steps, scans of the batch whose
+ * Frame::max_name the clustering could not determine (scvod_batch_cluster_last_name status 1 / 2: the chain handed out a fresh
+ * cluster number there where the reference re-uses the last one)}.  Synchronises.
  * Returns SCVOD_ERR_CAPACITY when a chain state did not fit the walkers' workspace (the result is then invalid). */
 int scvod_batch_track_stats(scvod_ctx* ctx, int32_t* h_out8);
 

@@ -77,6 +77,7 @@ def test_chain_with_the_literal_max_name(scvod, oracle, kind, preset, skip, coun
     # the oracle's own reading of which cluster carries K, scan by scan; where the device reported "unknown" the chain used none
     collide = np.asarray([oracle.cluster_last_name(P, r["apri"])[0] for r in res], np.int32)
     known = ln[:, 2] == 0
+    assert known.all()  # (round 5: also on the 128-beam sample -- the comparison with the literal chain below is independent of the device's answer)
     for s in np.nonzero(known)[0]:  # (none for an erased cluster: see test_last_name_equals_the_literal_loop)
         assert ln[s, 0] == collide[s] or (ln[s, 0] == -1 and types[s][collide[s]] == -1)
     collide[~known] = -1
