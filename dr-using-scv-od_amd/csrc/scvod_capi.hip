@@ -229,7 +229,6 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.irr_list = k.take<int32_t>(B * (kIrrListCap + 1));
     A.cc_perm = k.take<int32_t>(B);
     A.vb_count = k.take<int32_t>(B * kMaxBuckets);
-    A.vb_cursor = k.take<int32_t>(B * kMaxBuckets);
     A.vb_off = k.take<int32_t>(B * (kMaxBuckets + 1));
     A.vb_nvox = k.take<int32_t>(B * kMaxBuckets);
     A.vox_off = k.take<int32_t>(B * (kMaxBuckets + 1));

@@ -91,7 +91,6 @@ struct Arena {
     int32_t* cc_perm;         // [B] order in which k_cc_scan takes the scans: the irregular ones (the long-running workgroups) first
     // voxel stage
     int32_t* vb_count;        // [B][kMaxBuckets]
-    int32_t* vb_cursor;       // [B][kMaxBuckets]
     int32_t* vb_off;          // [B][kMaxBuckets+1]
     int32_t* vb_nvox;         // [B][kMaxBuckets]
     int32_t* vox_off;         // [B][kMaxBuckets+1]

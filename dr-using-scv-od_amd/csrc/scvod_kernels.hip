@@ -7,7 +7,7 @@
 //   gating + emission order                        patchwork.h:326-391         -> fit_status / fit_finish, arrange_group (in k_pw_fit_coop), k_pw_arrange, k_emit_offsets, k_emit
 //   SSC::makeApriVec                               ssc.cpp:155-195             -> k_emit (fused, compact apri_vec), k_apri_expand,
 //                                                                                  k_bin_direct
-//   SSC::makeHashCloud                             ssc.cpp:253-289             -> (bucket histogram: k_emit; k_vx_count without Patchwork), k_vx_offsets, k_vx_scatter, k_vx_order_*,
+//   SSC::makeHashCloud                             ssc.cpp:253-289             -> k_vx_partition (count + offsets + scatter per scan), k_vx_order_*,
 //                                                                                  k_vx_bucket<...>, k_vx_final*
 //   SSC::tracking bulk part                        ssc.cpp:1274-1321           -> k_track_probe_pair, k_track_probe, k_track_unique_bits
 //   SSC::clusterAndCreateFrame (next row f-1)      ssc.cpp:299-393             -> k_cc_scan (one workgroup per scan, union-find in LDS)
@@ -464,7 +464,6 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         TH_BEGIN("emit_offsets");
         hipLaunchKernelGGL(k_emit_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("emit_offsets");
-        if (do_voxels) hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);  // (k_emit counts the voxel stage's buckets)
         TH_BEGIN("emit");
         hipLaunchKernelGGL(k_emit, dim3(kPersistCUs * 8), dim3(kEmitThreads), 0, st, P, A);
         TH_END("emit");
@@ -479,20 +478,9 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
             hipMemsetAsync(A.irr_list, 0xff, sizeof(int32_t) * (size_t)B * (kIrrListCap + 1), st);  // (-1: irregular points not listed)
             hipLaunchKernelGGL(k_apri_split, dim3((A.max_scan_pts + 2047) / 2048, B), dim3(256), 0, st, A);
         }
-        hipMemsetAsync(A.vb_cursor, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
-        dim3 gv((A.max_scan_pts + kVxThreads * kVxItems - 1) / (kVxThreads * kVxItems), B);
-        if (do_patchwork != 1) {  // (after Patchwork k_emit has counted the buckets already)
-            hipMemsetAsync(A.vb_count, 0, sizeof(int32_t) * (size_t)B * kMaxBuckets, st);
-            TH_BEGIN("vx_count");
-            hipLaunchKernelGGL(k_vx_count, gv, dim3(kVxThreads), 0, st, P, A);
-            TH_END("vx_count");
-        }
-        TH_BEGIN("vx_offsets");
-        hipLaunchKernelGGL(k_vx_offsets, dim3(B), dim3(1024), 0, st, P, A);
-        TH_END("vx_offsets");
-        TH_BEGIN("vx_scatter");
-        hipLaunchKernelGGL(k_vx_scatter, gv, dim3(kVxThreads), 0, st, P, A);
-        TH_END("vx_scatter");
+        TH_BEGIN("vx_partition");
+        hipLaunchKernelGGL(k_vx_partition, dim3(B), dim3(1024), 0, st, P, A);
+        TH_END("vx_partition");
         dim3 gb(P.n_buckets, B);
         hipMemsetAsync(A.vorder_hist, 0, sizeof(int32_t) * 64, st);
         hipMemsetAsync(A.vorder_cursor, 0, sizeof(int32_t) * 64, st);
