@@ -144,3 +144,18 @@ def test_kitti_job_scaled_down_over_eight_ranks(tmp_path):
     assert np.array_equal(m1["dynamic_points"], m8["dynamic_points"])
     assert np.array_equal(m1["keys"], m8["keys"]) and np.array_equal(m1["vals"], m8["vals"])
     assert eight["config"]["split"]["chains_rewalked_at_boundary_all_ranks"] is not None
+
+
+def test_os128_sequence_over_four_ranks(tmp_path):
+    """BASELINE configs[4]'s multi-GPU leg as a dry run: a 128-beam sequence (258 k returns per scan, the 2x finer grid: the generic
+    clustering variant, the max_name passes beyond the LDS tables) cut over four gloo ranks of one device with a short halo -- a
+    rank whose warm-up misses the state at its cut walks its chains again from the state it receives.  Per-scan dynamic points
+    and the merged map equal the one-rank run."""
+    common = ["--kind", "OS128", "--preset", "os128_fine", "--scans", "64"]
+    one, m1 = _run_k64(str(tmp_path), "one", ["--gpus", "1"] + common)
+    four, m4 = _run_k64(str(tmp_path), "four", ["--gpus", "4", "--same-device", "--split-halo", "3"] + common)
+    assert four["n_gpus"] == 4 and four["scaling"] == "strong" and four["config"]["split"]["own"] == 16
+    assert np.array_equal(m1["scans"], m4["scans"]) and len(m4["scans"]) == 64
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m4["dynamic_points"])
+    assert np.array_equal(m1["keys"], m4["keys"]) and np.array_equal(m1["vals"], m4["vals"])
