@@ -384,7 +384,6 @@ constexpr int kSortCapXL = 16384, kClassXL = 52;  // n >= 8192 (pw_size_class)
 constexpr size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8; }
 constexpr int kVoxCapS = 1024, kVoxThreadsS = 64;
 constexpr int kVoxCapL = 8192, kVoxThreadsL = 512;
-constexpr size_t vox_lds_bytes(int cap) { return (size_t)(cap + cap / 8) * 8 + (size_t)cap * 8 + 128; }
 
 void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_patchwork, int apply_filter,
                     int do_voxels, TimerHook th, void* tu) {
@@ -510,28 +509,30 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         }
         auto bucket_tiers = [&](auto kt) {
             using KT = decltype(kt);
+            constexpr size_t KS = sizeof(KT);
+            constexpr int kMore = (KS == 4 && SCVOD_VOX_K32_LDS) ? 3 : 2;  // workgroups per CU of the 4096 tier (x2, x4 for the next two)
             hipFuncSetAttribute((const void*)k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv, 0, KT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(kVoxCapL, KS));
             hipFuncSetAttribute((const void*)k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 0, KT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_lds_bytes(4096, KS));
             TH_BEGIN("vx_bucket_8192");
             hipLaunchKernelGGL((k_vx_bucket<kVoxCapL, kVoxThreadsL * kTSv, kClassL, 63, kLGEv, 0, KT>), dim3(kPersistCUs), dim3(kVoxThreadsL * kTSv),
-                               vox_lds_bytes(kVoxCapL), st, P, A);
+                               vox_lds_bytes(kVoxCapL, KS), st, P, A);
             TH_END("vx_bucket_8192");
             TH_BEGIN("vx_bucket_4096");
-            hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 0, KT>), dim3(kPersistCUs * 2), dim3(256 * kTSv),
-                               vox_lds_bytes(4096), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<4096, 256 * kTSv, kClassM2, kClassL - 1, kLGEv, 0, KT>), dim3(kPersistCUs * kMore), dim3(256 * kTSv),
+                               vox_lds_bytes(4096, KS), st, P, A);
             TH_END("vx_bucket_4096");
             TH_BEGIN("vx_bucket_2048");
-            hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv, 0, KT>), dim3(kPersistCUs * 4), dim3(128 * kTSv),
-                               vox_lds_bytes(2048), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<2048, 128 * kTSv, kClassM, kClassM2 - 1, kLGEv, 0, KT>), dim3(kPersistCUs * kMore * 2), dim3(128 * kTSv),
+                               vox_lds_bytes(2048, KS), st, P, A);
             TH_END("vx_bucket_2048");
             TH_BEGIN("vx_bucket_1024");
             hipLaunchKernelGGL((k_vx_bucket<kVoxCapS, kVoxThreadsS * kTSv, kClassXS, kClassM - 1, kLGEv, 0, KT>), dim3(kPersistCUs * 8),
-                               dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS), st, P, A);
+                               dim3(kVoxThreadsS * kTSv), vox_lds_bytes(kVoxCapS, KS), st, P, A);  // (twelve per CU measured slower than eight)
             TH_END("vx_bucket_1024");
             TH_BEGIN("vx_bucket_256");
-            hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3, 0, KT>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256), st, P, A);
+            hipLaunchKernelGGL((k_vx_bucket<256, 64, 0, kClassXS - 1, 3, 0, KT>), dim3(kPersistCUs * 32), dim3(64), vox_lds_bytes(256, KS), st, P, A);
             TH_END("vx_bucket_256");
         };
         if (A.vx_k32)

@@ -78,6 +78,10 @@ __device__ __forceinline__ unsigned long long map_mix(unsigned long long k) {  /
     return k;
 }
 
+// home slot of a cell: a hash of the whole cell.  (Blocks of neighbouring cells laid side by side in the table were measured in rounds 3
+// and 5, from 2 x 2 x 1 to 4 x 4 x 4 cells: every one slower -- profiles/r05_experiments.md.)
+__device__ __forceinline__ unsigned long long map_home(unsigned long long key, unsigned long long mask) { return map_mix(key) & mask; }
+
 // cell + packed in-cell offset of a world point.  floor(p * inv_leaf) like pcl::VoxelGrid's cell index; the offset is
 // quantised to 16 bits of the cell edge, the intensity to 1/256 (clamped to [0, 255.996]).
 __device__ __forceinline__ bool map_encode(float x, float y, float z, float intensity, float inv_leaf, unsigned long long& key,
@@ -134,7 +138,7 @@ __device__ __forceinline__ bool map_insert_from(MapRec* table, unsigned long lon
     return false;
 }
 __device__ __forceinline__ bool map_insert(MapRec* table, unsigned long long mask, unsigned long long key, unsigned long long val) {
-    const unsigned long long h = map_mix(key) & mask;
+    const unsigned long long h = map_home(key, mask);
     return map_insert_from(table, mask, key, val, h, map_peek(table, h));
 }
 
@@ -163,9 +167,13 @@ __global__ __launch_bounds__(256) void k_map_accumulate(int s_first, Arena A, co
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = min(i0 + u * 256 + (int)threadIdx.x, n - 1);
-            pid[u] = have_pid ? (int)A.pid[(size_t)base + i] : 0;
-            cls[u] = marks ? A.pt_mapcls[(size_t)base + i] : (uint8_t)0;
-            q[u] = A.pts[base + i];
+            // the scan is read once: non-temporal loads keep it out of the way of the table's sectors in L2 (4.59 -> 4.39 / 4.61 -> 4.57 ms)
+            pid[u] = have_pid ? (int)__builtin_nontemporal_load(&A.pid[(size_t)base + i]) : 0;
+            cls[u] = marks ? __builtin_nontemporal_load(&A.pt_mapcls[(size_t)base + i]) : (uint8_t)0;
+            const float* pp = reinterpret_cast<const float*>(&A.pts[base + i]);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v v4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(pp));
+            q[u] = make_float4(v4.x, v4.y, v4.z, v4.w);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) pcnt[u] = have_pid ? A.patch_count[s * kMaxPatches + max(pid[u], 0)] : 0;
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256) void k_map_accumulate(int s_first, Arena A, co
                 if (lane + d < run_end && o < val[u]) val[u] = o;
             }
             need[u] = head && key[u] != kEmpty;
-            h[u] = map_mix(key[u]) & mask;
+            h[u] = map_home(key[u], mask);
         }
         MapRec first[U];
 #pragma unroll
