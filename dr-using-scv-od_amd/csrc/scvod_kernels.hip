@@ -543,7 +543,7 @@ void launch_process(const DevParams& P, const Arena& A, hipStream_t st, int do_p
         hipLaunchKernelGGL(k_vx_final_offsets, dim3(B), dim3(1024), 0, st, P, A);
         TH_END("vx_final_offsets");
         TH_BEGIN("vx_final");
-        hipLaunchKernelGGL(k_vx_final, gb, dim3(256), 0, st, P, A);
+        hipLaunchKernelGGL(k_vx_final, dim3((P.n_buckets + 3) / 4, B), dim3(256), 0, st, P, A);
         TH_END("vx_final");
     }
 }

@@ -314,16 +314,30 @@ __global__ __launch_bounds__(256) void k_tk_dyn(Arena A, int from_apri) {
     const int s = blockIdx.y;
     const int base = A.scan_off[s];
     const int n = A.counts[s * 8 + 4];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int t = A.pt_type[(size_t)base + i];
-        uint8_t d = SCVOD_DYN_STATIC;
-        if (t == 0)
-            d = SCVOD_DYN_UNCLUSTERED;
-        else if (t == 2 && A.cl_state[(size_t)base + A.pt_cluster[(size_t)base + i]] == 1)
-            d = SCVOD_DYN_DYNAMIC;
-        A.pt_dyn[(size_t)base + i] = d;
-        // the static map's mark of a car point: plain store, so that a second tracking run over the same clustering starts clean
-        if (!from_apri && t == 2) A.pt_mapcls[(size_t)base + A.apri_src[(size_t)base + i]] = (uint8_t)(kMapCar | (d == SCVOD_DYN_DYNAMIC ? kMapDynamic : 0));
+    // four points per thread in flight: the chain type -> cluster -> state is three dependent loads deep
+    constexpr int U = 4;
+    for (int i0 = blockIdx.x * (256 * U) + threadIdx.x; i0 < n; i0 += gridDim.x * (256 * U)) {
+        int t[U], c[U];
+        int8_t st[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = A.pt_type[(size_t)base + min(i0 + u * 256, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = (t[u] == 2) ? A.pt_cluster[(size_t)base + min(i0 + u * 256, n - 1)] : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) st[u] = (t[u] == 2) ? A.cl_state[(size_t)base + c[u]] : (int8_t)0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            if (i >= n) break;
+            uint8_t d = SCVOD_DYN_STATIC;
+            if (t[u] == 0)
+                d = SCVOD_DYN_UNCLUSTERED;
+            else if (t[u] == 2 && st[u] == 1)
+                d = SCVOD_DYN_DYNAMIC;
+            A.pt_dyn[(size_t)base + i] = d;
+            // the static map's mark of a car point: plain store, so that a second tracking run over the same clustering starts clean
+            if (!from_apri && t[u] == 2) A.pt_mapcls[(size_t)base + A.apri_src[(size_t)base + i]] = (uint8_t)(kMapCar | (d == SCVOD_DYN_DYNAMIC ? kMapDynamic : 0));
+        }
     }
 }
 
