@@ -389,7 +389,7 @@ def main():
         # above 2.2 x the cells the job really occupies (load <= 0.45; measured: a table at load 0.46 costs the accumulation more than its smaller clear saves); the per-step clear shrinks with it
         occupied = max(smap.count(), pmap.count() if pmap is not None else 0)
         want = 1 << int(np.ceil(np.log2(max(2.2 * occupied, 1 << 20))))
-        if want < cells:
+        if want != cells:  # (smaller: the usual case; larger: sparse scans whose first table -- a quarter of the points -- ran above load 0.45)
             smap.close()
             smap = scvod_py.StaticMap(want, leaf=args.map_leaf, device=local)
             if pmap is not None:
