@@ -3,6 +3,7 @@
 // This is a test helper: the product never runs these on the CPU.
 #include "../../dr-using-scv-od_amd/csrc/scvod_math.h"
 #include <cmath>
+#include <cstring>
 extern "C" {
 float spec_atan2f(float y, float x) { return scvod::atan2_f32(y, x); }
 double spec_atan2(double y, double x) { return scvod::atan2_f64(y, x); }
@@ -26,6 +27,27 @@ double spec_cmp_atan2(const double* y, const double* x, long n) {
         long long ua = (long long)scvod::d2u(a), ub = (long long)scvod::d2u(b);
         double d = (double)(ua > ub ? ua - ub : ub - ua);
         if (d > worst) worst = d;
+    }
+    return worst;
+}
+// the branch-free angle estimate of czm_patch_of: largest |atan01_poly(t) - atan(t)| over the floats [bits_lo, bits_hi] (as bit patterns
+// of non-negative floats, both inclusive), and largest |atan2_abs_rad_fast(|y|, x) - atan2(|y|, x)| over n points
+double spec_atan01_worst(unsigned bits_lo, unsigned bits_hi, unsigned step) {
+    double worst = 0;
+    for (unsigned long b = bits_lo; b <= bits_hi; b += step) {
+        float t;
+        const unsigned u = (unsigned)b;
+        std::memcpy(&t, &u, 4);
+        const double e = std::fabs((double)scvod::atan01_poly(t) - std::atan((double)t));
+        if (e > worst) worst = e;
+    }
+    return worst;
+}
+double spec_atan2_abs_worst(const float* ay, const float* x, long n) {
+    double worst = 0;
+    for (long i = 0; i < n; ++i) {
+        const double e = std::fabs((double)scvod::atan2_abs_rad_fast(ay[i], x[i]) - std::atan2((double)ay[i], (double)x[i]));
+        if (e > worst) worst = e;
     }
     return worst;
 }

@@ -96,6 +96,30 @@ def test_apri_spec_equals_oracle_binning(spec, oracle, scvod):
             assert bool(keep) == (i in keep_set)
 
 
+def test_angle_estimate_stays_inside_its_error_bound(spec):
+    """czm_patch_of trusts atan2_abs_rad_fast wherever theta / sector_size is farther than 4e-6 rad from an integer: the estimate has
+    to stay within the 6.1e-7 rad its header claims.  The polynomial over every 64th float of [0, 1] plus ALL floats of the stretch
+    around its worst point (the exhaustive run over all 2^30 floats found 1.05e-7 rad at t = 0.98361367: a minute of CPU, done once),
+    the whole estimate on points of every octant (host arithmetic: an exact quotient where the device takes v_rcp_f32, whose 1 ulp is
+    1.2e-7 of the bound)."""
+    spec.spec_atan01_worst.restype = C.c_double
+    spec.spec_atan2_abs_worst.restype = C.c_double
+    one = int(np.float32(1.0).view(np.uint32))
+    assert spec.spec_atan01_worst(C.c_uint(0), C.c_uint(one), C.c_uint(64)) <= 1.06e-7
+    lo, hi = int(np.float32(0.97).view(np.uint32)), int(np.float32(0.995).view(np.uint32))
+    w = spec.spec_atan01_worst(C.c_uint(lo), C.c_uint(hi), C.c_uint(1))
+    assert 1.0e-7 < w <= 1.06e-7
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    ay = np.abs(rng.choice([1e-3, 0.1, 1.0, 30.0, 80.0], n) * rng.uniform(0.01, 1.0, n)).astype(np.float32)
+    x = (rng.choice([-1, 1], n) * rng.choice([1e-3, 0.1, 1.0, 30.0, 80.0], n) * rng.uniform(0.0, 1.0, n)).astype(np.float32)
+    ay[ay == 0] = 1e-3
+    x[:1000] = 0.0
+    x[1000:2000] = ay[1000:2000]
+    x[2000:3000] = -ay[2000:3000]
+    assert spec.spec_atan2_abs_worst(ay.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_long(n)) <= 4.9e-7
+
+
 def test_patch_ids_spec_equals_libm_oracle(spec, oracle, scvod):
     """pc2czm zone / ring / sector of the spec (fp32 atan2 fast path + fp64 fdlibm fall-back) == the oracle's
     glibc-double evaluation, including points a few 1e-7 rad away from sector boundaries and on the axes."""
