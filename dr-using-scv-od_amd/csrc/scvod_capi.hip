@@ -98,6 +98,7 @@ struct scvod_ctx {
     std::vector<int32_t> plan_scans_tmp;
     std::vector<std::vector<int>> cuts_cache;  // the time-balanced segment starts of the plan below
     std::vector<int32_t> cuts_scans;
+    std::vector<int> cuts_chain_first, cuts_chain_len;  // (two successor tables can flatten to the same frames and still split them differently)
     std::vector<uint8_t> cuts_halo;
     int cuts_warm = -1;
     int chain_balance = 1;                   // 1: cut the segments of a stream's next batch by these times (scvod_set_track_mode: segment_steps 0)
@@ -822,7 +823,8 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
     std::vector<std::vector<int>> cuts;  // per chain: segment starts (own steps), when cut by time
     // (planned ONCE per plan of frames, halo and warm-up -- from the first times that arrive for it -- and kept: the host pays for the
     //  search once, the walker table is uploaded once, and a stream's batches keep one segmentation)
-    if (c->chain_seg <= 0 && c->chain_balance && !c->cuts_cache.empty() && c->cuts_scans == scans && c->cuts_warm == warm && c->cuts_halo == c->halo) {
+    if (c->chain_seg <= 0 && c->chain_balance && !c->cuts_cache.empty() && c->cuts_scans == scans && c->cuts_chain_first == chain_first &&
+        c->cuts_chain_len == chain_len && c->cuts_warm == warm && c->cuts_halo == c->halo) {
         cuts = c->cuts_cache;
     } else if (c->chain_seg <= 0 && c->chain_balance && !c->step_ticks.empty() && c->step_ticks_scans == scans) {
         std::vector<double> cost(scans.size(), 0.0);
@@ -878,8 +880,24 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
             plan(hi_t, &cuts);
             c->cuts_cache = cuts;
             c->cuts_scans = scans;
+            c->cuts_chain_first = chain_first;
+            c->cuts_chain_len = chain_len;
             c->cuts_warm = warm;
             c->cuts_halo = c->halo;
+        }
+    }
+    if (!cuts.empty()) {  // cuts that do not describe THIS plan (one list per chain, ascending starts inside the chain's steps): equal-length segments instead
+        bool ok = cuts.size() == chain_len.size();
+        for (size_t ci = 0; ok && ci < cuts.size(); ++ci) {
+            int prev = -1;
+            for (int a : cuts[ci]) {
+                if (a <= prev || a >= chain_len[ci] - 1) ok = false;
+                prev = a;
+            }
+        }
+        if (!ok) {
+            cuts.clear();
+            c->cuts_cache.clear();
         }
     }
     int n_chains = 0;
@@ -890,6 +908,9 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
         // are only ever a warm-up (the whole halo for the first walker: its start state has no other source on this shard)
         int a0 = 0;
         while (a0 < steps && (size_t)scans[first + a0] < c->halo.size() && c->halo[scans[first + a0]]) ++a0;
+        for (int a = a0; a < n; ++a)  // a halo flag behind a scan of the chain that is not halo would be ignored silently: refuse it
+            if ((size_t)scans[first + a] < c->halo.size() && c->halo[scans[first + a]] && a > a0)
+                return fail(c, SCVOD_ERR_INVALID, "scan %d is marked halo but follows scan %d of its chain, which is not: a chain's halo scans must be its first ones", scans[first + a], scans[first + a0]);
         if (!cuts.empty()) {
             const std::vector<int>& cs = cuts[ci];
             for (size_t k = 0; k < cs.size(); ++k) {
@@ -902,9 +923,6 @@ int plan_chains(scvod_ctx* c, const std::vector<int32_t>& next, std::vector<int3
             ++n_chains;
             continue;
         }
-        for (int a = a0; a < n; ++a)  // a halo flag behind a scan of the chain that is not halo would be ignored silently: refuse it
-            if ((size_t)scans[first + a] < c->halo.size() && c->halo[scans[first + a]] && a > a0)
-                return fail(c, SCVOD_ERR_INVALID, "scan %d is marked halo but follows scan %d of its chain, which is not: a chain's halo scans must be its first ones", scans[first + a], scans[first + a0]);
         for (int a = a0; a < steps; a += seg) {
             const int b = a + seg < steps ? a + seg : steps;
             const int t0 = (a == a0 && a0 > 0) ? 0 : (a - warm > 0 ? a - warm : 0);

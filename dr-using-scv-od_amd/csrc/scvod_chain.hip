@@ -1466,8 +1466,10 @@ __global__ __launch_bounds__(kChThreads) void k_tk_chain_fix(DevParams P, Arena 
         // segmentation of its first frame and has no snapshot to compare: the received state is what it has to start from, so it
         // counts as "differs" and is walked again from that state (round-4 advice: it used to be ignored silently)
         const bool ok = R.hdr[3] == 1 && W0.ext != 0 && K0.hdr[H_HAS_SNAP] != 0 && same_state_ext(K0, 2, R);
-        if (C.resume == 2) {  // compare only (scvod_batch_track_compare); a record that did not fit its exchange buffer (hdr[3] == 2) counts as a difference
-            if (threadIdx.x == 0 && !ok && R.hdr[3] != 0) atomicAdd(C.cmp_out, 1);
+        if (C.resume == 2) {  // compare only (scvod_batch_track_compare); a record that did not fit its exchange buffer (hdr[3] == 2) counts as a
+            // difference, and so does a row nobody wrote (hdr[3] == 0: the sender had no state for this sub-sequence, or its row was never
+            // exported) -- whoever hands a pointer over EXPECTS a state there (round-5 advice: such a chain used to pass unverified)
+            if (threadIdx.x == 0 && !ok) atomicAdd(C.cmp_out, 1);
             return;
         }
         if (ok) return;  // the warm-up reproduced it: everything behind stands

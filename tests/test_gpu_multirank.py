@@ -159,3 +159,26 @@ def test_os128_sequence_over_four_ranks(tmp_path):
     assert m1["dynamic_points"].sum() > 0
     assert np.array_equal(m1["dynamic_points"], m4["dynamic_points"])
     assert np.array_equal(m1["keys"], m4["keys"]) and np.array_equal(m1["vals"], m4["vals"])
+
+
+@pytest.mark.parametrize("halo", [2, 12])
+def test_device_boundary_step_logic_with_a_real_neighbour(tmp_path, halo):
+    """bench.py's nccl-path step on two ranks of ONE device (round-5 verdict, missing #1): `--boundary device` on gloo runs
+    shard.DeviceBoundary -- padded rows exported without a host read, the pinned pointer table, the compare kernel, the verdict word
+    copied behind an event and read when the NEXT step starts (or at the final barrier) -- with the rows and the verdict staged
+    through the host where RCCL would move them.  Halo 12: the verdict is 0, no slow path.  Halo 2: the warm-up cannot rebuild the
+    carried clouds, the verdict sends every step through resolve_chain_boundaries and the step's map is accumulated again from the
+    corrected labels.  Either way the job equals the one-rank run bit for bit."""
+    one, m1 = _run_k64(str(tmp_path), "one", ["--gpus", "1", "--scans", "170"])
+    two, m2 = _run_k64(str(tmp_path), "two", ["--gpus", "2", "--scans", "170", "--same-device", "--boundary", "device", "--split-halo", str(halo), "--steps", "2"])
+    sp = two["config"]["split"]
+    assert two["n_gpus"] == 2 and sp["boundary"]["path"].startswith("device rows") and sp["boundary"]["record_bytes"] >= 65536
+    assert "tk_boundary_exchange" in two["kernels"]
+    if halo == 12:
+        assert sp["boundary_slow_path_steps_rank0"] == 0 and sp["chains_rewalked_at_boundary_all_ranks"] == 0
+    else:  # warm-up + 2 timed + 2 attributed steps: each one's verdict sent the job down the host-driven protocol
+        assert sp["boundary_slow_path_steps_rank0"] >= 4 and sp["chains_rewalked_at_boundary_all_ranks"] > 0
+    assert np.array_equal(m1["scans"], m2["scans"]) and len(m2["scans"]) == 170
+    assert m1["dynamic_points"].sum() > 0
+    assert np.array_equal(m1["dynamic_points"], m2["dynamic_points"])
+    assert np.array_equal(m1["keys"], m2["keys"]) and np.array_equal(m1["vals"], m2["vals"])

@@ -136,3 +136,73 @@ def test_three_shards_with_random_cuts_and_halos(scvod, oracle, seed):
             assert np.array_equal(got, want[s]), (seed, cuts, halos, differs, k, s, int((got != want[s]).sum()))
             assert np.array_equal(got, ref[s]), (seed, cuts, halos, "oracle chain", k, s, int((got != ref[s]).sum()))
         sh.close()
+
+
+@pytest.mark.parametrize("halo_steps", [0, 1, 12])
+def test_device_compare_path_with_a_real_neighbour(scvod, halo_steps):
+    """The leg of shard.DeviceBoundary that no one-rank run executes (round-5 verdict, missing #1): shard A exports the state every
+    chain ENDED in into fixed-size PADDED rows without a word read on the host (chain_export_state_into), a device copy send -> recv
+    stands in for the RCCL point-to-point transfer, shard B runs the compare kernel on the rows through the pinned pointer table and
+    ADDS its verdict to a device word (batch_track_compare_device).  The word equals the host compare of the exact-size records; a
+    chain whose pointer is None is ignored; a row too small for its state (header word 3 = 2) and a row nobody wrote (all zero)
+    count as differing -- what sends bench.py down resolve_chain_boundaries."""
+    import synth
+    import torch
+    P = scvod.make_params("semantickitti")
+    skip, count, cut = 5, 110, 70
+    scans = [synth.make_scan(5, 900 + k, "K64", device="cuda") for k in range(count)]
+    d = torch.cat([sc[0] for sc in scans]).contiguous()
+    offs = np.concatenate([[0], np.cumsum([len(sc[0]) for sc in scans])]).astype(np.int64)
+    poses = np.asarray([sc[2] for sc in scans], np.float32)
+    A = _tracked(scvod, P, d, offs, poses, 0, cut + skip, skip)
+    firsts_a = A.batch_track_chains()
+    exact = {int(f) % skip: A.chain_export_state(c, 1) for c, f in enumerate(firsts_a)}
+    cap = 2 * max(int(t.numel()) for t in exact.values())
+    send = torch.zeros((skip, cap), dtype=torch.uint8, device="cuda")
+    for c, f in enumerate(firsts_a):
+        A.chain_export_state_into(c, 1, send[int(f) % skip])
+    torch.cuda.synchronize()
+    for r in range(skip):  # the padded row starts with the exact record, header word 3 says "complete"
+        n = int(exact[r].numel())
+        assert torch.equal(send[r, :n], exact[r]) and int(send[r, 12:16].view(torch.int32).item()) == 1
+    recv = torch.zeros_like(send)
+    recv.copy_(send)  # (the P2P transfer)
+    lo = cut - halo_steps * skip
+    B = _tracked(scvod, P, d, offs, poses, lo, count, skip, owned_first=cut - lo)
+    firsts_b = B.batch_track_chains()
+    res_of = [(lo + int(f)) % skip for f in firsts_b]
+    want = B.batch_track_compare([exact[r] for r in res_of])
+    assert (want > 0) == (halo_steps <= 1)
+    word = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rows = [recv[r] for r in res_of]
+    st0 = B.batch_track_stats()
+    B.batch_track_compare_device(rows, word)
+    torch.cuda.synchronize()
+    assert int(word.item()) == want and B.batch_track_stats() == st0  # (the comparison alone: nothing was walked)
+    B.batch_track_compare_device(rows, word)  # ADDS to the word; the pointer table is unchanged (no re-upload)
+    torch.cuda.synchronize()
+    assert int(word.item()) == 2 * want
+    # a None pointer: that chain is not compared
+    per_chain = [B.batch_track_compare([exact[r] if k == j else None for k, r in enumerate(res_of)]) for j in range(len(res_of))]
+    assert sum(per_chain) == want
+    word.zero_()
+    B.batch_track_compare_device([None] + rows[1:], word)
+    torch.cuda.synchronize()
+    assert int(word.item()) == want - per_chain[0]
+    # a row too small for its state: the export says so in header word 3, the compare counts the chain as differing
+    small = torch.zeros((skip, 64), dtype=torch.uint8, device="cuda")
+    for c, f in enumerate(firsts_a):
+        A.chain_export_state_into(c, 1, small[int(f) % skip])
+    torch.cuda.synchronize()
+    assert [int(small[r, 12:16].view(torch.int32).item()) for r in range(skip)] == [2] * skip
+    word.zero_()
+    B.batch_track_compare_device([small[r] for r in res_of], word)
+    torch.cuda.synchronize()
+    assert int(word.item()) == len(res_of)
+    # a row nobody wrote (the sender had no state for that sub-sequence): differs too (round-5 advice)
+    word.zero_()
+    B.batch_track_compare_device([torch.zeros(cap, dtype=torch.uint8, device="cuda")] + rows[1:], word)
+    torch.cuda.synchronize()
+    assert int(word.item()) == want - per_chain[0] + 1
+    A.close()
+    B.close()
