@@ -526,6 +526,13 @@ def main():
                 "algorithmic_bytes_per_scan": path_bytes / n_sc, "algorithmic_bytes_per_step": path_bytes, "by_stage_bytes_per_scan": {k: v / n_sc for k, v in ab.items()},
                 "basis": "SURVEY 8(d) bytes of the whole path / measured ms_per_step (all kernels of a step)"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        try:  # what this hardware reaches on known bytes (tools/pmc_calibrate.py, committed under profiles/): context for `frac`, which stays against the 8 TB/s of the spec
+            cal = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_calibration.json"))
+            cs = json.load(open(os.path.join(ROOT, "profiles", cal[-1])))["summary"]
+            roof["achievable_peak"] = {"read_GBps": cs["read_ceiling_GBps_2GiB"] * world, "copy_GBps": cs["copy_ceiling_GBps_2GiB"] * world, "source": "profiles/" + cal[-1],
+                                       "frac_of_read_ceiling": roof["achieved"] / (cs["read_ceiling_GBps_2GiB"] * world)}
+        except Exception:
+            roof["achievable_peak"] = None
         pmc_total = sum(v for k, v in traffic.items() if k in kt) if traffic else None
         roof["traffic"] = pmc_total * n_sc if pmc_total else None
         roof["traffic_source"] = traffic_src

@@ -70,6 +70,16 @@ def label(k):
 
 
 LABELS.update({"k_tk_chain": "tk_chain", "k_tk_chain_cmp": "tk_chain_fix", "k_tk_chain_fix": "tk_chain_fix", "k_tk_chain_spec": "tk_chain_fix"})
+# the counters against known bytes (tools/pmc_calibrate.py -> profiles/*_pmc_calibration.json): factors and the measured ceilings
+CAL = {}
+for f in sorted(os.listdir(here)):
+    if f.endswith("_pmc_calibration.json"):
+        CAL = json.load(open(os.path.join(here, f))).get("summary", {})
+FETCH_FACTOR = float(CAL.get("fetch_factor_coalesced_16B") or 2.0)  # (gathers: the same factor, see the calibration notes)
+WRITE_FACTOR = float(CAL.get("write_factor_coalesced_16B") or 1.0)
+COPY_CEIL = float(CAL.get("copy_ceiling_GBps_2GiB") or 4600.0)
+READ_CEIL = float(CAL.get("read_ceiling_GBps_2GiB") or 6000.0)
+HBM_BOUND_GBPS = 0.6 * COPY_CEIL
 total_by = {}
 for name in ("k64", "park", "os128"):
     fp, wp = os.path.join(src, f"FETCH_SIZE_counter_collection_{name}.csv"), os.path.join(src, f"WRITE_SIZE_counter_collection_{name}.csv")
@@ -78,8 +88,9 @@ for name in ("k64", "park", "os128"):
     scans = int(open(os.path.join(src, f"pmc_scans_{name}.txt")).read().split()[0])
     F, W = load(fp), load(wp)
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py [workload] --steps 1 --warmup 0 --no-cpu --no-extras; raw values are "
-                   "KB per dispatch, bytes = KB * 1024; FETCH doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read; uncalibrated for "
-                   "gathers, so read-side numbers of gather-heavy kernels are upper bounds); a kernel launched several times per step is summed",
+                   "KB per dispatch, bytes = KB * 1024; FETCH x 2 and WRITE x 1 as calibrated on known bytes (profiles/r06_pmc_calibration.md: coalesced reads of any width AND "
+                   "random gathers -- a gather moves its whole 128-B line; an atomic without return counts 32 B on the write side only); Infinity-Cache hits are counted: this is "
+                   "L2-fabric traffic, an upper bound of HBM traffic; a kernel launched several times per step is summed",
            "workload": name, "scans_per_launch": scans, "kernels": {}}
     by, total = collections.defaultdict(float), 0.0
     # the profiled command runs its step twice (the timed region and the hipEvent attribution pass): per-step = sum / passes
@@ -88,7 +99,7 @@ for name in ("k64", "park", "os128"):
     for k in F:
         f = sum(F[k]["FETCH_SIZE"]) / passes
         w = sum(W.get(k, {}).get("WRITE_SIZE", [0.0])) / passes
-        b = (2 * f + w) * 1024
+        b = (FETCH_FACTOR * f + WRITE_FACTOR * w) * 1024
         out["kernels"][k] = {"launches_per_step": len(F[k]["FETCH_SIZE"]) / passes, "fetch_KB_raw_per_step": f, "write_KB_raw_per_step": w, "hbm_bytes_per_step_corrected": b,
                              "hbm_bytes_per_scan": b / scans}
         by[label(k)] += b / scans
@@ -139,9 +150,12 @@ if d is not None:
     n_sc = d["config"]["scans_per_rank"]
     with open(os.path.join(here, f"{tag}_kernel_table.md"), "w") as f:
         f.write(f"Per-kernel table of the K64 bench line ({n_sc} scans per step; generated by profiles/refresh.py from bench_full.json, the PMC passes and the SQ pass).\n"
-                "ms: hipEvents around the kernel, average per step of the attribution pass.  MB/scan and GB/s: the kernel's OWN HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate\n"
-                "rocprofv3 --pmc passes) over its OWN time.  issue / valu / lds / wait: shares of SQ_WAVE_CYCLES; conflicts: LDS bank conflicts per LDS instruction.  bound: hbm when\n"
-                "the kernel moves > 2.5 TB/s, lds when the LDS share > 0.05 and it waits < 0.5, issue when > 0.45 of the cycles issue, latency otherwise.\n\n")
+                "ms: hipEvents around the kernel, average per step of the attribution pass.  MB/scan and GB/s: the kernel's OWN L2-fabric bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate\n"
+                "rocprofv3 --pmc passes; factors calibrated on known bytes, Infinity-Cache hits included: an upper bound of its HBM bytes) over its OWN time.  issue / valu / lds / wait:\n"
+                "shares of SQ_WAVE_CYCLES; conflicts: LDS bank conflicts per LDS instruction.\n"
+                f"Measured ceilings of this box (tools/pmc_calibrate.py, 2 GiB sets): read {READ_CEIL:.0f} GB/s, copy (read + write) {COPY_CEIL:.0f} GB/s; spec 8000.  bound: hbm only when the kernel\n"
+                f"moves >= 0.6 x the copy ceiling = {HBM_BOUND_GBPS:.0f} GB/s; lds when the LDS share > 0.05 and it waits < 0.5; issue when > 0.45 of the cycles issue (or VALU share x resident\n"
+                "waves says so: see DESIGN 8); latency otherwise.\n\n")
         f.write("| kernel | ms / step | share | MB / scan | GB/s | issue | valu | lds | wait | conflicts | bound |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
         for name, k in d["kernels"].items():
             mb = k.get("pmc_MB_per_scan")
@@ -149,9 +163,9 @@ if d is not None:
             q = sq.get(name)
             bound = "-"
             if q:
-                bound = "hbm" if (gb or 0) > 2500 else ("lds" if q[2] > 0.05 and q[3] < 0.5 else ("issue" if q[0] > 0.45 else "latency"))
+                bound = "hbm" if (gb or 0) >= HBM_BOUND_GBPS else ("lds" if q[2] > 0.05 and q[3] < 0.5 else ("issue" if q[0] > 0.45 else "latency"))
             elif gb:
-                bound = "hbm" if gb > 2500 else "latency"
+                bound = "hbm" if gb >= HBM_BOUND_GBPS else "latency"
             f.write(f"| `{name}` | {k['avg_ms']:.3f} | {100 * k['share']:.1f} % | {('%.2f' % mb) if mb is not None else '-'} | {('%.0f' % gb) if gb else '-'} | "
                     + (" | ".join(f"{v:.2f}" for v in q[:4]) + f" | {q[4]:.1f}" if q else "- | - | - | - | -") + f" | {bound} |\n")
 print("scans/s", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "roofline frac", round(d["roofline"]["frac"], 4))
