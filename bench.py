@@ -149,8 +149,8 @@ def main():
     ap.add_argument("--track-mode", default="chain", choices=["chain", "first-order"], help="chain: the reference's sequential tracking chain (default); first-order: every pair independent")
     ap.add_argument("--chain-seg", type=int, default=0, help="steps per chain segment (0: library default)")
     ap.add_argument("--chain-warm", type=int, default=-1, help="warm-up steps in front of a segment (-1: library default)")
-    ap.add_argument("--cluster-exact", type=int, default=0, choices=[0, 1, 2],
-                    help="scans beyond the LDS clustering variant (OS128 class): 0 (default) = visiting-order model for the components the local rule does not settle, up to 4096 nodes; 1 = whatever their size; 2 = without the rule")
+    ap.add_argument("--cluster-exact", type=int, default=1, choices=[0, 1, 2, 3],
+                    help="(round 6: 1 is the library's default; 3 = 1 without helper blocks) "scans beyond the LDS clustering variant (OS128 class): 0 (default) = visiting-order model for the components the local rule does not settle, up to 4096 nodes; 1 = whatever their size; 2 = without the rule")
     ap.add_argument("--max-name-fresh", action="store_true", help="new clusters of the tracking chain get fresh numbers instead of the reference's re-used Frame::max_name (ssc.cpp:354): profiling only, the labels then differ from the reference's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (use --backend gloo: RCCL refuses two ranks on one device)")
@@ -240,7 +240,7 @@ def main():
     ctx = scvod_py.Ctx(P, max_points_total=total_pts + 1024, max_scans=n_sc, device=local)
     if args.track_mode != "chain" or args.chain_seg > 0 or args.chain_warm >= 0:
         ctx.set_track_mode(chain=args.track_mode == "chain", segment_steps=max(args.chain_seg, 0), warmup_steps=max(args.chain_warm, -1))
-    if args.cluster_exact != 0:
+    if args.cluster_exact != 1:
         ctx.set_cluster_exact(args.cluster_exact)
     if args.max_name_fresh:
         ctx.set_max_name_literal(False)
@@ -625,7 +625,7 @@ def main():
             del ctx
             torch.cuda.empty_cache()
             c2 = scvod_py.Ctx(P, max_points_total=total_pts + 1024, max_scans=n_sc, device=local)
-            if args.cluster_exact != 0:
+            if args.cluster_exact != 1:
                 c2.set_cluster_exact(args.cluster_exact)
             m2 = None if args.no_map else scvod_py.StaticMap(cells, leaf=args.map_leaf, device=local)
             ms = []

@@ -248,7 +248,11 @@ void carve(scvod_ctx* c, unsigned char* base, size_t* total) {
     A.vox_av = k.take<float>(N);
     A.vox_cov = k.take<float>(N);
     A.cc_stats = k.take<int32_t>(8);
-    A.cc_exact_max = 4096;
+    A.cc_again = k.take<int32_t>(B + 1);
+    A.cc_help = k.take<int32_t>(kCcHelpWords);
+    A.cc_help_blocks = 0;
+    A.cc_help_blocks_wanted = 1;
+    A.cc_exact_max = 0x3fffffff;  // (round 6: exact whatever the component's size is the default -- the passes are shared with helper blocks, k_cc_exact)
     A.cc_plain_rule = 1;
     A.cc_parent = k.take<int32_t>(N);
     A.cc_touched = k.take<uint8_t>(N);
@@ -1645,6 +1649,7 @@ int scvod_set_cluster_exact(scvod_ctx* c, int32_t on) {
     if (!c) return SCVOD_ERR_INVALID;
     c->A.cc_exact_max = on ? 0x3fffffff : 4096;
     c->A.cc_plain_rule = on == 2 ? 0 : 1;
+    c->A.cc_help_blocks_wanted = on == 3 ? 0 : 1;  // 3: exact, every scan's workgroup on its own (the round-5 form: A/B runs, tests of the shared rounds)
     c->clusters_valid = c->types_valid = c->tables_valid = c->track_valid = false;
     return SCVOD_OK;
 }
@@ -1663,6 +1668,30 @@ int scvod_batch_cluster_rule_stats(scvod_ctx* c, int32_t* h_out2) {
     if (!c->clusters_valid) return fail(c, SCVOD_ERR_STATE, "no clustering of the last batch");
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     HIPCHK(c, hipMemcpy(h_out2, c->A.cc_stats + 4, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return SCVOD_OK;
+}
+
+int scvod_batch_cluster_help_stats(scvod_ctx* c, int32_t* h_out2) {
+    if (!c || !h_out2) return SCVOD_ERR_INVALID;
+    if (!c->clusters_valid) return fail(c, SCVOD_ERR_STATE, "no clustering of the last batch");
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    HIPCHK(c, hipMemcpy(h_out2, c->A.cc_help, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h_out2 + 1, c->A.cc_stats + 6, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (getenv("SCVOD_CC_HELP_DUMP")) {  // development: the board of the last launch (10 ns ticks relative to the first scan block)
+        std::vector<int32_t> b(kCcHelpWords);
+        HIPCHK(c, hipMemcpy(b.data(), c->A.cc_help, b.size() * 4, hipMemcpyDeviceToHost));
+        auto t64 = [&](size_t w) { return *reinterpret_cast<long long*>(&b[w]); };
+        long long t0 = 0x7fffffffffffffffll;
+        for (int k = 0; k < b[0] && k < kCcHelpSlots; ++k) t0 = std::min(t0, t64(kCcHelpHdr + (size_t)k * kCcHelpSlotWords + 20));
+        int32_t nr = 0;
+        HIPCHK(c, hipMemcpy(&nr, c->A.cc_again, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "cc_help: %d scans handed to k_cc_exact, %d asked for help, %d past their shared passes (clocks: x10 ns after the first rounds began)\n", nr, b[0], b[1]);
+        for (int k = 0; k < b[0] && k < kCcHelpSlots; ++k) {
+            const size_t w = kCcHelpHdr + (size_t)k * kCcHelpSlotWords;
+            fprintf(stderr, "  slot %d scan %d: na %d chunks/round %d rounds %d leader chunks %d | entry +%lld rule done +%lld listed +%lld rounds start +%lld end +%lld unions end +%lld\n", k, b[w + 18], b[w + 3], b[w + 4], b[w + 19], b[w + 5],
+                    t64(w + 38) - t0, t64(w + 40) - t0, t64(w + 42) - t0, t64(w + 20) - t0, t64(w + 22) - t0, t64(w + 24) - t0);
+        }
+    }
     return SCVOD_OK;
 }
 

@@ -49,6 +49,11 @@ struct PatchRec {
 
 // Device arena of one batch.  Per-point arrays are indexed by scan_off[s] + local index;
 // per-scan arrays by s * stride.
+// board of k_cc_scan's shared exact re-clustering (scvod_k_cluster.inc, cc_help_loop): header [0] slots taken, [1] scans past their exact phase;
+// per slot: [0,1] claim word (round << 32 | next chunk), [2] chunks done by helpers, [3] listed nodes, [4] chunks per round, [6..17] six table pointers of the rounds, [26..35] five more for the passes after them, [18..25] development clocks
+constexpr int kCcHelpSlots = 256, kCcHelpHdr = 32, kCcHelpSlotWords = 64;  // (a slot = two 128-byte lines of its own)
+constexpr size_t kCcHelpWords = kCcHelpHdr + (size_t)kCcHelpSlots * kCcHelpSlotWords;
+constexpr int kCcExactBlocks = 256, kCcExactLeaders = 160;  // grid of k_cc_exact; blocks that lead a listed scan at most (the others help)
 struct Arena {
     // inputs
     const float4* pts;
@@ -118,6 +123,10 @@ struct Arena {
     int32_t* cc_stats;        // [8] per clustering call: [4] irregular runs settled by the rule, [5] the others; [0..3] scans that kept "everything found is joined" for a component, nodes of
                               //   those components (an upper bound from a sample when they are not even listed), 0, scans of the generic variant
                               //   whose z-planes are too large for the windowed search (forest in HBM)
+    int32_t* cc_again;        // [1 + B] scans k_cc_scan hands over to k_cc_exact: [0] how many, then the scans; [0] cleared per launch
+    int32_t* cc_help;         // [kCcHelpWords] board of the exact re-clustering rounds that leaders share with helper blocks (scvod_k_cluster.inc: cc_help_loop); cleared per launch
+    int32_t cc_help_blocks;   // > 0: the blocks of k_cc_exact that lead no scan help (set per launch by launch_cluster)
+    int32_t cc_help_blocks_wanted;  // what the ctx asks for (0 = leaders always work alone: tests / A-B runs)
     int32_t* cc_parent;       // [N] union-find forest over apri indices (scan-local)
     uint8_t* cc_touched;      // [N] per voxel slot: appeared in a neighbourhood
     int32_t* pt_voxel;        // [N] voxel slot of every apri point

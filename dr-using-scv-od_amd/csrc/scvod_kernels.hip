@@ -578,15 +578,25 @@ void launch_cls(const Arena& A, int s, size_t scan_base, int n_points, hipStream
     hipLaunchKernelGGL(k_cls_from_lists, dim3((n_points + 2047) / 2048), dim3(256), 0, st, A, s);
 }
 
-void launch_cluster(const DevParams& P, const Arena& A, int from_apri, hipStream_t st, TimerHook th, void* tu) {
+void launch_cluster(const DevParams& P, const Arena& A0, int from_apri, hipStream_t st, TimerHook th, void* tu) {
+    Arena A = A0;
     hipMemsetAsync(A.cc_stats, 0, 8 * sizeof(int32_t), st);
     const int B = A.n_scans;
     if (B <= 0 || A.max_scan_pts <= 0) return;
+    // k_cc_scan hands the scans with an unsettled irregular run over to k_cc_exact (cc_again, counted on the device); helper blocks there
+    // unless the ctx asks for every such scan's workgroup to work alone (scvod_set_cluster_exact(ctx, 3))
+    A.cc_help_blocks = A.cc_help_blocks_wanted > 0 ? 1 : 0;
+    hipMemsetAsync(A.cc_again, 0, sizeof(int32_t), st);
+    hipMemsetAsync(A.cc_help, 0, kCcHelpWords * sizeof(int32_t), st);
     hipFuncSetAttribute((const void*)k_cc_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcLdsBytes);
+    hipFuncSetAttribute((const void*)k_cc_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcLdsBytes);
     TH_BEGIN("cc_scan");
     hipLaunchKernelGGL(k_cc_order, dim3(1), dim3(1024), 0, st, A);
     hipLaunchKernelGGL(k_cc_scan, dim3(B), dim3(kCcThreads), kCcLdsBytes, st, P, A, from_apri);
     TH_END("cc_scan");
+    TH_BEGIN("cc_exact");
+    hipLaunchKernelGGL(k_cc_exact, dim3(kCcExactBlocks), dim3(kCcThreads), kCcLdsBytes, st, P, A, from_apri);
+    TH_END("cc_exact");
 }
 
 void launch_track(const DevParams& P, const Arena& A, const TrackJob& J, int batch_mode, hipStream_t st,

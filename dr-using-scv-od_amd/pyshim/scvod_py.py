@@ -133,6 +133,7 @@ def load_lib():
         "scvod_set_cluster_exact": (C.c_int, [vp, i32]),
         "scvod_batch_cluster_stats": (C.c_int, [vp, vp]),
         "scvod_batch_cluster_rule_stats": (C.c_int, [vp, vp]),
+        "scvod_batch_cluster_help_stats": (C.c_int, [vp, vp]),
         "scvod_set_max_name_literal": (C.c_int, [vp, i32]),
         "scvod_batch_cluster_last_name": (C.c_int, [vp, vp, i32, vp]),
         "scvod_set_chain_capacity": (C.c_int, [vp, i64]),
@@ -182,7 +183,7 @@ EXPORTED_SYMBOLS = ["scvod_params_default", "scvod_pw_params_default", "scvod_gr
                     "scvod_bin_scan", "scvod_voxelize", "scvod_pose_delta", "scvod_track_probe", "scvod_batch_process",
                     "scvod_batch_counts", "scvod_batch_fetch", "scvod_batch_cluster", "scvod_batch_fetch_clusters", "scvod_cluster",
                     "scvod_batch_cluster_types", "scvod_batch_fetch_cluster_types",
-                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_batch_cluster_rule_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_get_params", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_track_compare", "scvod_batch_track_compare_device", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
+                    "scvod_batch_track", "scvod_batch_fetch_track", "scvod_set_track_mode", "scvod_set_cluster_exact", "scvod_batch_cluster_stats", "scvod_batch_cluster_rule_stats", "scvod_batch_cluster_help_stats", "scvod_set_max_name_literal", "scvod_batch_cluster_last_name", "scvod_set_chain_capacity", "scvod_chain_workspace_bytes", "scvod_get_params", "scvod_set_track_owned", "scvod_set_track_halo", "scvod_batch_track_chains", "scvod_chain_state_bytes", "scvod_chain_export_state", "scvod_batch_track_resume", "scvod_batch_track_compare", "scvod_batch_track_compare_device", "scvod_batch_map_accumulate_range", "scvod_batch_track_stats", "scvod_batch_export_table", "scvod_batch_track_tables", "scvod_sequence_ingest",
                     "scvod_map_create", "scvod_map_destroy", "scvod_map_last_error", "scvod_map_capacity", "scvod_map_clear",
                     "scvod_pose_matrix", "scvod_batch_map_accumulate", "scvod_map_export", "scvod_map_export_parts", "scvod_map_export_parts_padded", "scvod_map_merge", "scvod_map_points",
                     "scvod_batch_timings", "scvod_set_timing", "scvod_nn_search", "scvod_nn_radius_search", "scvod_nn_search_device", "scvod_batch_voxelgrid", "scvod_voxelgrid"]
@@ -482,9 +483,10 @@ class Ctx:
         self._chk(self.lib.scvod_set_track_mode(self.h, (3 if generic_step else 1) if chain else 0, int(segment_steps), int(warmup_steps)))
 
     def set_cluster_exact(self, on=True):
-        """False / 0 (default of a context): exact visiting order for the components the local rule does not settle while they
-        have <= 4096 nodes (larger ones keep "everything found is joined" and are counted); True / 1: whatever their size;
-        2: exact without the rule"""
+        """True / 1 (default of a context since round 6): the components the local rule does not settle are clustered again in visiting
+        order whatever their size (k_cc_exact, passes shared with helper blocks); 0: only while they have <= 4096 nodes together (larger
+        ones keep "everything found is joined" and are counted: the default of rounds 3-5); 2: exact without the rule; 3: like 1, every
+        scan's workgroup on its own"""
         self._chk(self.lib.scvod_set_cluster_exact(self.h, int(on)))
 
     def batch_cluster_stats(self):
@@ -492,8 +494,10 @@ class Ctx:
         self._chk(self.lib.scvod_batch_cluster_stats(self.h, out.ctypes.data_as(C.c_void_p)))
         r2 = np.zeros(2, np.int32)
         self._chk(self.lib.scvod_batch_cluster_rule_stats(self.h, r2.ctypes.data_as(C.c_void_p)))
+        h2 = np.zeros(2, np.int32)
+        self._chk(self.lib.scvod_batch_cluster_help_stats(self.h, h2.ctypes.data_as(C.c_void_p)))
         return dict(scans_approximated=int(out[0]), nodes_concerned=int(out[1]), exact=bool(out[2]), scans_on_hbm_forest=int(out[3]),
-                    runs_settled_by_rule=int(r2[0]), runs_clustered_again=int(r2[1]))
+                    runs_settled_by_rule=int(r2[0]), runs_clustered_again=int(r2[1]), scans_that_shared_their_rounds=int(h2[0]), chunks_taken_by_helpers=int(h2[1]))
 
     def set_max_name_literal(self, literal=True):
         """ssc.cpp:354 keeps the LAST USED running number in Frame::max_name; False = fresh numbers (rounds 1-3)"""

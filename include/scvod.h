@@ -389,17 +389,24 @@ int scvod_batch_cluster(scvod_ctx* ctx, void* stream, int32_t sync);
  * per irregular run -- do the cells around its triple and around its key's own cell settle that every find sticks? (the
  * statement: csrc/scvod_k_cluster.inc cc_run_is_plain, pinned against the reference loop by
  * tests/test_irregular_runs_rule.py) -- and model the visiting order exactly for the components of the runs it does not
- * settle (about one 128-beam scan in thirty has such a run).  on = 0 (the default): while those components have <= 4096
- * nodes together; beyond that the scan keeps "everything found is joined" for them (the reference's partition then
- * refines the device's) and is counted.  on = 1: whatever their size -- tens of milliseconds for a component of tens of
- * thousands of nodes, on the one workgroup that owns the scan (a batch waits for its slowest scan: DESIGN.md section 7b).
+ * settle (about one 128-beam scan in thirty has such a run): such a scan is handed to a second kernel (k_cc_exact) whose
+ * workgroups cluster it again from scratch and SHARE the passes over an affected component -- the listed voxels of every node, the
+ * Jacobi rounds of the labelling times, the joins -- with the blocks of that kernel that lead no scan (round 6).
+ * on = 1 (the default since round 6): whatever the component's size (4-6 ms per 1000 128-beam scans; nothing for scans that fit the
+ * LDS).  on = 0 (the default of rounds 3-5): while those components have <= 4096 nodes together; beyond that the scan keeps
+ * "everything found is joined" for them (the reference's partition then refines the device's) and is counted.
  * on = 2: exact without the rule (every component with an irregular run is clustered again: what the rule is
- * tested against).  scvod_batch_cluster_stats: h_out4 = {scans of the last clustering that kept the approximation, nodes
- * of the components concerned (upper bound), 1 when the bound is lifted (on = 1, 2), scans beyond the LDS whose z-planes were
+ * tested against).  on = 3: like 1, every scan's workgroup on its own (the round-5 form of on = 1: tens of milliseconds for a
+ * component of tens of thousands of nodes; A/B runs and the test of the shared passes).
+ * scvod_batch_cluster_stats: h_out4 = {scans of the last clustering that kept the approximation, nodes
+ * of the components concerned (upper bound), 1 when the bound is lifted (on = 1, 2, 3), scans beyond the LDS whose z-planes were
  * too large for the windowed search and were joined on a forest in HBM instead (slower, same result)};
  * scvod_batch_cluster_rule_stats: h_out2 = {irregular runs of those larger scans the rule settled, runs whose component
  * was clustered again}.  Both synchronise. */
 int scvod_set_cluster_exact(scvod_ctx* ctx, int32_t on);
+/* scvod_batch_cluster_help_stats: h_out2 = {workgroups of the last clustering that published their passes, chunks (1024 nodes of
+ * one pass) that helper blocks took}.  Synchronises. */
+int scvod_batch_cluster_help_stats(scvod_ctx* ctx, int32_t* h_out2);
 int scvod_batch_cluster_stats(scvod_ctx* ctx, int32_t* h_out4);
 int scvod_batch_cluster_rule_stats(scvod_ctx* ctx, int32_t* h_out2);
 /* Frame::max_name.  clusterAndCreateFrame ends with `frame_ssc.max_name = cluster_name ++;` (ssc.cpp:354): the frame keeps

@@ -287,7 +287,7 @@ def _in_grid(oracle, P, apri):
 
 
 @pytest.mark.parametrize("seed", [77, 207])
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle, mode, seed):
     """sixty seeded random clouds on random grids, from a handful of voxels to more than the all-in-LDS variant holds (both
     variants of the clustering kernel).  (a) Their in-grid points alone: the device partition IS the reference's.  (b) With
@@ -297,8 +297,9 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle, mode, seed):
     where the two find each other; an aliased voxel is found by points it does not find.  The kernel models that visiting
     order: exactly for every cloud whose tables fit the LDS; the generic (HBM) variant asks a local
     rule per irregular run first (cc_run_is_plain) and models the order for the components of the runs the rule does not
-    settle -- mode 1 (scvod_set_cluster_exact(ctx, 1)): whatever their size; mode 2: without the rule (every such component);
-    both must give the reference's partition for every cloud, with no scan counted.  Mode 0, the default, stops at 4096
+    settle -- mode 1 (the default since round 6; k_cc_exact, passes shared with helper blocks) and mode 3 (the same, every scan's
+    workgroup alone): whatever their size; mode 2: without the rule (every such component);
+    all must give the reference's partition for every cloud, with no scan counted.  Mode 0, the default until round 5, stops at 4096
     nodes: beyond that it keeps "everything found is joined" -- the reference's partition must then refine the device's,
     the points that differ stay below 10 % of such (adversarial) clouds, and scvod_batch_cluster_stats counts the scan."""
     # (seed 207: case 9 holds a failing run whose home voxel -- settled on its own, in another component -- must be clustered
@@ -312,8 +313,7 @@ def test_random_clouds_on_random_grids_cluster_fuzz(scvod, oracle, mode, seed):
         if len(apri) == 0:
             continue
         ctx = scvod.Ctx(P, max_points_total=len(apri) + 64, max_scans=1)
-        if mode != 0:
-            ctx.set_cluster_exact(mode)
+        ctx.set_cluster_exact(mode)  # (1 is the library's default since round 6; 0 was until round 5)
         reg = apri[_in_grid(oracle, P, apri)].copy()
         generic += len(np.unique(reg["voxel_idx"])) > 14336
         got = ctx.cluster(reg)
@@ -942,12 +942,12 @@ def test_realistic_scans_with_their_irregular_returns_agree(scvod, oracle, kind,
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 def test_os128_scans_with_runs_the_local_rule_does_not_settle(scvod, oracle, mode):
     """two synthetic 128-beam scans (729, 734 of the sequence) hold an irregular return whose finds the cells around it do
     not settle (two listed voxels that do not find each other, both still unvisited): its component -- a facade of tens of
-    thousands of points -- is clustered again with the visiting order when the bound is lifted (mode 1: the reference's
-    partition), and kept as found + counted by default (mode 0: the reference's partition refines the device's); scan 700
+    thousands of points -- is clustered again with the visiting order (mode 1, the default, and mode 3: the reference's
+    partition), and kept as found + counted in the bounded form (mode 0: the reference's partition refines the device's); scan 700
     is settled by the rule alone in both modes"""
     import torch
     import synth
@@ -955,13 +955,16 @@ def test_os128_scans_with_runs_the_local_rule_does_not_settle(scvod, oracle, mod
     scans = [synth.make_scan(5, i, "OS128")[0].numpy() for i in (729, 700, 734)]
     offs = np.concatenate([[0], np.cumsum([len(x) for x in scans])]).astype(np.int32)
     ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=3)
-    if mode:
-        ctx.set_cluster_exact(mode)
+    ctx.set_cluster_exact(mode)  # (1: the default since round 6 -- k_cc_exact with helper blocks; 3: without them; 0: the bounded form)
     ctx.batch_process(torch.from_numpy(np.concatenate(scans)).cuda(), offs)
     ctx.batch_cluster()
     st = ctx.batch_cluster_stats()
     assert st["runs_clustered_again"] >= 2 and st["runs_settled_by_rule"] >= 100
     assert st["scans_approximated"] == (0 if mode else 2)
+    if mode == 1:  # components of tens of thousands of nodes: their passes went on the board and helper blocks took chunks of them
+        assert st["scans_that_shared_their_rounds"] == 2 and st["chunks_taken_by_helpers"] > 0
+    else:
+        assert st["scans_that_shared_their_rounds"] == 0
     for s in range(3):
         r = ctx.batch_fetch(s)
         got = ctx.batch_fetch_clusters(s, r["n_apri"])
