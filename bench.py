@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--chain-seg", type=int, default=0, help="steps per chain segment (0: library default)")
     ap.add_argument("--chain-warm", type=int, default=-1, help="warm-up steps in front of a segment (-1: library default)")
     ap.add_argument("--cluster-exact", type=int, default=1, choices=[0, 1, 2, 3],
-                    help="(round 6: 1 is the library's default; 3 = 1 without helper blocks) "scans beyond the LDS clustering variant (OS128 class): 0 (default) = visiting-order model for the components the local rule does not settle, up to 4096 nodes; 1 = whatever their size; 2 = without the rule")
+                    help="scans beyond the LDS clustering variant (OS128 class): 1 (the library's default since round 6) = visiting-order model for the components the local rule does not settle, whatever their size (k_cc_exact, passes shared with helper blocks); 0 = up to 4096 nodes (rounds 3-5); 2 = without the rule; 3 = 1 without helper blocks")
     ap.add_argument("--max-name-fresh", action="store_true", help="new clusters of the tracking chain get fresh numbers instead of the reference's re-used Frame::max_name (ssc.cpp:354): profiling only, the labels then differ from the reference's")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (use --backend gloo: RCCL refuses two ranks on one device)")
