@@ -976,6 +976,56 @@ def test_os128_scans_with_runs_the_local_rule_does_not_settle(scvod, oracle, mod
             assert len(np.unique(pairs[:, 0])) == len(pairs), f"scan {s}: a reference cluster is split on the device"
     ctx.close()
 
+# scans of the OS128 bench job (seq 5, indices 0..999) whose clustering kept "everything found is joined" for a component of more than 4096
+# nodes until round 5 (tools/cluster_help_check.py with SCVOD_CC_HELP_DUMP=1 lists them: 7, 51, 69, 128, 185, 220, 303, 314, 353, 362, 384, 402,
+# 414, 444, 532, 535, 541, 598, 645, 652, 718, 735, 798, 805, 810, 821, 826, 908, 953 hold a listed component of 6.5 k - 42.6 k nodes)
+OS128_OFFENDERS_300_420 = (303, 314, 353, 362, 384, 402, 414)
+
+
+def test_os128_batch_that_contains_the_known_offenders(scvod, oracle):
+    """round-5 verdict, next #1: a batch of 120 consecutive 128-beam scans of the bench job (indices 300..419) that CONTAINS seven of the
+    scans the bounded form approximated (components of 6.5 k - 38 k nodes around an irregular run the local rule does not settle).  With the
+    default (k_cc_exact: such scans clustered again, the passes over a large component shared with helper blocks) no scan is counted, the
+    seven partitions are the reference loop's point for point (so are thirteen of the other scans), and the whole batch equals the run
+    in which every scan's workgroup works alone (mode 3)."""
+    import torch
+    import synth
+    P = _params(scvod, "os128_fine")
+    first, count = 300, 120
+    parts, offs = [], [0]
+    for k in range(count):
+        p, _, _ = synth.make_scan(5, first + k, "OS128", device="cuda")
+        parts.append(p)
+        offs.append(offs[-1] + p.shape[0])
+    pts = torch.cat(parts).contiguous()
+    offs = np.asarray(offs, np.int32)
+    ctx = scvod.Ctx(P, max_points_total=int(offs[-1]) + 64, max_scans=count)
+    ctx.batch_process(pts, offs)
+    cnt = ctx.batch_counts()
+    ctx.batch_cluster()
+    st = ctx.batch_cluster_stats()
+    assert st["exact"] and st["scans_approximated"] == 0 and st["nodes_concerned"] == 0
+    assert st["runs_clustered_again"] >= len(OS128_OFFENDERS_300_420)
+    assert st["scans_that_shared_their_rounds"] >= len(OS128_OFFENDERS_300_420) and st["chunks_taken_by_helpers"] > 0
+    got = [ctx.batch_fetch_clusters(s, int(cnt[s, 4])) for s in range(count)]
+    check = sorted(set(i - first for i in OS128_OFFENDERS_300_420) | set(range(0, count, 9)))
+    for s in check:
+        r = ctx.batch_fetch(s)
+        can = _canonical(oracle.cluster(P, r["apri"])[0])
+        assert np.array_equal(got[s], can), f"scan {first + s}"
+    ctx.set_cluster_exact(3)
+    ctx.batch_cluster()
+    st3 = ctx.batch_cluster_stats()
+    assert st3["scans_approximated"] == 0 and st3["scans_that_shared_their_rounds"] == 0
+    for s in range(count):
+        assert np.array_equal(ctx.batch_fetch_clusters(s, int(cnt[s, 4])), got[s]), f"scan {first + s}: shared passes vs alone"
+    ctx.set_cluster_exact(0)  # the bounded form of rounds 3-5 counts exactly these scans
+    ctx.batch_cluster()
+    st0 = ctx.batch_cluster_stats()
+    assert st0["scans_approximated"] == len(OS128_OFFENDERS_300_420)
+    ctx.close()
+
+
 
 def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
     """more apri points than the generic variant's LDS bit arrays hold (262 144): start bits / prefixes in arena scratch,
