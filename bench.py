@@ -4,7 +4,7 @@
 Workload at one GPU (BASELINE.json configs[1]): a SemanticKITTI-seq-05-shaped sequence -- 2761 scans of a 64-beam sensor,
 ~118 k returns per scan, config/semantickitti.yaml parameters -- synthetic (no dataset exists in this environment),
 resident in HBM before the timed region starts.  With N GPUs the SAME job is cut over the ranks (strong scaling, the
-default): the scans of the sequence in N contiguous blocks, each with a halo of 12 x skip_ scans in front for the warm-up
+default): the scans of the sequence in N contiguous blocks, each with a halo of 10 x skip_ scans in front for the warm-up
 of the tracking chain (pyshim/shard.py plan_split / plan_job_split).  The reference tracks frame i against frame i + 1 in
 order and every call mutates the successor (SSC::segDF, ssc.cpp:1449-1451): the chain's state at a cut is exported by the
 rank before, compared with what the halo's warm-up produced and walked again only where it differs.  `--kitti
@@ -139,11 +139,11 @@ def main():
     ap.add_argument("--no-cpu-all", action="store_true", help="skip the multi-threaded CPU context number")
     ap.add_argument("--no-quality", action="store_true", help="skip the PR/RR comparison")
     ap.add_argument("--no-extras", action="store_true", help="skip the separately reported stages (VoxelGrid, ingest): profiling runs")
-    ap.add_argument("--split-sequence", action="store_true", help="strong scaling: ONE sequence of --scans scans over the ranks (contiguous blocks, a halo of 12 x skip scans for the tracking chain's warm-up, the chain's state handed from rank to rank: pyshim/shard.py plan_split)")
+    ap.add_argument("--split-sequence", action="store_true", help="strong scaling: ONE sequence of --scans scans over the ranks (contiguous blocks, a halo of 10 x skip scans for the tracking chain's warm-up, the chain's state handed from rank to rank: pyshim/shard.py plan_split)")
     ap.add_argument("--replicate", action="store_true", help="N > 1: every rank runs a sequence of its own (weak scaling: rounds 1-3) instead of cutting ONE sequence over the ranks (the default at N > 1)")
     ap.add_argument("--kitti", action="store_true", help="the job is SemanticKITTI seq 00-10 at their real lengths (BASELINE configs[3], 23 201 scans: needs the memory of several GPUs); with --split-sequence the sequences are cut where the load says")
     ap.add_argument("--kitti-scale", default="1", help="with --kitti: every sequence length times this fraction (e.g. 1/32: a dry run of configs[3]'s 11-sequence plan that fits one GPU)")
-    ap.add_argument("--split-halo", type=int, default=12, help="warm-up steps of the halo in front of a rank's block (--split-sequence)")
+    ap.add_argument("--split-halo", type=int, default=10, help="warm-up steps of the halo in front of a rank's block (--split-sequence); 10 since round 6 (12 before): on the eight-rank K64 jobs no chain is walked again at a cut down to 8 steps, from 6 on the warm-up misses states (profiles/r06_halo_sweep.txt)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short PARK / OS128 sub-runs that the default invocation appends under extras.configs")
     ap.add_argument("--no-map", action="store_true", help="leave the static map out of the step (profiling)")
     ap.add_argument("--track-mode", default="chain", choices=["chain", "first-order"], help="chain: the reference's sequential tracking chain (default); first-order: every pair independent")

@@ -87,7 +87,7 @@ def test_two_sequences_cut_over_three_ranks(tmp_path):
 
 
 def test_k64_sequence_over_two_ranks_with_the_default_halo(tmp_path):
-    """the KITTI stride (five interleaved chains) cut in two with the default halo of 12 steps: the warm-up reproduces every
+    """the KITTI stride (five interleaved chains) cut in two with the default halo of 10 steps: the warm-up reproduces every
     chain's boundary state (nothing is walked again: the ranks' comparison round is the whole exchange) and the job equals
     the one-rank run"""
     one, m1 = _run(str(tmp_path), "one", ["--gpus", "1", "--scans", "170", "--kind", "K64", "--preset", "semantickitti"])
@@ -113,7 +113,7 @@ def _run_k64(tmp, name, extra, timeout=1500):
 
 
 def test_one_k64_sequence_over_eight_ranks(tmp_path):
-    """The driver's `bench.py --gpus 8` job (ONE sequence cut over eight ranks, default halo of 12 steps, the KITTI stride of five
+    """The driver's `bench.py --gpus 8` job (ONE sequence cut over eight ranks, default halo of 10 steps, the KITTI stride of five
     interleaved chains) driven through the device path before the first 8-GPU run: eight gloo ranks on one device, 30 own scans
     each + a halo of 60 + one successor per chain.  Per-scan dynamic points and the merged map equal the one-rank run bit for
     bit; the line reports how many chains were walked again at a cut (none with the full halo)."""
