@@ -1688,8 +1688,8 @@ int scvod_batch_cluster_help_stats(scvod_ctx* c, int32_t* h_out2) {
         fprintf(stderr, "cc_help: %d scans handed to k_cc_exact, %d asked for help, %d past their shared passes (clocks: x10 ns after the first rounds began)\n", nr, b[0], b[1]);
         for (int k = 0; k < b[0] && k < kCcHelpSlots; ++k) {
             const size_t w = kCcHelpHdr + (size_t)k * kCcHelpSlotWords;
-            fprintf(stderr, "  slot %d scan %d: na %d chunks/round %d rounds %d leader chunks %d | entry +%lld rule done +%lld listed +%lld rounds start +%lld end +%lld unions end +%lld\n", k, b[w + 18], b[w + 3], b[w + 4], b[w + 19], b[w + 5],
-                    t64(w + 38) - t0, t64(w + 40) - t0, t64(w + 42) - t0, t64(w + 20) - t0, t64(w + 22) - t0, t64(w + 24) - t0);
+            fprintf(stderr, "  slot %d scan %d: na %d chunks/round %d rounds %d leader chunks %d | entry +%lld rule done +%lld listed +%lld rounds start +%lld end +%lld unions end +%lld scan done +%lld\n", k, b[w + 18], b[w + 3], b[w + 4], b[w + 19], b[w + 5],
+                    t64(w + 38) - t0, t64(w + 40) - t0, t64(w + 42) - t0, t64(w + 20) - t0, t64(w + 22) - t0, t64(w + 24) - t0, t64(w + 54) - t0);
         }
     }
     return SCVOD_OK;
