@@ -1447,7 +1447,10 @@ int scvod_batch_track(scvod_ctx* c, const float* h_T, const int32_t* h_next_scan
                 c->chain_geom_pool = c->chain_pool_points;
                 c->chain_ws_clean = false;
             }
-            const size_t need = (size_t)nw * c->chain_geom.stride;
+            // (the plan cut by measured time -- the stream's second or third batch -- has up to one walker per CU: room for them from the first call,
+            //  or that batch would stop the device, free, allocate and clear ~18 GB again: 3.7 ms of a one-shot job's second step, round 6)
+            const int nw_room = (c->chain_seg <= 0 && c->chain_balance && nw < c->n_cu) ? c->n_cu : nw;
+            const size_t need = (size_t)nw_room * c->chain_geom.stride;
             if (need > c->chain_ws_bytes) {  // first call / larger job: the only allocation, outside any steady-state step
                 HIPCHK(c, hipDeviceSynchronize());
                 if (c->chain_ws) hipFree(c->chain_ws);
