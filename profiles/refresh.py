@@ -50,7 +50,7 @@ def load(path):
 LABELS = {"k_pw_classify": "pw_classify", "k_pw_offsets": "pw_offsets", "k_pw_scatter": "pw_scatter", "k_pw_fit": "pw_fit", "k_emit_offsets": "emit_offsets",
           "k_emit": "emit", "k_vx_partition": "vx_partition", "k_vx_final_offsets": "vx_final_offsets",
           "k_vx_final": "vx_final", "k_pw_sort_wave": "pw_sort_wave", "k_cc_scan": "cc_scan", "k_tk_init": "tk_init", "k_tk_probe": "tk_probe", "k_tk_dyn": "tk_dyn",
-          "k_map_accumulate": "map_accumulate"}
+          "k_map_accumulate": "map_accumulate", "k_cc_exact": "cc_exact", "k_cc_order": "cc_scan"}
 
 
 def label(k):
