@@ -11,8 +11,9 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
+GENERATED = ("_bench_", "_rocprofv3_kernel_stats_", "_pmc_traffic_", "_sq_pmc_summary", "_kernel_phases", "_kernel_table")
 for f in os.listdir(here):
-    if f.startswith(tag + "_") and not f.endswith(".md"):  # (hand-written notes of the round stay)
+    if f.startswith(tag + "_") and any(g in f for g in GENERATED):  # (only what this script writes: notes, calibration and sweeps of the round stay)
         os.remove(os.path.join(here, f))
 
 
