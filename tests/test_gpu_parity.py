@@ -1025,6 +1025,48 @@ def test_os128_batch_that_contains_the_known_offenders(scvod, oracle):
     assert st0["scans_approximated"] == len(OS128_OFFENDERS_300_420)
     ctx.close()
 
+def _big_cloud(rng):
+    """120-250 k points on a disc of 30 m, coarse cells (several points per voxel): a ground sheet and walls that form components of tens of
+    thousands of voxels, a handful of returns at polar angle exactly 0 (sector index -1) inside them (tools/cluster_shared_fuzz.py)"""
+    n = int(rng.integers(120000, 250000))
+    kw = dict(range_res=float(rng.choice([0.4, 0.8])), sector_res=float(rng.choice([1.2, 2.4])), azimuth_res=float(rng.choice([2.0, 4.0])))
+    kind = rng.random(n)
+    r = 30.0 * np.sqrt(rng.uniform(0.0003, 1.0, n))
+    th = rng.uniform(0, 2 * np.pi, n)
+    x = np.stack([r * np.cos(th), r * np.sin(th), rng.uniform(-3, 10, n), rng.uniform(0, 255, n)], 1)
+    wall = kind < 0.35
+    x[wall, 0] = np.round(x[wall, 0] / 8) * 8 + rng.normal(0, 0.04, wall.sum())
+    disc = (kind >= 0.35) & (kind < 0.75)
+    x[disc, 2] = -1.7 + rng.normal(0, 0.03, disc.sum())
+    few = rng.choice(np.nonzero(disc | wall)[0], size=int(rng.integers(1, 12)), replace=False)
+    x[few, 1] = 0.0
+    x[few, 0] = np.abs(x[few, 0])
+    return kw, x.astype(np.float32)
+
+
+def test_shared_exact_reclustering_on_large_random_clouds(scvod, oracle):
+    """the passes k_cc_exact shares with its helper blocks (rows, Jacobi rounds, q's, unions over a claim board) on adversarial input: ten
+    large random clouds of the generic variant whose giant components (30-60 k voxels) hold irregular returns, clustered without the local
+    rule (mode 2: every such component goes through the visiting-order model) -- the reference loop's partition point for point, most of
+    them with helper blocks at work.  (Development sweep: 150 clouds, five seeds, modes 1 and 2, 87 of them shared: 0 differ.)"""
+    rng = np.random.default_rng(1)
+    shared = chunks = 0
+    for case in range(10):
+        kw, x = _big_cloud(rng)
+        P = scvod.make_params("semantickitti", **kw)
+        apri = oracle.bin(P, x, case % 3 != 0)["apri"]
+        ctx = scvod.Ctx(P, max_points_total=len(apri) + 64, max_scans=1)
+        ctx.set_cluster_exact(2)
+        got = ctx.cluster(apri)
+        st = ctx.batch_cluster_stats()
+        assert st["scans_approximated"] == 0
+        assert np.array_equal(_canonical(got), _canonical(oracle.cluster(P, apri)[0])), f"case {case}: {kw} {st}"
+        shared += st["scans_that_shared_their_rounds"]
+        chunks += st["chunks_taken_by_helpers"]
+        ctx.close()
+    assert shared >= 5 and chunks > 1000
+
+
 
 
 def test_cluster_partition_of_a_scan_beyond_the_lds_bit_arrays(scvod, oracle):
