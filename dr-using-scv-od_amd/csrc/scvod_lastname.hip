@@ -1326,7 +1326,7 @@ __device__ void ln_scan(const DevParams& P, const Arena& A, int s, unsigned char
         if (tid == 0) {
             state[0] = n_mk, state[1] = L.n_irr, state[2] = L.n_xs, state[3] = L.n_names;
             if (cnt > kLnCapHugeNodes) {
-                outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = 0;
+                outp[0] = outp[1] = -1, outp[2] = 1, outp[3] = cnt;  // (undetermined: the fourth word reports how many nodes the set holds)
                 atomicAdd(&A.ln_stats[0], 1);
             } else {
                 int32_t* list = redo + (size_t)(cnt <= kLnCapTinyNodes ? 0 : (cnt <= kLnCapSmallNodes ? 1 : (cnt <= kLnCapBigNodes ? 2 : 3))) * (A.n_scans + 1);

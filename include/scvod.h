@@ -419,7 +419,8 @@ int scvod_batch_cluster_rule_stats(scvod_ctx* ctx, int32_t* h_out2);
  * that could carry it was erased by the bounding-box refine: such a cluster is no cluster any more and the pass does not walk it),
  * lowest voxel slot whose first point belongs to it or -1, status, events replayed}; status 0 = exact; 1 = the classes
  * that had to be replayed hold more than 32 767 voxels together (node numbers are 16-bit in the replay's lists; up to 8192 the
- * tables live in LDS, beyond that in arena scratch: the facades of a 128-beam scan) or do not fit the scan's scratch: reported as "none"; 2 = more than 256 points with
+ * tables live in LDS, beyond that in arena scratch: the facades of a 128-beam scan) or do not fit the scan's scratch: reported as "none"
+ * (the fourth word then holds the number of voxels the set has, when the triage pass already knew: 33-54 k on the 128-beam bench job); 2 = more than 256 points with
  * an index triple outside the grid: reported as "none".  h_stats4 (optional) = {scans with status 1, with status 2, 0, 0}. */
 int scvod_set_max_name_literal(scvod_ctx* ctx, int32_t literal);
 int scvod_batch_cluster_last_name(scvod_ctx* ctx, int32_t* h_out4, int32_t cap_scans, int32_t* h_stats4);

@@ -17,3 +17,5 @@ ctx.batch_cluster()
 ln, st = ctx.batch_cluster_last_name(count)
 print(kind, first, count, stride, st, "status histogram", np.bincount(ln[:, 2], minlength=4).tolist())
 ctx.close()
+bad = np.nonzero(ln[:, 2] != 0)[0]
+print("undetermined scans (index in the sample: nodes of the set that would have to be followed):", {int(first + b * stride): int(ln[b, 3]) for b in bad})
