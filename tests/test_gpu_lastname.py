@@ -97,6 +97,36 @@ def test_chain_with_the_literal_max_name(scvod, oracle, kind, preset, skip, coun
     ctx.close()
 
 
+def test_chain_across_scans_whose_max_name_stays_undetermined(scvod, oracle):
+    """The ONE limit that is still counted at bench size (README): six consecutive 128-beam scans of the bench job (223 .. 228) whose max_name
+    could only be settled by following classes of 46-50 k voxels together -- more than the 32 767 nodes the largest pass holds.  The device
+    reports them (status 1, the set's size in the fourth word) and the chain hands out a fresh number there: its labels equal the literal
+    chain's with exactly that substitution, and the test measures what the substitution costs against the reference's own reading (the oracle
+    knows which cluster carries the number in every scan)."""
+    kind, preset, first, count = "OS128", "os128_fine", 216, 20
+    P, ctx, d, offs, poses = _batch(scvod, preset, kind, 5, first, count, 1)
+    res = [ctx.batch_fetch(s) for s in range(count)]
+    names = [ctx.batch_fetch_clusters(s, res[s]["n_apri"]) for s in range(count)]
+    types = [ctx.batch_fetch_cluster_types(s, res[s]["n_apri"], car_label=2, other_label=1) for s in range(count)]
+    ln, st = ctx.batch_cluster_last_name(count)
+    unknown = ln[:, 2] != 0
+    assert [first + int(s) for s in np.nonzero(unknown)[0]] == [223, 224, 225, 226, 227, 228] and st["unknown_too_large"] == 6 and st["unknown_irregular"] == 0
+    assert all(32767 < int(ln[s, 3]) <= 65534 for s in np.nonzero(unknown)[0])
+    T = np.zeros((count, 12), np.float32)
+    for s in range(count - 1):
+        T[s] = ctx.pose_delta(poses[s], poses[s + 1])
+    ctx.batch_track(T)
+    assert ctx.batch_track_stats()["error_bits"] == 0
+    got = np.concatenate([ctx.batch_fetch_track(s)["pt_dyn"] for s in range(count)])
+    with_fresh, _ = oracle.reference_chain(P, res, names, types, poses, unknown=unknown)
+    assert np.array_equal(got, with_fresh), f"{int((got != with_fresh).sum())} bytes differ from the literal chain with fresh numbers in the undetermined scans"
+    literal, _ = oracle.reference_chain(P, res, names, types, poses)
+    differ = int((got != literal).sum())
+    print(f"undetermined max_name in 6 of {count} scans: {differ} of {len(got)} per-point bytes differ from the reference's own reading")
+    assert differ <= len(got) // 1000  # (measured: see DESIGN.md section 2)
+    ctx.close()
+
+
 @pytest.mark.parametrize("kind,preset,seq,idx", [("K64", "semantickitti", 5, 77), ("PARK", "parkinglot", 3, 9), ("K64", "semantickitti", 5, 1201)])
 def test_last_name_with_index_triples_outside_the_grid(scvod, oracle, kind, preset, seq, idx):
     """returns at polar angle exactly 0 (sector index -1) alias onto another cell's voxel key, list nine cells instead of 27 and are
