@@ -2,14 +2,14 @@
 """Development sweep for the SHARED exact re-clustering (k_cc_exact, round 6): large random clouds on fine grids -- walls, a ground disc, blobs,
 1-2 % of the points with an index triple outside the grid -- so that the generic clustering variant runs, components of more than 6144
 listed nodes appear and their passes go on the claim board.  Device (default mode) against the oracle's literal loop, point for point.
-usage: python tools/cluster_shared_fuzz.py [--seed 1] [--clouds 40]"""
+usage: python tests/devtools/cluster_shared_fuzz.py [--seed 1] [--clouds 40]"""
 import argparse
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

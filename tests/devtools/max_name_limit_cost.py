@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """What the one counted limit costs: the 20 scans of the 1000-scan OS128 bench job whose Frame::max_name stays undetermined (the chain hands out
 a fresh number there) -- per-point dynamic bytes of the device chain against the oracle's literal chain that KNOWS which cluster carries the
-number, over a window of consecutive scans around every group of them.  usage (GPU box): python tools/max_name_limit_cost.py"""
+number, over a window of consecutive scans around every group of them.  usage (GPU box): python tests/devtools/max_name_limit_cost.py"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "dr-using-scv-od_amd", "pyshim"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_py

@@ -1027,7 +1027,7 @@ def test_os128_batch_that_contains_the_known_offenders(scvod, oracle):
 
 def _big_cloud(rng):
     """120-250 k points on a disc of 30 m, coarse cells (several points per voxel): a ground sheet and walls that form components of tens of
-    thousands of voxels, a handful of returns at polar angle exactly 0 (sector index -1) inside them (tools/cluster_shared_fuzz.py)"""
+    thousands of voxels, a handful of returns at polar angle exactly 0 (sector index -1) inside them (tests/devtools/cluster_shared_fuzz.py)"""
     n = int(rng.integers(120000, 250000))
     kw = dict(range_res=float(rng.choice([0.4, 0.8])), sector_res=float(rng.choice([1.2, 2.4])), azimuth_res=float(rng.choice([2.0, 4.0])))
     kind = rng.random(n)
